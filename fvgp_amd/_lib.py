@@ -1,0 +1,230 @@
+"""ctypes binding of libfvgp_hip.so (include/fvgp_hip.h) -- the only door into the HIP kernels.
+
+There is no CPU fallback: if the shared library is missing or a call fails, this module
+raises.  `build()` compiles the library in-tree with hipcc for gfx950 (works without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libfvgp_hip.so")
+
+KERNEL_IDS = {"rbf_ard": 0, "matern32_ard": 1, "matern52_ard": 2,
+              "rbf_iso": 3, "matern32_iso": 4, "matern52_iso": 5}
+FULL, LOWER = 0, 1
+PAD_NONE, PAD_IDENTITY, PAD_ZERO = 0, 1, 2
+TILE = 128
+MAX_RHS_VEC = 8
+
+# every symbol include/fvgp_hip.h declares (tests check the library exports each of them)
+SYMBOLS = [
+    "fvgp_hip_version", "fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_create",
+    "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
+    "fvgp_hip_potrf", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
+    "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_posterior", "fvgp_hip_gemm",
+    "fvgp_hip_mfma_selftest", "fvgp_hip_symmetrize",
+]
+
+
+class HipExtensionError(RuntimeError):
+    """The native library is missing, failed to load, or a call into it failed."""
+
+
+def build(force=False, verbose=False):
+    """Compile fvgp_amd/csrc/*.hip into libfvgp_hip.so (hipcc --offload-arch=gfx950)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise HipExtensionError("building libfvgp_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def pad128(n):
+    return (int(n) + TILE - 1) // TILE * TILE
+
+
+def lib():
+    """Load (once) and return the ctypes library with argtypes set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionError(
+            f"{LIB_PATH} not found. The HIP extension is the product path and has no fallback; "
+            f"build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {CSRC}`.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipExtensionError(f"cannot load {LIB_PATH}: {e}") from e
+    c_i, c_l, c_d, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+    P_d = ctypes.POINTER(ctypes.c_double)
+    P_i = ctypes.POINTER(ctypes.c_int)
+    L.fvgp_hip_version.restype = c_i
+    L.fvgp_hip_last_error_string.restype = ctypes.c_char_p
+    L.fvgp_hip_padded_dim.restype = c_l
+    L.fvgp_hip_padded_dim.argtypes = [c_l]
+    L.fvgp_hip_create.argtypes = [ctypes.POINTER(c_p), c_i, c_p]
+    L.fvgp_hip_destroy.argtypes = [c_p]
+    L.fvgp_hip_sync.argtypes = [c_p]
+    L.fvgp_hip_set_option.argtypes = [c_p, ctypes.c_char_p, c_l]
+    L.fvgp_hip_get_profile.argtypes = [c_p, P_d]
+    L.fvgp_hip_kmat.argtypes = [c_p, c_i, c_p, c_l, c_p, c_l, c_i, P_d, c_i, c_p, c_p, c_l, c_i, c_i]
+    L.fvgp_hip_potrf.argtypes = [c_p, c_p, c_l, c_l, P_i]
+    L.fvgp_hip_potrs.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
+    L.fvgp_hip_trsm_lower.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
+    L.fvgp_hip_logdet.argtypes = [c_p, c_p, c_l, c_l, P_d]
+    L.fvgp_hip_potri.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l]
+    L.fvgp_hip_loglik.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_p, c_i, c_p, c_l, c_p, P_d, P_i]
+    L.fvgp_hip_loglik_grad.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_i, c_i, c_p, c_l, c_p, c_l, P_d]
+    L.fvgp_hip_posterior.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_l, c_p, c_i, c_p, c_l,
+                                     c_p, c_l, c_p, c_p, c_p, c_l]
+    L.fvgp_hip_gemm.argtypes = [c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l]
+    L.fvgp_hip_mfma_selftest.argtypes = [c_p, c_p, c_p, c_p]
+    L.fvgp_hip_symmetrize.argtypes = [c_p, c_p, c_l, c_l]
+    for s in SYMBOLS:
+        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim"):
+            getattr(L, s).restype = c_i
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().fvgp_hip_last_error_string().decode(errors="replace")
+        raise HipExtensionError(f"{what} failed with status {rc}" + (f": {msg}" if msg else ""))
+
+
+def _theta(theta):
+    t = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
+    return t, t.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(t.size)
+
+
+def _ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class Handle:
+    """One device + one stream.  Thin, argument-for-argument wrapper of the C ABI; tensors are
+    torch CUDA fp64 tensors used purely as device-memory containers."""
+
+    def __init__(self, device=0, stream=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise HipExtensionError("no HIP device visible (torch.cuda.is_available() is False); "
+                                    "the native path has no CPU fallback")
+        self.torch = torch
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().fvgp_hip_create(ctypes.byref(self._h), self.device, ctypes.c_void_p(stream)), "fvgp_hip_create")
+
+    def close(self):
+        if self._h:
+            lib().fvgp_hip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers -------------------------------------------------------------------------------
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.float64, device=f"cuda:{self.device}")
+
+    def zeros(self, *shape):
+        return self.torch.zeros(*shape, dtype=self.torch.float64, device=f"cuda:{self.device}")
+
+    def to_device(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=f"cuda:{self.device}")
+
+    def sync(self):
+        _check(lib().fvgp_hip_sync(self._h), "fvgp_hip_sync")
+
+    def set_option(self, key, value):
+        _check(lib().fvgp_hip_set_option(self._h, key.encode(), int(value)), "fvgp_hip_set_option")
+
+    def get_profile(self):
+        out = (ctypes.c_double * 4)()
+        _check(lib().fvgp_hip_get_profile(self._h, out), "fvgp_hip_get_profile")
+        return {"launches": out[0], "ms": out[1], "flops": out[2], "potrf_ms": out[3]}
+
+    # -- ABI calls -----------------------------------------------------------------------------
+    def kmat(self, kernel_id, x1, x2, theta, K, vdiag=None, uplo=FULL, pad=PAD_NONE):
+        t, tp, nt = _theta(theta)
+        _check(lib().fvgp_hip_kmat(self._h, int(kernel_id), _ptr(x1), x1.shape[0], _ptr(x2), x2.shape[0],
+                                   x1.shape[1], tp, nt, _ptr(vdiag), _ptr(K), K.stride(0), int(uplo), int(pad)),
+               "fvgp_hip_kmat")
+
+    def potrf(self, A, n):
+        info = ctypes.c_int(0)
+        _check(lib().fvgp_hip_potrf(self._h, _ptr(A), int(n), A.stride(0), ctypes.byref(info)), "fvgp_hip_potrf")
+        return info.value
+
+    def potrs(self, L, n, B, nrhs):
+        _check(lib().fvgp_hip_potrs(self._h, _ptr(L), int(n), L.stride(0), _ptr(B), int(nrhs), B.stride(0)),
+               "fvgp_hip_potrs")
+
+    def trsm_lower(self, L, n, B, nrhs):
+        _check(lib().fvgp_hip_trsm_lower(self._h, _ptr(L), int(n), L.stride(0), _ptr(B), int(nrhs), B.stride(0)),
+               "fvgp_hip_trsm_lower")
+
+    def logdet(self, L, n):
+        out = ctypes.c_double(0.0)
+        _check(lib().fvgp_hip_logdet(self._h, _ptr(L), int(n), L.stride(0), ctypes.byref(out)), "fvgp_hip_logdet")
+        return out.value
+
+    def potri(self, L, n, work):
+        _check(lib().fvgp_hip_potri(self._h, _ptr(L), int(n), L.stride(0), _ptr(work), work.stride(0)), "fvgp_hip_potri")
+
+    def loglik(self, kernel_id, x, theta, vdiag, ymean, KV, alpha):
+        t, tp, nt = _theta(theta)
+        out = (ctypes.c_double * 3)()
+        info = ctypes.c_int(0)
+        n, d = x.shape
+        _check(lib().fvgp_hip_loglik(self._h, int(kernel_id), _ptr(x), n, d, tp, nt, _ptr(vdiag), _ptr(ymean),
+                                     ymean.shape[1], _ptr(KV), KV.stride(0), _ptr(alpha), out, ctypes.byref(info)),
+               "fvgp_hip_loglik")
+        return out[0], out[1], out[2], info.value
+
+    def loglik_grad(self, kernel_id, x, theta, alpha, ncol, component, KV, work):
+        t, tp, nt = _theta(theta)
+        g = (ctypes.c_double * nt)()
+        n, d = x.shape
+        _check(lib().fvgp_hip_loglik_grad(self._h, int(kernel_id), _ptr(x), n, d, tp, nt, _ptr(alpha), int(ncol),
+                                          int(component), _ptr(KV), KV.stride(0), _ptr(work), work.stride(0), g),
+               "fvgp_hip_loglik_grad")
+        return np.array(g[:], dtype=np.float64)
+
+    def posterior(self, kernel_id, x, theta, L, alpha, ncol, xpred, kx, mean_out=None, var_out=None, S_out=None):
+        t, tp, nt = _theta(theta)
+        n, d = x.shape
+        _check(lib().fvgp_hip_posterior(self._h, int(kernel_id), _ptr(x), n, d, tp, nt, _ptr(L), L.stride(0),
+                                        _ptr(alpha), int(ncol), _ptr(xpred), xpred.shape[0], _ptr(kx), kx.stride(0),
+                                        _ptr(mean_out), _ptr(var_out), _ptr(S_out),
+                                        0 if S_out is None else S_out.stride(0)), "fvgp_hip_posterior")
+
+    def gemm(self, a_kmajor, b_nmajor, lower, M, N, K, alpha, A, B, beta, C):
+        _check(lib().fvgp_hip_gemm(self._h, int(a_kmajor), int(b_nmajor), int(lower), M, N, K, float(alpha),
+                                   _ptr(A), A.stride(0), _ptr(B), B.stride(0), float(beta), _ptr(C), C.stride(0)),
+               "fvgp_hip_gemm")
+
+    def mfma_selftest(self, A, B, D):
+        _check(lib().fvgp_hip_mfma_selftest(self._h, _ptr(A), _ptr(B), _ptr(D)), "fvgp_hip_mfma_selftest")
+
+    def symmetrize(self, A, n):
+        _check(lib().fvgp_hip_symmetrize(self._h, _ptr(A), int(n), A.stride(0)), "fvgp_hip_symmetrize")

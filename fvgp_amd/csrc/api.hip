@@ -1,0 +1,562 @@
+// Host side of the C ABI (include/fvgp_hip.h): argument checks, the blocked drivers that
+// sequence the kernels on the handle's stream, and the fused log-likelihood / gradient /
+// posterior evaluations.  No torch types; plain pointers and sizes only.
+#include "common.h"
+#include <math.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+void fvgp_set_error(const std::string &s) { g_err = s; }
+int fvgp_hip_fail(hipError_t e, const char *what, int line) {
+    g_err = std::string("HIP error '") + hipGetErrorString(e) + "' at api line " + std::to_string(line) + ": " + what;
+    return 1000 + (int)e;
+}
+
+extern "C" {
+
+int fvgp_hip_version(void) { return 100; }
+const char *fvgp_hip_last_error_string(void) { return g_err.c_str(); }
+int64_t fvgp_hip_padded_dim(int64_t n) { return pad128(n); }
+
+int fvgp_hip_create(fvgp_handle **out, int device, void *stream) {
+    if (!out) return -1;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) { fvgp_set_error("no such HIP device"); return -2; }
+    HIPCHK(hipSetDevice(device));
+    fvgp_handle *h = new fvgp_handle();
+    h->device = device;
+    h->stream = (hipStream_t)stream;
+    HIPCHK(hipMalloc((void **)&h->red, RED_SLOTS * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&h->dinfo, 64));
+    HIPCHK(hipHostMalloc((void **)&h->hpin, RED_SLOTS * sizeof(double), hipHostMallocDefault));
+    *out = h;
+    return 0;
+}
+
+int fvgp_hip_destroy(fvgp_handle *h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    if (h->linv) (void)hipFree(h->linv);
+    if (h->logdet_parts) (void)hipFree(h->logdet_parts);
+    if (h->red) (void)hipFree(h->red);
+    if (h->dinfo) (void)hipFree(h->dinfo);
+    if (h->vec) (void)hipFree(h->vec);
+    if (h->hpin) (void)hipHostFree(h->hpin);
+    delete h;
+    return 0;
+}
+
+int fvgp_hip_sync(fvgp_handle *h) {
+    if (!h) return -1;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
+    if (!h) return -1;
+    if (!key) return -2;
+    if (!strcmp(key, "outer_block")) {
+        if (value < 128 || value % 128) { fvgp_set_error("outer_block must be a positive multiple of 128"); return -3; }
+        h->outer_block = value;
+        return 0;
+    }
+    if (!strcmp(key, "profile")) { h->profile = value ? 1 : 0; return 0; }
+    fvgp_set_error(std::string("unknown option ") + key);
+    return -2;
+}
+
+int fvgp_hip_get_profile(fvgp_handle *h, double *out) {
+    if (!h) return -1;
+    if (!out) return -2;
+    out[0] = h->prof_launches; out[1] = h->prof_ms; out[2] = h->prof_flops; out[3] = h->prof_total_ms;
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+static int ensure_blocks(fvgp_handle *h, int64_t nblk) {
+    if ((size_t)nblk > h->linv_blocks) {
+        if (h->linv) HIPCHK(hipFree(h->linv));
+        h->linv = nullptr; h->linv_blocks = 0; h->linv_L = nullptr;
+        HIPCHK(hipMalloc((void **)&h->linv, (size_t)nblk * LEAF_DOUBLES * sizeof(double)));
+        h->linv_blocks = (size_t)nblk;
+    }
+    if ((size_t)nblk > h->logdet_cap) {
+        if (h->logdet_parts) HIPCHK(hipFree(h->logdet_parts));
+        h->logdet_parts = nullptr; h->logdet_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->logdet_parts, (size_t)nblk * sizeof(double)));
+        h->logdet_cap = (size_t)nblk;
+    }
+    return 0;
+}
+
+int ensure_scratch(fvgp_handle *h, int64_t np) {
+    size_t need = (size_t)np * 8;
+    if (need > h->vec_cap) {
+        if (h->vec) HIPCHK(hipFree(h->vec));
+        h->vec = nullptr; h->vec_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->vec, need * sizeof(double)));
+        h->vec_cap = need;
+    }
+    return 0;
+}
+
+// diagonal-block inverses for factor L: reuse those left by potrf, else recompute (batched)
+int ensure_linv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl) {
+    const int64_t np = pad128(n), nblk = np / TILE;
+    if (h->linv_L == L && h->linv_n == n && h->linv_ld == ldl && (size_t)nblk <= h->linv_blocks) return 0;
+    int rc = ensure_blocks(h, nblk);
+    if (rc) return rc;
+    rc = launch_leaf_inverse_batched(h, L, ldl, nblk, h->linv);
+    if (rc) return rc;
+    h->linv_L = L; h->linv_n = n; h->linv_ld = ldl;
+    return 0;
+}
+
+static int check_square(const void *A, int64_t n, int64_t ld, int argA, int argn, int argld) {
+    if (!A) return -argA;
+    if (n <= 0) return -argn;
+    if (ld < pad128(n) || (ld & 1)) { fvgp_set_error("leading dimension must be even and >= padded_dim(n)"); return -argld; }
+    if ((uintptr_t)A & 15) { fvgp_set_error("matrix base must be 16-byte aligned"); return -argA; }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// blocked right-looking Cholesky, two block sizes:
+//   inner 128: leaf (potf2 + trtri in LDS) -> panel TRSM as GEMM with inv(L_kk) -> update of
+//              the remaining columns of the current outer panel (K = 128);
+//   outer NB : one trailing SYRK per outer panel with K = NB, which carries ~all the flops
+//              and keeps the C-tile read-modify-write traffic at 8/NB bytes per flop.
+static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host) {
+    const int64_t np = pad128(n), nblk = np / TILE;
+    int rc = ensure_blocks(h, nblk);
+    if (rc) return rc;
+    h->linv_L = nullptr;
+    HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
+    const int64_t NB = h->outer_block;
+    size_t nev = 0;
+    h->ev_flops.clear();
+    hipEvent_t e_begin = nullptr, e_end = nullptr;
+    auto get_event = [&](hipEvent_t *e) -> int {
+        if (nev >= h->ev.size()) { hipEvent_t x; HIPCHK(hipEventCreate(&x)); h->ev.push_back(x); }
+        *e = h->ev[nev++];
+        return 0;
+    };
+    if (h->profile) { rc = get_event(&e_begin); if (rc) return rc; HIPCHK(hipEventRecord(e_begin, h->stream)); }
+
+    for (int64_t J0 = 0; J0 < np; J0 += NB) {
+        const int64_t Jend = (J0 + NB < np) ? J0 + NB : np;
+        for (int64_t k0 = J0; k0 < Jend; k0 += TILE) {
+            const int64_t kb = k0 / TILE;
+            rc = launch_leaf(h, A + k0 * lda + k0, lda, h->linv + kb * LEAF_DOUBLES, h->logdet_parts + kb, (int)k0, 1);
+            if (rc) return rc;
+            const int64_t r0 = k0 + TILE, R = np - r0;
+            if (R <= 0) continue;
+            // panel TRSM in place: A[r0:, k0:k0+128] <- A[r0:, k0:k0+128] * inv(L_kk)^T
+            GemmDesc t{};
+            t.a_kmajor = 0; t.b_nmajor = 0; t.lower = 0; t.M = R; t.N = TILE; t.K = TILE;
+            t.alpha = 1.0; t.beta = 0.0;
+            t.A = A + r0 * lda + k0; t.lda = lda;
+            t.B = h->linv + kb * LEAF_DOUBLES; t.ldb = TILE;
+            t.C = A + r0 * lda + k0; t.ldc = lda;
+            rc = launch_gemm(h, t);
+            if (rc) return rc;
+            // update of the rest of the outer panel: A[r0:, r0:Jend] -= P P[0:Jend-r0]^T (lower tiles)
+            const int64_t W = Jend - r0;
+            if (W > 0) {
+                GemmDesc u{};
+                u.a_kmajor = 0; u.b_nmajor = 0; u.lower = 1; u.M = R; u.N = W; u.K = TILE;
+                u.alpha = -1.0; u.beta = 1.0;
+                u.A = A + r0 * lda + k0; u.lda = lda;
+                u.B = A + r0 * lda + k0; u.ldb = lda;
+                u.C = A + r0 * lda + r0; u.ldc = lda;
+                rc = launch_gemm(h, u);
+                if (rc) return rc;
+            }
+        }
+        const int64_t R = np - Jend;
+        if (R > 0) {
+            GemmDesc s{};
+            s.a_kmajor = 0; s.b_nmajor = 0; s.lower = 1; s.M = R; s.N = R; s.K = Jend - J0;
+            s.alpha = -1.0; s.beta = 1.0;
+            s.A = A + Jend * lda + J0; s.lda = lda;
+            s.B = A + Jend * lda + J0; s.ldb = lda;
+            s.C = A + Jend * lda + Jend; s.ldc = lda;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (h->profile) { rc = get_event(&e0); if (rc) return rc; HIPCHK(hipEventRecord(e0, h->stream)); }
+            rc = launch_gemm(h, s);
+            if (rc) return rc;
+            if (h->profile) {
+                rc = get_event(&e1); if (rc) return rc; HIPCHK(hipEventRecord(e1, h->stream));
+                const double T = (double)(R / TILE);
+                h->ev_flops.push_back(T * (T + 1.0) * 0.5 * 128.0 * 128.0 * 2.0 * (double)(Jend - J0));
+            }
+        }
+    }
+    if (h->profile) { rc = get_event(&e_end); if (rc) return rc; HIPCHK(hipEventRecord(e_end, h->stream)); }
+    int *hinfo = reinterpret_cast<int *>(h->hpin + RED_SLOTS - 2);
+    HIPCHK(hipMemcpyAsync(hinfo, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int info = *hinfo;
+    if (info > n) info = 0;   // cannot happen: the padding is an identity block
+    if (info_host) *info_host = info;
+    h->linv_L = A; h->linv_n = n; h->linv_ld = lda;
+    if (h->profile) {
+        h->prof_launches = (double)h->ev_flops.size(); h->prof_ms = 0; h->prof_flops = 0;
+        for (size_t i = 0; i < h->ev_flops.size(); ++i) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h->ev[1 + 2 * i], h->ev[2 + 2 * i]));
+            h->prof_ms += ms; h->prof_flops += h->ev_flops[i];
+        }
+        float tot = 0.f;
+        HIPCHK(hipEventElapsedTime(&tot, e_begin, e_end));
+        h->prof_total_ms = tot;
+    }
+    return 0;
+}
+
+// B (np x ldb), nrhs columns: in-place solve, vector path (nrhs <= 8)
+static int potrs_vec(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb, bool backward) {
+    const int64_t np = pad128(n);
+    int rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
+    rc = ensure_scratch(h, np); if (rc) return rc;
+    const int c = (int)nrhs;
+    const int C = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : 8;
+    double *Y = h->vec;
+    for (int64_t k0 = 0; k0 < np; k0 += TILE) {
+        rc = launch_fwd_step(h, L, ldl, np, k0, h->linv + (k0 / TILE) * LEAF_DOUBLES, B, ldb, Y, c);
+        if (rc) return rc;
+    }
+    if (!backward) {
+        // forward result lives in Y (np x C); copy back to B
+        return launch_copy_cols(h, Y, C, B, ldb, np, c, np, c);
+    }
+    for (int64_t k0 = np - TILE; k0 >= 0; k0 -= TILE) {
+        rc = launch_bwd_step(h, L, ldl, np, k0, h->linv + (k0 / TILE) * LEAF_DOUBLES, Y, B, ldb, c);
+        if (rc) return rc;
+    }
+    (void)C;
+    return 0;
+}
+
+// B (np x ldb), nrhs (multiple of 128) columns: forward block substitution on MFMA GEMMs
+static int trsm_fwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t ncols, int64_t ldb) {
+    const int64_t np = pad128(n);
+    int rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
+    for (int64_t k0 = 0; k0 < np; k0 += TILE) {
+        GemmDesc d{};
+        d.a_kmajor = 0; d.b_nmajor = 1; d.lower = 0; d.M = TILE; d.N = ncols; d.K = TILE; d.alpha = 1.0; d.beta = 0.0;
+        d.A = h->linv + (k0 / TILE) * LEAF_DOUBLES; d.lda = TILE;
+        d.B = B + k0 * ldb; d.ldb = ldb; d.C = B + k0 * ldb; d.ldc = ldb;
+        rc = launch_gemm(h, d); if (rc) return rc;
+        const int64_t r0 = k0 + TILE, R = np - r0;
+        if (R <= 0) continue;
+        GemmDesc u{};
+        u.a_kmajor = 0; u.b_nmajor = 1; u.lower = 0; u.M = R; u.N = ncols; u.K = TILE; u.alpha = -1.0; u.beta = 1.0;
+        u.A = L + r0 * ldl + k0; u.lda = ldl; u.B = B + k0 * ldb; u.ldb = ldb; u.C = B + r0 * ldb; u.ldc = ldb;
+        rc = launch_gemm(h, u); if (rc) return rc;
+    }
+    return 0;
+}
+
+static int trsm_bwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t ncols, int64_t ldb) {
+    const int64_t np = pad128(n);
+    int rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
+    for (int64_t k0 = np - TILE; k0 >= 0; k0 -= TILE) {
+        GemmDesc d{};   // X_k = inv(L_kk)^T Y_k
+        d.a_kmajor = 1; d.b_nmajor = 1; d.lower = 0; d.M = TILE; d.N = ncols; d.K = TILE; d.alpha = 1.0; d.beta = 0.0;
+        d.A = h->linv + (k0 / TILE) * LEAF_DOUBLES; d.lda = TILE;
+        d.B = B + k0 * ldb; d.ldb = ldb; d.C = B + k0 * ldb; d.ldc = ldb;
+        rc = launch_gemm(h, d); if (rc) return rc;
+        if (k0 == 0) continue;
+        GemmDesc u{};   // Y[0:k0] -= L[k-block, 0:k0]^T X_k
+        u.a_kmajor = 1; u.b_nmajor = 1; u.lower = 0; u.M = k0; u.N = ncols; u.K = TILE; u.alpha = -1.0; u.beta = 1.0;
+        u.A = L + k0 * ldl; u.lda = ldl; u.B = B + k0 * ldb; u.ldb = ldb; u.C = B; u.ldc = ldb;
+        rc = launch_gemm(h, u); if (rc) return rc;
+    }
+    return 0;
+}
+
+static int read_back(fvgp_handle *h, const double *dev, double *host, int count) {
+    HIPCHK(hipMemcpyAsync(h->hpin, dev, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < count; ++i) host[i] = h->hpin[i];
+    return 0;
+}
+
+extern "C" {
+
+int fvgp_hip_kmat(fvgp_handle *h, int kernel_id, const double *x1, int64_t n1, const double *x2, int64_t n2,
+                  int d, const double *theta, int ntheta, const double *vdiag, double *K, int64_t ldk, int uplo, int pad) {
+    if (!h) return -1;
+    if (!x1) return -3;
+    if (n1 <= 0) return -4;
+    if (!x2) return -5;
+    if (n2 <= 0) return -6;
+    if (!theta) return -8;
+    if (!K) return -11;
+    if (ldk < (pad ? pad128(n2) : n2)) { fvgp_set_error("ldk too small"); return -12; }
+    if (uplo != FVGP_FULL && uplo != FVGP_LOWER) return -13;
+    if (pad < 0 || pad > 2) return -14;
+    HIPCHK(hipSetDevice(h->device));
+    KmatDesc k{};
+    int rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &k);
+    if (rc) return rc;
+    k.x1 = x1; k.n1 = n1; k.x2 = x2; k.n2 = n2; k.vdiag = vdiag; k.K = K; k.ldk = ldk; k.uplo = uplo; k.pad = pad;
+    return launch_kmat(h, k);
+}
+
+int fvgp_hip_potrf(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host) {
+    if (!h) return -1;
+    int rc = check_square(A, n, lda, 2, 3, 4);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    rc = launch_pad_identity(h, A, n, pad128(n), lda);
+    if (rc) return rc;
+    return potrf_driver(h, A, n, lda, info_host);
+}
+
+int fvgp_hip_potrs(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb) {
+    if (!h) return -1;
+    int rc = check_square(L, n, ldl, 2, 3, 4);
+    if (rc) return rc;
+    if (!B) return -5;
+    if (nrhs <= 0) return -6;
+    if (ldb < nrhs) return -7;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t np = pad128(n);
+    if (np > n) { rc = launch_copy_cols(h, B, ldb, B + n * ldb, ldb, 0, 0, np - n, nrhs); if (rc) return rc; }
+    if (nrhs <= FVGP_MAX_RHS_VEC) return potrs_vec(h, L, n, ldl, B, nrhs, ldb, true);
+    if (nrhs % 128 || (ldb & 1) || ((uintptr_t)B & 15)) { fvgp_set_error("potrs with nrhs > 8 needs nrhs % 128 == 0, even ldb, 16-byte aligned B"); return -6; }
+    rc = trsm_fwd_gemm(h, L, n, ldl, B, nrhs, ldb);
+    if (rc) return rc;
+    return trsm_bwd_gemm(h, L, n, ldl, B, nrhs, ldb);
+}
+
+int fvgp_hip_trsm_lower(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb) {
+    if (!h) return -1;
+    int rc = check_square(L, n, ldl, 2, 3, 4);
+    if (rc) return rc;
+    if (!B) return -5;
+    if (nrhs <= 0) return -6;
+    if (ldb < nrhs) return -7;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t np = pad128(n);
+    if (np > n) { rc = launch_copy_cols(h, B, ldb, B + n * ldb, ldb, 0, 0, np - n, nrhs); if (rc) return rc; }
+    if (nrhs <= FVGP_MAX_RHS_VEC) return potrs_vec(h, L, n, ldl, B, nrhs, ldb, false);
+    if (nrhs % 128 || (ldb & 1) || ((uintptr_t)B & 15)) { fvgp_set_error("trsm with nrhs > 8 needs nrhs % 128 == 0, even ldb, 16-byte aligned B"); return -6; }
+    return trsm_fwd_gemm(h, L, n, ldl, B, nrhs, ldb);
+}
+
+int fvgp_hip_logdet(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *out_host) {
+    if (!h) return -1;
+    if (!L) return -2;
+    if (n <= 0) return -3;
+    if (ldl < n) return -4;
+    if (!out_host) return -5;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = launch_diag_logsum(h, L, n, ldl, h->red);
+    if (rc) return rc;
+    return read_back(h, h->red, out_host, 1);
+}
+
+int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *work, int64_t ldw) {
+    if (!h) return -1;
+    int rc = check_square(L, n, ldl, 2, 3, 4);
+    if (rc) return rc;
+    rc = check_square(work, n, ldw, 5, 3, 6);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t np = pad128(n);
+    rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
+    // W = inv(L) into work, block row by block row:
+    //   W[i][0:i] = -inv(L_ii) * ( L[i][0:i] * W[0:i][0:i] ),  W[i][i] = inv(L_ii)
+    for (int64_t i0 = 0; i0 < np; i0 += TILE) {
+        const double *li = h->linv + (i0 / TILE) * LEAF_DOUBLES;
+        rc = launch_copy_cols(h, li, TILE, work + i0 * ldw + i0, ldw, TILE, TILE, TILE, TILE); if (rc) return rc;
+        if (i0 == 0) continue;
+        GemmDesc a{};   // T = L[i][0:i] * W[0:i][0:i]   (W lower-triangular: k starts at the column tile)
+        a.a_kmajor = 0; a.b_nmajor = 1; a.lower = 0; a.M = TILE; a.N = i0; a.K = i0; a.alpha = 1.0; a.beta = 0.0;
+        a.A = L + i0 * ldl; a.lda = ldl; a.B = work; a.ldb = ldw; a.C = work + i0 * ldw; a.ldc = ldw;
+        a.kb0 = 0; a.kbi = 0; a.kbj = TILE; a.ke0 = -1;
+        rc = launch_gemm(h, a); if (rc) return rc;
+        GemmDesc b{};   // W[i][0:i] = -inv(L_ii) * T  (in place)
+        b.a_kmajor = 0; b.b_nmajor = 1; b.lower = 0; b.M = TILE; b.N = i0; b.K = TILE; b.alpha = -1.0; b.beta = 0.0;
+        b.A = li; b.lda = TILE; b.B = work + i0 * ldw; b.ldb = ldw; b.C = work + i0 * ldw; b.ldc = ldw;
+        rc = launch_gemm(h, b); if (rc) return rc;
+    }
+    // KV^-1 = W^T W, lower tiles, k >= row tile
+    GemmDesc s{};
+    s.a_kmajor = 1; s.b_nmajor = 1; s.lower = 1; s.M = np; s.N = np; s.K = np; s.alpha = 1.0; s.beta = 0.0;
+    s.A = work; s.lda = ldw; s.B = work; s.ldb = ldw; s.C = L; s.ldc = ldl;
+    s.kb0 = 0; s.kbi = TILE; s.kbj = 0; s.ke0 = -1;
+    rc = launch_gemm(h, s); if (rc) return rc;
+    h->linv_L = nullptr;   // L is gone
+    return 0;
+}
+
+int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                    const double *theta, int ntheta, const double *vdiag, const double *ymean, int ncol,
+                    double *KV, int64_t ld, double *alpha, double *out_host, int *info_host) {
+    if (!h) return -1;
+    if (!x) return -3;
+    if (n <= 0) return -4;
+    if (!theta) return -6;
+    if (!ymean) return -9;
+    if (ncol < 1 || ncol > FVGP_MAX_RHS_VEC) { fvgp_set_error("1 <= ncol <= 8"); return -10; }
+    int rc = check_square(KV, n, ld, 11, 4, 12);
+    if (rc) return rc;
+    if (!alpha) return -13;
+    if (!out_host) return -14;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t np = pad128(n);
+    KmatDesc k{};
+    rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &k); if (rc) return rc;
+    k.x1 = x; k.n1 = n; k.x2 = x; k.n2 = n; k.vdiag = vdiag; k.K = KV; k.ldk = ld; k.uplo = FVGP_LOWER; k.pad = 1;
+    rc = launch_kmat(h, k); if (rc) return rc;
+    int info = 0;
+    rc = potrf_driver(h, KV, n, ld, &info); if (rc) return rc;
+    if (info_host) *info_host = info;
+    if (info != 0) { out_host[0] = out_host[1] = out_host[2] = NAN; return 0; }
+    rc = launch_copy_cols(h, ymean, ncol, alpha, ncol, n, ncol, np, ncol); if (rc) return rc;
+    rc = potrs_vec(h, KV, n, ld, alpha, ncol, ncol, true); if (rc) return rc;
+    rc = launch_sum(h, h->logdet_parts, np / TILE, h->red); if (rc) return rc;
+    rc = launch_dot_rows(h, ymean, ncol, alpha, ncol, n, ncol, h->red + 1); if (rc) return rc;
+    double r[2];
+    rc = read_back(h, h->red, r, 2); if (rc) return rc;
+    const double logdet = 2.0 * r[0], quad = r[1] / (double)ncol;
+    out_host[0] = -0.5 * (quad + logdet + (double)n * log(2.0 * M_PI));
+    out_host[1] = logdet;
+    out_host[2] = quad;
+    return 0;
+}
+
+int fvgp_hip_loglik_grad(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                         const double *theta, int ntheta, const double *alpha, int ncol, int component,
+                         double *KV, int64_t ld, double *work, int64_t ldw, double *grad_host) {
+    if (!h) return -1;
+    if (!x) return -3;
+    if (n <= 0) return -4;
+    if (!theta) return -6;
+    if (!alpha) return -8;
+    if (ncol < 1) return -9;
+    if (component < 0 || component >= ncol) return -10;
+    if (!grad_host) return -15;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = fvgp_hip_potri(h, KV, n, ld, work, ldw);
+    if (rc) return rc;
+    GradDesc g{};
+    rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &g.k); if (rc) return rc;
+    g.k.x1 = x; g.k.n1 = n; g.k.x2 = x; g.k.n2 = n;
+    g.kernel_id = kernel_id;
+    const bool iso = kernel_id >= 3;
+    const int nk = iso ? 2 : d + 1;     // kernel-owned hyperparameters; the rest get a zero gradient
+    g.ntheta = nk;
+    g.W = KV; g.ldw = ld; g.b = alpha + component; g.ldb = ncol;
+    g.partial = work;                    // inv(L) is dead by now: reuse as the partial-sum buffer
+    int nblocks = 0;
+    rc = launch_grad_trace(h, g, &nblocks); if (rc) return rc;
+    // reduce partial (nblocks x nk) on the host side: nblocks <= ~80k doubles per theta
+    std::vector<double> part((size_t)nblocks * nk);
+    HIPCHK(hipMemcpyAsync(part.data(), work, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < ntheta; ++i) grad_host[i] = 0.0;
+    for (int i = 0; i < nk; ++i) {
+        long double s = 0.0L;
+        for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * nk + i];
+        grad_host[i] = 0.5 * (double)s;
+    }
+    return 0;
+}
+
+int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                       const double *theta, int ntheta, const double *L, int64_t ldl,
+                       const double *alpha, int ncol, const double *xpred, int64_t P,
+                       double *kx, int64_t ldk, double *mean_out, double *var_out, double *S_out, int64_t lds) {
+    if (!h) return -1;
+    if (!x) return -3;
+    if (n <= 0) return -4;
+    if (!theta) return -6;
+    int rc = check_square(L, n, ldl, 8, 4, 9);
+    if (rc) return rc;
+    if (!alpha) return -10;
+    if (ncol < 1 || ncol > 128) return -11;
+    if (!xpred) return -12;
+    if (P <= 0) return -13;
+    const int64_t np = pad128(n), Pp = pad128(P);
+    if (!kx || ((uintptr_t)kx & 15)) return -14;
+    if (ldk < Pp || (ldk & 1)) return -15;
+    if (S_out && (lds < Pp || (lds & 1) || ((uintptr_t)S_out & 15))) return -19;
+    HIPCHK(hipSetDevice(h->device));
+    KmatDesc k{};
+    rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &k); if (rc) return rc;
+    // cross covariance k(x_data, x_pred) (gp_prior.py:200-215), zero padding
+    k.x1 = x; k.n1 = n; k.x2 = xpred; k.n2 = P; k.vdiag = nullptr; k.K = kx; k.ldk = ldk; k.uplo = FVGP_FULL; k.pad = 2;
+    rc = launch_kmat(h, k); if (rc) return rc;
+    if (mean_out) {
+        // mean = k^T alpha: GEMM with alpha widened to 128 columns in the handle scratch;
+        // the (Pp x 128) result goes to the tail of the same scratch
+        rc = ensure_scratch(h, np * 16 + Pp * 16); if (rc) return rc;
+        double *aw = h->vec;
+        rc = launch_copy_cols(h, alpha, ncol, aw, 128, np, ncol, np, 128); if (rc) return rc;
+        double *mw = h->vec + np * 128;
+        GemmDesc g{};
+        g.a_kmajor = 1; g.b_nmajor = 1; g.lower = 0; g.M = Pp; g.N = 128; g.K = np; g.alpha = 1.0; g.beta = 0.0;
+        g.A = kx; g.lda = ldk; g.B = aw; g.ldb = 128; g.C = mw; g.ldc = 128;
+        rc = launch_gemm(h, g); if (rc) return rc;
+        rc = launch_copy_cols(h, mw, 128, mean_out, ncol, P, ncol, P, ncol); if (rc) return rc;
+    }
+    if (var_out || S_out) {
+        rc = trsm_fwd_gemm(h, L, n, ldl, kx, Pp, ldk); if (rc) return rc;   // kx <- L^-1 k
+        if (S_out) {
+            KmatDesc kk = k;
+            kk.x1 = xpred; kk.n1 = P; kk.x2 = xpred; kk.n2 = P; kk.K = S_out; kk.ldk = lds; kk.uplo = FVGP_FULL; kk.pad = 2;
+            rc = launch_kmat(h, kk); if (rc) return rc;
+            GemmDesc g{};
+            g.a_kmajor = 1; g.b_nmajor = 1; g.lower = 0; g.M = Pp; g.N = Pp; g.K = np; g.alpha = -1.0; g.beta = 1.0;
+            g.A = kx; g.lda = ldk; g.B = kx; g.ldb = ldk; g.C = S_out; g.ldc = lds;
+            rc = launch_gemm(h, g); if (rc) return rc;
+        }
+        if (var_out) {
+            // v_p = k(x_p,x_p) - |L^-1 k_p|^2 ; stationary kernels: k(x,x) = signal variance
+            rc = launch_colsumsq(h, kx, np, ldk, P, k.sig, var_out); if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t M, int64_t N, int64_t K,
+                  double alpha, const double *A, int64_t lda, const double *B, int64_t ldb,
+                  double beta, double *C, int64_t ldc) {
+    if (!h) return -1;
+    if (!A) return -9;
+    if (!B) return -11;
+    if (!C) return -14;
+    HIPCHK(hipSetDevice(h->device));
+    GemmDesc g{};
+    g.a_kmajor = a_kmajor; g.b_nmajor = b_nmajor; g.lower = lower; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    return launch_gemm(h, g);
+}
+
+int fvgp_hip_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D) {
+    if (!h) return -1;
+    HIPCHK(hipSetDevice(h->device));
+    return launch_mfma_selftest(h, A, B, D);
+}
+
+int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda) {
+    if (!h) return -1;
+    if (!A) return -2;
+    if (n <= 0) return -3;
+    if (lda < n) return -4;
+    HIPCHK(hipSetDevice(h->device));
+    return launch_symmetrize(h, A, n, lda);
+}
+
+}  // extern "C"

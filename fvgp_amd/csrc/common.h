@@ -1,0 +1,110 @@
+// Shared host-side declarations of libfvgp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/fvgp_hip.h"
+
+constexpr int TILE = FVGP_TILE;        // 128: tile edge of every kernel and the leaf Cholesky block
+constexpr int LEAF_DOUBLES = TILE * TILE;
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+struct fvgp_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // inverses of the 128x128 diagonal blocks of the last factor (row-major, upper = 0)
+    double *linv = nullptr;
+    size_t linv_blocks = 0;
+    const double *linv_L = nullptr;   // which factor they belong to
+    int64_t linv_n = 0, linv_ld = 0;
+    // per-leaf sum(log L_ii), device
+    double *logdet_parts = nullptr;
+    size_t logdet_cap = 0;
+    // small device scratch: reductions, info flag
+    double *red = nullptr;            // RED_SLOTS doubles
+    int *dinfo = nullptr;
+    double *hpin = nullptr;           // pinned host mirror (RED_SLOTS doubles)
+    // scratch for the vector solves (padded_n x 8)
+    double *vec = nullptr;
+    size_t vec_cap = 0;
+    // options
+    int64_t outer_block = 512;
+    int profile = 0;
+    // profile of the last potrf
+    std::vector<hipEvent_t> ev;
+    std::vector<double> ev_flops;
+    double prof_launches = 0, prof_ms = 0, prof_flops = 0, prof_total_ms = 0;
+};
+constexpr int RED_SLOTS = 4096;
+
+void fvgp_set_error(const std::string &s);
+int fvgp_hip_fail(hipError_t e, const char *what, int line);
+
+#define HIPCHK(call)                                                  \
+    do {                                                              \
+        hipError_t e__ = (call);                                      \
+        if (e__ != hipSuccess) return fvgp_hip_fail(e__, #call, __LINE__); \
+    } while (0)
+
+static inline int64_t pad128(int64_t n) { return (n + TILE - 1) / TILE * TILE; }
+
+// ---- launches implemented in the .hip units ------------------------------------------------
+struct GemmDesc {
+    int a_kmajor, b_nmajor, lower;
+    int64_t M, N, K;
+    double alpha, beta;
+    const double *A; int64_t lda;
+    const double *B; int64_t ldb;
+    double *C; int64_t ldc;
+    // per-tile K range: [kb0 + kbi*ti + kbj*tj, ke0 + kei*ti + kej*tj) clamped to [0,K], in elements
+    int64_t kb0 = 0, kbi = 0, kbj = 0, ke0 = -1, kei = 0, kej = 0;
+};
+int launch_gemm(fvgp_handle *h, const GemmDesc &g);
+
+struct KmatDesc {
+    int kind;                 // 0 rbf, 1 matern 3/2, 2 matern 5/2
+    const double *x1; int64_t n1;
+    const double *x2; int64_t n2;
+    int d;
+    double sig;
+    double invl[FVGP_MAX_DIM];
+    const double *vdiag;
+    double *K; int64_t ldk;
+    int uplo, pad;
+};
+int launch_kmat(fvgp_handle *h, const KmatDesc &k);
+int kmat_desc_from_theta(int kernel_id, int d, const double *theta, int ntheta, KmatDesc *out);
+
+struct GradDesc {
+    KmatDesc k;               // x1 == x2 == x, n1 == n2 == n
+    int kernel_id;
+    int ntheta;
+    const double *W; int64_t ldw;   // lower triangle of KV^-1
+    const double *b; int64_t ldb;   // KVinvY column (stride ldb)
+    double *partial;                // device, nblocks x ntheta
+};
+int launch_grad_trace(fvgp_handle *h, const GradDesc &g, int *nblocks_out);
+
+int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor);
+int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, int64_t nblk, double *linv);
+
+int launch_fwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,
+                    double *B, int64_t ldb, double *Y, int c);
+int launch_bwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,
+                    double *Yres, double *X, int64_t ldx, int c);
+int launch_diag_logsum(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *out_dev);
+int launch_sum(fvgp_handle *h, const double *v, int64_t n, double *out_dev);
+int launch_dot_rows(fvgp_handle *h, const double *a, int64_t lda, const double *b, int64_t ldb, int64_t n, int c, double *out_dev);
+int launch_pad_identity(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda);
+int launch_copy_cols(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t rows, int64_t cols,
+                     int64_t rows_pad, int64_t cols_pad);
+int launch_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda);
+int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t P, double base, double *out);
+int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D);
+int launch_zero_upper_tiles(fvgp_handle *h, double *A, int64_t np, int64_t lda);
+
+int ensure_linv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl);
+int ensure_scratch(fvgp_handle *h, int64_t np);

@@ -1,0 +1,256 @@
+// fp64 MFMA GEMM / SYRK for gfx950:  C = alpha * opA * opB + beta * C  on 128x128 tiles.
+//
+// This is the kernel the metric lives in: the trailing update of the blocked Cholesky
+// (dsyrk/dgemm inside LAPACK dpotrf, reached from fvgp/gp_lin_alg.py:245) is
+//     A22 -= L21 * L21^T          (a_kmajor = 0, b_nmajor = 0, lower = 1)
+// and every other level-3 step of the path (TRSM by inverted diagonal blocks, POTRI,
+// posterior cross products) is one of the four operand layouts below.
+//
+// Design (CDNA4):
+//   * v_mfma_f64_16x16x4_f64; one 256-thread workgroup = 4 waves in a 2x2 grid, each wave
+//     owns 64x64 of C = 16 MFMA tiles = 64 fp64 accumulators per lane;
+//   * K is walked in steps of 16 through a double-buffered LDS image, global -> registers
+//     -> LDS, one barrier per step (the next step's loads are in flight during the MFMAs);
+//   * LDS images are padded so the ds_read_b64 fragment reads are bank-conflict free:
+//     k-minor operand [128][16+2], m-minor operand [16][128+16];
+//   * 2 workgroups per CU (<=256 VGPR, 72 KiB LDS each) so one workgroup's C read-modify-
+//     write epilogue hides under the other's MFMA stream;
+//   * blockIdx -> tile map walks the lower triangle in 8x8 super-tiles and deals consecutive
+//     super-tiles to the same XCD (blocks b, b+8, .. share an L2), so the row/column slabs
+//     of L21 a super-tile needs are fetched into that XCD's L2 once.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int LDK = 18;            // doubles per row of a k-minor LDS image  [128][18]
+constexpr int LDM = 144;           // doubles per row of an m-minor LDS image [16][144]
+constexpr int IMG = 128 * LDK;     // == 16 * LDM == 2304 doubles per operand image
+
+struct GemmArgs {
+    const double *A; const double *B; double *C;
+    long lda, ldb, ldc;
+    double alpha, beta;
+    int tiles_m, tiles_n, lower;
+    long K;
+    long kb0, kbi, kbj, ke0, kei, kej;
+    long ntiles;
+};
+
+// linear index -> (ti, tj).  Tiles are enumerated in super-tiles of 8 x SN (SN = min(8, tiles_n)),
+// row-major inside a super-tile; in lower mode only super-tiles that touch ti >= tj exist
+// (super-row si holds min(si+1, sn) of them), so neighbours in the order share operand slabs.
+__device__ inline void tile_of(long t, int tiles_m, int tiles_n, int lower, int &ti, int &tj) {
+    constexpr int S = 8;
+    const int SN = tiles_n < S ? tiles_n : S;
+    const int sn = (tiles_n + SN - 1) / SN;
+    const long per = (long)S * SN;
+    const long st = t / per; const int in = (int)(t % per);
+    int si, sj;
+    if (!lower || SN < S) {          // SN < S implies sn == 1
+        si = (int)(st / sn); sj = (int)(st % sn);
+    } else {
+        const long tri = (long)sn * (sn + 1) / 2;
+        if (st < tri) {
+            si = (int)((__builtin_sqrt(8.0 * (double)st + 1.0) - 1.0) * 0.5);
+            while ((long)(si + 1) * (si + 2) / 2 <= st) ++si;
+            while ((long)si * (si + 1) / 2 > st) --si;
+            sj = (int)(st - (long)si * (si + 1) / 2);
+        } else {
+            const long rr = st - tri;
+            si = sn + (int)(rr / sn); sj = (int)(rr % sn);
+        }
+    }
+    ti = si * S + in / SN; tj = sj * SN + in % SN;
+}
+
+template <int AKM, int BNM>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+    __shared__ double smem[2][2][IMG];
+
+    // XCD-aware remap: hardware deals block b to XCD b%8; give each XCD a contiguous run of tiles
+    const long nwg = gridDim.x;
+    const long b = blockIdx.x;
+    const long q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const long t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    int ti, tj;
+    tile_of(t, g.tiles_m, g.tiles_n, g.lower, ti, tj);
+    if (ti >= g.tiles_m || tj >= g.tiles_n) return;
+    if (g.lower && tj > ti) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+
+    long kbeg = g.kb0 + g.kbi * ti + g.kbj * tj;
+    long kend = (g.ke0 < 0 ? g.K : g.ke0 + g.kei * ti + g.kej * tj);
+    if (kbeg < 0) kbeg = 0;
+    if (kend > g.K) kend = g.K;
+    const int nk = kend > kbeg ? (int)((kend - kbeg) / BK) : 0;
+
+    const long m0 = (long)ti * 128, n0 = (long)tj * 128;
+
+    // global -> register staging maps (4 x 16 B per operand per thread)
+    const double *ga[4]; const double *gb[4];
+    int sa[4], sb[4];
+    long astep, bstep;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (AKM) {           // A stored (K, M): rows of 128 contiguous m
+            int kr = p * 4 + (tid >> 6), mc = (tid & 63) * 2;
+            ga[p] = g.A + (kbeg + kr) * g.lda + m0 + mc;
+            sa[p] = kr * LDM + mc;
+        } else {             // A stored (M, K): rows of 16 contiguous k
+            int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
+            ga[p] = g.A + (m0 + row) * g.lda + kbeg + kc;
+            sa[p] = row * LDK + kc;
+        }
+        if (BNM) {           // B stored (K, N)
+            int kr = p * 4 + (tid >> 6), nc = (tid & 63) * 2;
+            gb[p] = g.B + (kbeg + kr) * g.ldb + n0 + nc;
+            sb[p] = kr * LDM + nc;
+        } else {             // B stored (N, K)
+            int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
+            gb[p] = g.B + (n0 + row) * g.ldb + kbeg + kc;
+            sb[p] = row * LDK + kc;
+        }
+    }
+    astep = AKM ? (long)BK * g.lda : BK;
+    bstep = BNM ? (long)BK * g.ldb : BK;
+
+    // fragment read offsets (doubles) for k-substep 0; substep s adds 4*s (k-minor) or 4*s*LDM
+    int fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        fa[i] = AKM ? (q * LDM + wm * 64 + i * 16 + r) : ((wm * 64 + i * 16 + r) * LDK + q);
+        fb[i] = BNM ? (q * LDM + wn * 64 + i * 16 + r) : ((wn * 64 + i * 16 + r) * LDK + q);
+    }
+    constexpr int SA = AKM ? 4 * LDM : 4;
+    constexpr int SB = BNM ? 4 * LDM : 4;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    double2_t ra[4], rb[4];
+    if (nk > 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = *reinterpret_cast<const double2_t *>(ga[p]);
+            rb[p] = *reinterpret_cast<const double2_t *>(gb[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<double2_t *>(&smem[0][0][sa[p]]) = ra[p];
+            *reinterpret_cast<double2_t *>(&smem[0][1][sb[p]]) = rb[p];
+        }
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                ga[p] += astep; gb[p] += bstep;
+                ra[p] = *reinterpret_cast<const double2_t *>(ga[p]);
+                rb[p] = *reinterpret_cast<const double2_t *>(gb[p]);
+            }
+        }
+        const double *pa = &smem[cur][0][0];
+        const double *pb = &smem[cur][1][0];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            double a[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = pa[fa[i] + s * SA]; bv[i] = pb[fb[i] + s * SB]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][0][sa[p]]) = ra[p];
+                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][1][sb[p]]) = rb[p];
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const long row = m0 + wm * 64 + i * 16 + q + 4 * v;
+            double *crow = g.C + row * g.ldc + n0 + wn * 64 + r;
+            if (beta != 0.0) {
+                double old[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) old[j] = crow[j * 16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) crow[j * 16] = alpha * acc[i][j][v] + beta * old[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) crow[j * 16] = alpha * acc[i][j][v];
+            }
+        }
+    }
+}
+
+__global__ void mfma_selftest_kernel(const double *A, const double *B, double *D) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    // A is 16x4 row-major, B is 4x16 row-major
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[r * 4 + q], B[q * 16 + r], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) D[(q + 4 * v) * 16 + r] = acc[v];
+}
+
+}  // namespace
+
+int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D) {
+    hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, h->stream, A, B, D);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
+    if (d.M <= 0 || d.N <= 0) return 0;
+    if (d.M % 128 || d.N % 128 || d.K % BK || d.K < 0) { fvgp_set_error("gemm: M,N must be multiples of 128 and K of 16"); return -5; }
+    if ((d.lda & 1) || (d.ldb & 1) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) {
+        fvgp_set_error("gemm: operands must be 16-byte aligned with even leading dimensions"); return -9;
+    }
+    GemmArgs g;
+    g.A = d.A; g.B = d.B; g.C = d.C; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
+    g.alpha = d.alpha; g.beta = d.beta; g.K = d.K;
+    g.tiles_m = (int)(d.M / 128); g.tiles_n = (int)(d.N / 128); g.lower = d.lower;
+    g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
+    // grid = whole super-tiles (out-of-range tiles exit at once); must mirror tile_of()
+    const long S = 8;
+    const long SN = g.tiles_n < S ? g.tiles_n : S;
+    const long sm = (g.tiles_m + S - 1) / S, sn = (g.tiles_n + SN - 1) / SN;
+    long nst;
+    if (d.lower && SN == S) {
+        if (sm <= sn) nst = sm * (sm + 1) / 2;
+        else nst = sn * (sn + 1) / 2 + (sm - sn) * sn;
+    } else nst = sm * sn;
+    g.ntiles = nst * S * SN;
+    dim3 grid((unsigned)g.ntiles), block(256);
+#define GO(AK, BN) hipLaunchKernelGGL((gemm_f64_kernel<AK, BN>), grid, block, 0, h->stream, g)
+    if (!d.a_kmajor && !d.b_nmajor) GO(0, 0);
+    else if (!d.a_kmajor && d.b_nmajor) GO(0, 1);
+    else if (d.a_kmajor && !d.b_nmajor) GO(1, 0);
+    else GO(1, 1);
+#undef GO
+    HIPCHK(hipGetLastError());
+    return 0;
+}

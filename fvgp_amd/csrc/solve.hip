@@ -1,0 +1,293 @@
+// Vector triangular solves, reductions and small data-movement kernels (HBM-bound work).
+//
+// potrs with a handful of right-hand sides (y has 1..few columns, fvgp/gp_kv.py:592) is
+// bandwidth work: L is streamed exactly once per direction.  Both sweeps use the inverted
+// 128x128 diagonal blocks left behind by the factorisation, so a block step is
+//   forward :  y_k = inv(L_kk) b_k ;  b[r > k] -= L[r, k-block] y_k      (column panel, rows below)
+//   backward:  x_k = inv(L_kk)^T y_k ; y[c < k] -= L[k-block, c]^T x_k   (row panel, columns left)
+// Each workgroup recomputes the 128-vector of its step from the L2-resident diagonal
+// inverse (128 KiB) instead of waiting on a second launch, so one launch = one block step.
+#include "common.h"
+
+namespace {
+
+template <int C>
+__global__ __launch_bounds__(256) void fwd_step_kernel(const double *L, long ldl, long np, long k0, const double *linv,
+                                                       double *B, long ldb, double *Y, int c_used) {
+    __shared__ double sb[128 * C];
+    __shared__ double sy[128 * C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < 128 * C; e += 256) {
+        const int i = e / C, cc = e - i * C;
+        sb[e] = cc < c_used ? B[(k0 + i) * ldb + cc] : 0.0;
+    }
+    __syncthreads();
+    // y = Linv * b : wave handles rows wave, wave+4, ...; lanes hold 2 columns each
+    for (int i = wave; i < 128; i += 4) {
+        const double2_t l2 = *reinterpret_cast<const double2_t *>(linv + i * 128 + 2 * lane);
+        double acc[C];
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) acc[cc] = l2[0] * sb[(2 * lane) * C + cc] + l2[1] * sb[(2 * lane + 1) * C + cc];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) acc[cc] += __shfl_down(acc[cc], off, 64);
+        if (lane == 0)
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) sy[i * C + cc] = acc[cc];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < 128 * C; e += 256) {
+            const int i = e / C, cc = e - i * C;
+            if (cc < c_used) Y[(k0 + i) * C + cc] = sy[e];
+        }
+    }
+    // rows below: each wave takes rows r0 + gw, stride = total waves
+    double y0[C], y1[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) { y0[cc] = sy[(2 * lane) * C + cc]; y1[cc] = sy[(2 * lane + 1) * C + cc]; }
+    const long r0 = k0 + 128;
+    const long nw = (long)gridDim.x * 4;
+    for (long row = r0 + (long)blockIdx.x * 4 + wave; row < np; row += nw) {
+        const double2_t l2 = *reinterpret_cast<const double2_t *>(L + row * ldl + k0 + 2 * lane);
+        double acc[C];
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) acc[cc] = l2[0] * y0[cc] + l2[1] * y1[cc];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) acc[cc] += __shfl_down(acc[cc], off, 64);
+        if (lane == 0)
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) if (cc < c_used) B[row * ldb + cc] -= acc[cc];
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void bwd_step_kernel(const double *L, long ldl, long np, long k0, const double *linv,
+                                                       double *Yres, double *X, long ldx, int c_used) {
+    __shared__ double sy[128 * C];
+    __shared__ double sxv[128 * C];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 128 * C; e += 256) sy[e] = Yres[k0 * C + e];
+    __syncthreads();
+    // x = Linv^T y : thread i (<128) walks down column i (coalesced across threads)
+    if (tid < 128) {
+        double acc[C];
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) acc[cc] = 0.0;
+        for (int j = tid; j < 128; ++j) {       // Linv is lower: Linv[j][i] = 0 for j < i
+            const double l = linv[j * 128 + tid];
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) acc[cc] = fma(l, sy[j * C + cc], acc[cc]);
+        }
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) sxv[tid * C + cc] = acc[cc];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < 128 * C; e += 256) {
+            const int i = e / C, cc = e - i * C;
+            if (cc < c_used) X[(k0 + i) * ldx + cc] = sxv[e];
+        }
+    }
+    // columns to the left: thread owns 2 adjacent columns, walks the 128 rows of the block
+    for (long c2 = ((long)blockIdx.x * 256 + tid) * 2; c2 < k0; c2 += (long)gridDim.x * 512) {
+        double a0[C], a1[C];
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) { a0[cc] = 0.0; a1[cc] = 0.0; }
+#pragma unroll 4
+        for (int rr = 0; rr < 128; ++rr) {
+            const double2_t l2 = *reinterpret_cast<const double2_t *>(L + (k0 + rr) * ldl + c2);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) { a0[cc] = fma(l2[0], sxv[rr * C + cc], a0[cc]); a1[cc] = fma(l2[1], sxv[rr * C + cc], a1[cc]); }
+        }
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) { Yres[c2 * C + cc] -= a0[cc]; Yres[(c2 + 1) * C + cc] -= a1[cc]; }
+    }
+}
+
+__global__ void diag_logsum_kernel(const double *L, long n, long ldl, double *out) {
+    __shared__ double sw[16];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s += log(fabs(L[i * ldl + i]));
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sw[w]; out[0] = 2.0 * t; }
+}
+
+__global__ void sum_kernel(const double *v, long n, double *out) {
+    __shared__ double sw[16];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sw[w]; out[0] = t; }
+}
+
+// out[0] = sum_{i<n, cc<c} a[i*lda+cc] * b[i*ldb+cc]
+__global__ void dot_rows_kernel(const double *a, long lda, const double *b, long ldb, long n, int c, double *out) {
+    __shared__ double sw[16];
+    double s = 0.0;
+    const long tot = n * c;
+    for (long e = threadIdx.x; e < tot; e += blockDim.x) { const long i = e / c; const int cc = (int)(e - i * c); s = fma(a[i * lda + cc], b[i * ldb + cc], s); }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sw[w]; out[0] = t; }
+}
+
+// dst (rows_pad, ldd) <- src (rows, lds) for [rows x cols], zero elsewhere up to rows_pad x cols_pad
+__global__ void copy_cols_kernel(const double *src, long lds, double *dst, long ldd, long rows, long cols, long rows_pad, long cols_pad) {
+    const long tot = rows_pad * cols_pad;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        const long i = e / cols_pad, j = e - i * cols_pad;
+        dst[i * ldd + j] = (i < rows && j < cols) ? src[i * lds + j] : 0.0;
+    }
+}
+
+__global__ void symmetrize_kernel(double *A, long n, long lda) {
+    // 32x32 tile transpose through LDS; only tiles with bi > bj (and the diagonal tiles in place)
+    __shared__ double t[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int rr = ty; rr < 32; rr += 8) {
+        const long i = (long)bi * 32 + rr, j = (long)bj * 32 + tx;
+        t[rr][tx] = (i < n && j < n) ? A[i * lda + j] : 0.0;
+    }
+    __syncthreads();
+    for (int rr = ty; rr < 32; rr += 8) {
+        const long i = (long)bj * 32 + rr, j = (long)bi * 32 + tx;   // target (i,j) in the upper triangle = source (j,i)
+        if (i < n && j < n && j > i) A[i * lda + j] = t[tx][rr];
+    }
+}
+
+// out[p] = base - sum_{i<rows} V[i*ldv+p]^2, p < P   (posterior variance: k(x_p,x_p) - |L^-1 k_p|^2)
+__global__ void colsumsq_kernel(const double *V, long rows, long ldv, long P, double base, double *out) {
+    __shared__ double sp[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long p = (long)blockIdx.x * 32 + tx;
+    double s = 0.0;
+    if (p < P) for (long i = ty; i < rows; i += 8) { const double v = V[i * ldv + p]; s = fma(v, v, s); }
+    sp[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && p < P) { double t = 0.0; for (int k = 0; k < 8; ++k) t += sp[k][tx]; out[p] = base - t; }
+}
+
+// zero the 128x128 tiles strictly above the block diagonal (POTRI needs a clean upper half)
+__global__ void zero_upper_tiles_kernel(double *A, long np, long lda) {
+    const int tj = blockIdx.x, ti = blockIdx.y;
+    if (tj <= ti) return;
+    for (int e = threadIdx.x; e < 128 * 64; e += blockDim.x) {
+        const int rr = e >> 6, c2 = (e & 63) * 2;
+        *reinterpret_cast<double2_t *>(A + ((long)ti * 128 + rr) * lda + (long)tj * 128 + c2) = (double2_t){0.0, 0.0};
+    }
+}
+
+// rows n..np-1 of a padded square matrix <- identity rows (lower part; the strict upper is never read)
+__global__ void pad_identity_kernel(double *A, long n, long np, long lda) {
+    const long rows = np - n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < rows * np; e += (long)gridDim.x * blockDim.x) {
+        const long i = n + e / np, j = e % np;
+        if (j <= i) A[i * lda + j] = (i == j) ? 1.0 : 0.0;
+    }
+}
+
+}  // namespace
+
+int launch_pad_identity(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda) {
+    if (np <= n) return 0;
+    long tot = (np - n) * np;
+    long blocks = (tot + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, (long)n, (long)np, (long)lda);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <int C>
+static int fwd_go(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv, double *B, int64_t ldb, double *Y, int c) {
+    long rows = np - k0 - 128;
+    long blocks = rows > 0 ? (rows + 15) / 16 : 1;   // 4 rows per wave-pass, 4 waves
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((fwd_step_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, h->stream, L, (long)ldl, (long)np, (long)k0, linv, B, (long)ldb, Y, c);
+    return 0;
+}
+
+int launch_fwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,
+                    double *B, int64_t ldb, double *Y, int c) {
+    if (c <= 1) fwd_go<1>(h, L, ldl, np, k0, linv_k, B, ldb, Y, c);
+    else if (c <= 2) fwd_go<2>(h, L, ldl, np, k0, linv_k, B, ldb, Y, c);
+    else if (c <= 4) fwd_go<4>(h, L, ldl, np, k0, linv_k, B, ldb, Y, c);
+    else fwd_go<8>(h, L, ldl, np, k0, linv_k, B, ldb, Y, c);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <int C>
+static int bwd_go(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv, double *Yres, double *X, int64_t ldx, int c) {
+    long blocks = k0 > 0 ? (k0 + 511) / 512 : 1;
+    hipLaunchKernelGGL((bwd_step_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, h->stream, L, (long)ldl, (long)np, (long)k0, linv, Yres, X, (long)ldx, c);
+    return 0;
+}
+
+int launch_bwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,
+                    double *Yres, double *X, int64_t ldx, int c) {
+    if (c <= 1) bwd_go<1>(h, L, ldl, np, k0, linv_k, Yres, X, ldx, c);
+    else if (c <= 2) bwd_go<2>(h, L, ldl, np, k0, linv_k, Yres, X, ldx, c);
+    else if (c <= 4) bwd_go<4>(h, L, ldl, np, k0, linv_k, Yres, X, ldx, c);
+    else bwd_go<8>(h, L, ldl, np, k0, linv_k, Yres, X, ldx, c);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_diag_logsum(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *out_dev) {
+    hipLaunchKernelGGL(diag_logsum_kernel, dim3(1), dim3(1024), 0, h->stream, L, (long)n, (long)ldl, out_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_sum(fvgp_handle *h, const double *v, int64_t n, double *out_dev) {
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, h->stream, v, (long)n, out_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_dot_rows(fvgp_handle *h, const double *a, int64_t lda, const double *b, int64_t ldb, int64_t n, int c, double *out_dev) {
+    hipLaunchKernelGGL(dot_rows_kernel, dim3(1), dim3(1024), 0, h->stream, a, (long)lda, b, (long)ldb, (long)n, c, out_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_copy_cols(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t rows, int64_t cols,
+                     int64_t rows_pad, int64_t cols_pad) {
+    long tot = rows_pad * cols_pad;
+    if (tot <= 0) return 0;
+    long blocks = (tot + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, src, (long)lds, dst, (long)ldd, (long)rows, (long)cols, (long)rows_pad, (long)cols_pad);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda) {
+    unsigned nb = (unsigned)((n + 31) / 32);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, h->stream, A, (long)n, (long)lda);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t P, double base, double *out) {
+    hipLaunchKernelGGL(colsumsq_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, h->stream, V, (long)rows, (long)ldv, (long)P, base, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_zero_upper_tiles(fvgp_handle *h, double *A, int64_t np, int64_t lda) {
+    unsigned nb = (unsigned)(np / 128);
+    hipLaunchKernelGGL(zero_upper_tiles_kernel, dim3(nb, nb), dim3(256), 0, h->stream, A, (long)np, (long)lda);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

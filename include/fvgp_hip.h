@@ -1,0 +1,144 @@
+/*
+ * fvgp_hip.h -- flat C ABI of the MI355X-native exact-GP engine (libfvgp_hip.so).
+ *
+ * The library replaces the numpy/scipy calls on fvGP's dense hot path.  Each entry point
+ * names the reference interface it stands in for (paths relative to the lbl-camera/fvGP
+ * root).  The reference is pure Python, so the binding a maintainer adds is a ctypes stub
+ * (INTEGRATION.md); fvgp_amd/_lib.py is that stub.
+ *
+ * Conventions
+ *   - every matrix is fp64, ROW-MAJOR (numpy / torch default) with an explicit leading
+ *     dimension in elements; device pointers unless the parameter says "host";
+ *   - square factor / covariance buffers are PADDED: rows and leading dimension are
+ *     fvgp_hip_padded_dim(n) (a multiple of 128); the library owns the contents of the
+ *     padding (identity on the diagonal, zero elsewhere) so every kernel runs on whole
+ *     128x128 tiles;
+ *   - only the LOWER triangle (i >= j) of a symmetric input / Cholesky output is defined,
+ *     exactly like scipy.linalg.cho_factor(lower=True) (fvgp/gp_lin_alg.py:245);
+ *   - the caller (torch tensors on the Python side) owns every buffer; the handle owns
+ *     only its scratch (diagonal-block inverses, reduction slots);
+ *   - return value: 0 ok; -k = argument k (1-based) is invalid (LAPACK style);
+ *     >= 1000 = HIP runtime failure (text in fvgp_hip_last_error_string);
+ *     "info" out-parameters follow dpotrf: 0, or the order of the first leading minor
+ *     that is not positive definite.
+ *   - a handle is bound to one device and one stream and is not thread-safe; distinct
+ *     handles are independent.  Calls that return host scalars synchronise the stream;
+ *     all others are asynchronous on it.
+ */
+#ifndef FVGP_HIP_H
+#define FVGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fvgp_handle fvgp_handle;
+
+/* stationary kernels of fvgp/kernels.py; theta = [signal variance, l_1..l_d] (ARD)
+ * or [signal variance, l] (isotropic) */
+enum fvgp_kernel_id {
+    FVGP_KERNEL_RBF_ARD = 0,      /* hps[0]*squared_exponential_kernel(get_anisotropic_distance_matrix(..,hps[1:]),1)  kernels.py:16-33,461-481 */
+    FVGP_KERNEL_MATERN32_ARD = 1, /* GPprior._default_kernel                                                            gp_prior.py:376-400 */
+    FVGP_KERNEL_MATERN52_ARD = 2, /* gp_bo._surrogate_kernel                                                            gp_bo.py:115-126 */
+    FVGP_KERNEL_RBF_ISO = 3,      /* hps[0]*squared_exponential_kernel(get_distance_matrix(x1,x2),hps[1])               kernels.py:440-458 */
+    FVGP_KERNEL_MATERN32_ISO = 4, /* hps[0]*matern_kernel_diff1(get_distance_matrix, hps[1])                            kernels.py:98-118 */
+    FVGP_KERNEL_MATERN52_ISO = 5  /* hps[0]*matern_kernel_diff2(get_distance_matrix, hps[1])                            kernels.py:166-188 */
+};
+
+enum fvgp_uplo { FVGP_FULL = 0, FVGP_LOWER = 1 };
+
+#define FVGP_TILE 128
+#define FVGP_MAX_DIM 16     /* input dimension limit of the assembly kernels */
+#define FVGP_MAX_RHS_VEC 8  /* potrs switches from the GEMV path to the GEMM path above this */
+
+int fvgp_hip_version(void);
+const char *fvgp_hip_last_error_string(void);
+int64_t fvgp_hip_padded_dim(int64_t n);
+
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL */
+int fvgp_hip_create(fvgp_handle **out, int device, void *stream);
+int fvgp_hip_destroy(fvgp_handle *h);
+int fvgp_hip_sync(fvgp_handle *h);
+/* keys: "outer_block" (K of the trailing SYRK, multiple of 128), "profile" (0/1: time
+ * the trailing-update launches with HIP events, read back by fvgp_hip_get_profile) */
+int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value);
+/* out[0] = number of trailing-update launches of the last potrf, out[1] = their summed
+ * duration in ms, out[2] = their summed algorithmic flops, out[3] = whole-potrf ms */
+int fvgp_hip_get_profile(fvgp_handle *h, double *out4_host);
+
+/* ---- covariance assembly -------------------------------------------------------------
+ * replaces GPprior.compute_covariances -> kernel(x1,x2,hps) (gp_prior.py:217-224) and,
+ * with vdiag, GPkv.addKV (gp_kv.py:639-669) fused into the same pass.
+ * x1 (n1,d), x2 (n2,d) row-major device; theta host; K (rows, ldk).
+ * uplo = FVGP_LOWER writes only tiles on/below the diagonal (requires x1 == x2 semantics).
+ * pad != 0: K has padded_dim(n1) rows and ldk >= padded_dim(n2); padding is written
+ *           (1 on the diagonal, else 0).  pad == 0: exactly n1 x n2 entries are written. */
+int fvgp_hip_kmat(fvgp_handle *h, int kernel_id, const double *x1, int64_t n1, const double *x2, int64_t n2,
+                  int d, const double *theta_host, int ntheta, const double *vdiag_or_null,
+                  double *K, int64_t ldk, int uplo, int pad);
+
+/* ---- dense Cholesky ------------------------------------------------------------------
+ * potrf  : calculate_Chol_factor   gp_lin_alg.py:237-269   (scipy cho_factor -> dpotrf)
+ * potrs  : calculate_Chol_solve    gp_lin_alg.py:289-328   (cho_solve -> dpotrs)
+ * logdet : calculate_Chol_logdet   gp_lin_alg.py:331-360   (2*sum(log|diag|))
+ * potri  : calculate_inv_from_chol gp_lin_alg.py:1558-1578 (KV^-1 from L), lower triangle
+ * A / L: padded_dim(n) rows, lda >= padded_dim(n).  B: (padded_dim(n), ldb) row-major,
+ * nrhs columns used; rows >= n of B are overwritten with zeros. */
+int fvgp_hip_potrf(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host);
+int fvgp_hip_potrs(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb);
+int fvgp_hip_logdet(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *out_host);
+int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *work, int64_t ldw);
+/* forward half only: B <- L^-1 B (used by the posterior covariance, gp_posterior.py:120-136) */
+int fvgp_hip_trsm_lower(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb);
+
+/* ---- fused evaluations ----------------------------------------------------------------
+ * loglik: GPMarginalLikelihood.log_likelihood(theta)  gp_marginal_likelihood.py:137-179
+ *         = kernel -> addKV -> potrf -> potrs -> logdet -> scalar, nothing leaves HBM.
+ *   ymean  (n, ncol) row-major = y - m   (default mean: gp_prior.py:449-458, done by caller)
+ *   KV     scratch, padded_dim(n) x ld; holds the factor L on return
+ *   alpha  (padded_dim(n), ncol) receives KVinvY
+ *   out_host[0] = log marginal likelihood, [1] = log|KV|, [2] = sum((y-m)*KVinvY)/ncol */
+int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                    const double *theta_host, int ntheta, const double *vdiag,
+                    const double *ymean, int ncol, double *KV, int64_t ld,
+                    double *alpha, double *out_host, int *info_host);
+
+/* loglik_grad: GPMarginalLikelihood.neg_log_likelihood_gradient  gp_marginal_likelihood.py:224-309
+ *   g_i = 1/2 sum_jk (KVinv_jk - b_j b_k) dK_jk/dtheta_i,  b = KVinvY[:,component];
+ *   dK/dtheta re-evaluated on the fly (gp_prior.py:421-436, gp_bo.py:167-201).
+ *   KV on entry: the factor L from fvgp_hip_loglik / potrf (destroyed: holds KV^-1 lower on return)
+ *   work: second padded_dim(n) x ld scratch.  grad_host: ntheta doubles. */
+int fvgp_hip_loglik_grad(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                         const double *theta_host, int ntheta, const double *alpha, int ncol, int component,
+                         double *KV, int64_t ld, double *work, int64_t ldw, double *grad_host);
+
+/* posterior: GPposterior.posterior_mean / posterior_covariance  gp_posterior.py:139-182,229-288
+ *   L: factor (padded), alpha: KVinvY (padded_dim(n), ncol)
+ *   kx: scratch padded_dim(n) x ldk with ldk >= padded_dim(P); holds L^-1 k on return
+ *   mean_out (P, ncol) device  = k^T alpha          (prior mean added by the caller)
+ *   S_out (padded_dim(P), lds) device or NULL  = kk - k^T KV^-1 k  (full, symmetric)
+ *   var_out (P) device  = diag of the above (unclipped; clipping is gp_posterior.py:248-259, caller side) */
+int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                       const double *theta_host, int ntheta, const double *L, int64_t ldl,
+                       const double *alpha, int ncol, const double *xpred, int64_t P,
+                       double *kx, int64_t ldk, double *mean_out, double *var_out, double *S_out, int64_t lds);
+
+/* ---- building blocks exported for the parity tests --------------------------------------
+ * C (M,N) = alpha * opA * opB + beta * C on fp64 MFMA.  M, N multiples of 128, K of 16.
+ *   a_kmajor == 0: A stored (M,K) row-major;  != 0: A stored (K,M) row-major (A^T product)
+ *   b_nmajor == 0: B stored (N,K) row-major (C = A B^T); != 0: B stored (K,N) row-major
+ *   lower != 0: only 128x128 tiles with row-tile >= col-tile are computed (SYRK-style) */
+int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t M, int64_t N, int64_t K,
+                  double alpha, const double *A, int64_t lda, const double *B, int64_t ldb,
+                  double beta, double *C, int64_t ldc);
+/* one 64-lane wave: D = A(16x4) * B(4x16) with the lane maps the kernels assume */
+int fvgp_hip_mfma_selftest(fvgp_handle *h, const double *A16x4, const double *B4x16, double *D16x16);
+/* mirror the lower triangle into the upper (for exporting K / KV^-1 to numpy) */
+int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

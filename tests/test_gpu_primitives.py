@@ -1,0 +1,305 @@
+"""HIP kernels through the C ABI (fvgp_amd/_lib.py -> libfvgp_hip.so) against numpy/scipy and the
+oracle, on sizes the CPU finishes in seconds.  Mirrors tests/test_fvgp.py:44-182 of the reference
+(GPU vs CPU linalg), with its rtol 1e-5 tightened to the fp64 bars of SURVEY 8c."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+from conftest import load_golden, synth
+from oracle import fvgp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope="module")
+def H():
+    from fvgp_amd import _lib
+    h = _lib.Handle(0)
+    yield h
+    h.close()
+
+
+def _padded(H, a, rows_pad=None, cols_pad=None, fill=0.0):
+    """host (r,c) array -> device tensor padded to multiples of 128 (zeros)."""
+    from fvgp_amd._lib import pad128
+    r, c = a.shape
+    rp = rows_pad or pad128(r)
+    cp = cols_pad or pad128(c)
+    buf = np.full((rp, cp), fill)
+    buf[:r, :c] = a
+    return H.to_device(buf)
+
+
+def test_mfma_lane_maps(H):
+    """A = 16x4, B = 4x16 with distinct integer entries: exact product, asymmetric operands."""
+    rng = np.random.default_rng(1)
+    A = rng.integers(-50, 50, (16, 4)).astype(float)
+    B = rng.integers(-50, 50, (4, 16)).astype(float)
+    D = H.zeros(16, 16)
+    H.mfma_selftest(H.to_device(A), H.to_device(B), D)
+    H.sync()
+    assert np.array_equal(D.cpu().numpy(), A @ B)
+
+
+@pytest.mark.parametrize("akm", [0, 1])
+@pytest.mark.parametrize("bnm", [0, 1])
+@pytest.mark.parametrize("lower", [0, 1])
+def test_gemm_layouts(H, akm, bnm, lower):
+    rng = np.random.default_rng(10 + akm * 4 + bnm * 2 + lower)
+    M, N, K = 384, 256 if not lower else 384, 176
+    opA = rng.standard_normal((M, K))
+    opB = rng.standard_normal((K, N))
+    C0 = rng.standard_normal((M, N))
+    A = H.to_device(opA.T.copy() if akm else opA)
+    B = H.to_device(opB if bnm else opB.T.copy())
+    C = H.to_device(C0)
+    H.gemm(akm, bnm, lower, M, N, K, -0.75, A, B, 1.25, C)
+    H.sync()
+    ref = -0.75 * opA @ opB + 1.25 * C0
+    got = C.cpu().numpy()
+    scale = np.abs(opA) @ np.abs(opB)
+    if lower:
+        for ti in range(M // 128):
+            for tj in range(N // 128):
+                sl = (slice(ti * 128, ti * 128 + 128), slice(tj * 128, tj * 128 + 128))
+                if tj <= ti:
+                    assert np.max(np.abs(got[sl] - ref[sl]) / scale[sl]) < 8 * EPS
+                else:
+                    assert np.array_equal(got[sl], C0[sl]), "tile above the diagonal must be untouched"
+    else:
+        assert np.max(np.abs(got - ref) / scale) < 8 * EPS
+
+
+def test_gemm_beta_zero_and_big_k(H):
+    rng = np.random.default_rng(3)
+    M, N, K = 128, 128, 2048
+    a = rng.standard_normal((M, K)); b = rng.standard_normal((N, K))
+    C = H.to_device(np.full((M, N), np.nan))          # beta = 0 must not read C
+    H.gemm(0, 0, 0, M, N, K, 1.0, H.to_device(a), H.to_device(b), 0.0, C)
+    H.sync()
+    got = C.cpu().numpy()
+    assert np.max(np.abs(got - a @ b.T) / (np.abs(a) @ np.abs(b.T))) < 32 * EPS
+
+
+KERNEL_CASES = [("rbf_ard", 3), ("matern32_ard", 2), ("matern52_ard", 3), ("rbf_ard", 1), ("matern52_ard", 5),
+                ("rbf_iso", 2), ("matern32_iso", 3), ("matern52_iso", 2)]
+
+
+@pytest.mark.parametrize("name,d", KERNEL_CASES)
+def test_kmat_rectangular(H, name, d):
+    from fvgp_amd import _lib
+    rng = np.random.default_rng(5)
+    x1 = rng.random((300, d)); x2 = rng.random((201, d))
+    theta = np.concatenate([[1.7], 0.2 + rng.random(d if name.endswith("ard") else 1)])
+    ref = orc.KERNELS[name](x1, x2, theta)
+    K = H.to_device(np.full((300, 201), np.nan))
+    H.kmat(_lib.KERNEL_IDS[name], H.to_device(x1), H.to_device(x2), theta, K, pad=_lib.PAD_NONE)
+    H.sync()
+    got = K.cpu().numpy()
+    # K entries within a few ulp of sigma^2
+    assert np.max(np.abs(got - ref)) <= 8 * EPS * theta[0]
+    # padded variant with zero fill
+    Kp = H.to_device(np.full((384, 256), np.nan))
+    H.kmat(_lib.KERNEL_IDS[name], H.to_device(x1), H.to_device(x2), theta, Kp, pad=_lib.PAD_ZERO)
+    H.sync()
+    gp = Kp.cpu().numpy()
+    assert np.array_equal(gp[:300, :201], got)
+    assert np.all(gp[300:, :] == 0) and np.all(gp[:, 201:] == 0)
+
+
+@pytest.mark.parametrize("name,d", KERNEL_CASES[:4])
+def test_kmat_lower_padded_with_noise(H, name, d):
+    from fvgp_amd import _lib
+    rng = np.random.default_rng(6)
+    n = 333
+    x = rng.random((n, d))
+    theta = np.concatenate([[0.9], 0.25 + rng.random(d)])
+    v = 0.01 + rng.random(n)
+    ref = orc.addKV(orc.KERNELS[name](x, x, theta), v)
+    K = H.to_device(np.full((384, 384), np.nan))
+    xd = H.to_device(x)
+    H.kmat(_lib.KERNEL_IDS[name], xd, xd, theta, K, vdiag=H.to_device(v), uplo=_lib.LOWER, pad=_lib.PAD_IDENTITY)
+    H.sync()
+    got = K.cpu().numpy()
+    il = np.tril_indices(n)
+    assert np.max(np.abs(got[:n, :n][il] - ref[il])) <= 8 * EPS * theta[0]
+    # padding = identity (lower tiles), and tiles strictly above the block diagonal untouched (NaN)
+    assert np.array_equal(np.tril(got[n:, :])[:, :n], np.zeros((384 - n, n)))
+    assert np.array_equal(np.diag(got)[n:], np.ones(384 - n))
+    assert np.all(np.isnan(got[:128, 128:]))
+
+
+def _spd(n, seed):
+    rng = np.random.default_rng(seed)
+    B = rng.standard_normal((n, n))
+    return B @ B.T + n * np.eye(n)
+
+
+@pytest.mark.parametrize("n", [96, 128, 200, 512, 1000, 1537])
+@pytest.mark.parametrize("outer", [128, 512])
+def test_potrf_solve_logdet(H, n, outer):
+    """calculate_Chol_factor / _solve / _logdet (gp_lin_alg.py:237-360) on B B^T + n I."""
+    from fvgp_amd._lib import pad128
+    M = _spd(n, n)
+    H.set_option("outer_block", outer)
+    npad = pad128(n)
+    buf = np.full((npad, npad), np.nan)       # strict upper left as NaN: the kernels must never read it
+    buf[:n, :n] = np.tril(M) + np.triu(np.full((n, n), np.nan), 1)
+    buf[n:, :] = 0.0
+    buf[n:, n:] = np.tril(np.eye(npad - n)) + np.triu(np.full((npad - n, npad - n), np.nan), 1)
+    A = H.to_device(buf)
+    info = H.potrf(A, n)
+    assert info == 0
+    L = np.tril(A.cpu().numpy()[:n, :n])
+    Lref = np.tril(sla.cho_factor(M, lower=True)[0])
+    assert np.max(np.abs(L - Lref)) / np.max(np.abs(Lref)) < 1e-13
+    np.testing.assert_allclose(H.logdet(A, n), 2 * np.sum(np.log(np.diag(Lref))), rtol=1e-13)
+    rng = np.random.default_rng(n + 1)
+    for nrhs in (1, 3, 8):
+        rhs = rng.standard_normal((n, nrhs))
+        B = _padded(H, rhs, cols_pad=nrhs, fill=7.0)   # junk in padding rows must be cleared
+        H.potrs(A, n, B, nrhs)
+        H.sync()
+        ref = sla.cho_solve((Lref, True), rhs)
+        got = B.cpu().numpy()
+        assert np.max(np.abs(got[:n] - ref)) / np.max(np.abs(ref)) < 1e-12
+        assert np.all(got[n:] == 0)
+    rhs = rng.standard_normal((n, 128))
+    B = _padded(H, rhs)
+    H.potrs(A, n, B, 128)
+    H.sync()
+    ref = sla.cho_solve((Lref, True), rhs)
+    assert np.max(np.abs(B.cpu().numpy()[:n] - ref)) / np.max(np.abs(ref)) < 1e-12
+    B = _padded(H, rhs)
+    H.trsm_lower(A, n, B, 128)
+    H.sync()
+    ref = sla.solve_triangular(Lref, rhs, lower=True)
+    assert np.max(np.abs(B.cpu().numpy()[:n] - ref)) / np.max(np.abs(ref)) < 1e-12
+    H.set_option("outer_block", 512)
+
+
+def test_potrf_nonpd_info(H):
+    """dpotrf info: order of the first non-positive leading minor (tests/test_fvgp.py:4653-4665)."""
+    fx = load_golden("G7_nonpd.npz")
+    A = _padded(H, np.tril(fx["M"]))
+    A[96:, 96:] = H.to_device(np.eye(32))
+    assert H.potrf(A, 96) == int(fx["info"])
+    # and a failure in a later diagonal block of a larger matrix
+    M = _spd(700, 9)
+    M[444, 444] = -3.0
+    A = _padded(H, np.tril(M))
+    A[700:, 700:] = H.to_device(np.eye(68))
+    try:
+        sla.cho_factor(M, lower=True)
+        raise AssertionError("scipy accepted it?")
+    except np.linalg.LinAlgError as e:
+        assert "445-th leading minor" in str(e)
+    assert H.potrf(A, 700) == 445
+
+
+def test_golden_lin_alg_block(H):
+    fx = load_golden("G7_nonpd.npz")
+    A = _padded(H, np.tril(fx["Mok"]))
+    A[96:, 96:] = H.to_device(np.eye(32))
+    assert H.potrf(A, 96) == 0
+    np.testing.assert_allclose(np.tril(A.cpu().numpy()[:96, :96]), fx["Lok"], rtol=0, atol=1e-13 * np.max(fx["Lok"]))
+    B = _padded(H, fx["rhs"], cols_pad=3)
+    H.potrs(A, 96, B, 3)
+    H.sync()
+    np.testing.assert_allclose(B.cpu().numpy()[:96], fx["sol"], rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(H.logdet(A, 96), float(fx["logdet"]), rtol=1e-13)
+
+
+@pytest.mark.parametrize("n", [128, 300, 900])
+def test_potri(H, n):
+    from fvgp_amd._lib import pad128
+    M = _spd(n, 40 + n)
+    npad = pad128(n)
+    buf = np.zeros((npad, npad)); buf[:n, :n] = np.tril(M); buf[n:, n:] = np.eye(npad - n)
+    A = H.to_device(buf)
+    assert H.potrf(A, n) == 0
+    W = H.empty(npad, npad)
+    H.potri(A, n, W)
+    H.sync()
+    inv = np.linalg.inv(M)
+    got = np.tril(A.cpu().numpy()[:n, :n])
+    assert np.max(np.abs(got - np.tril(inv))) / np.max(np.abs(inv)) < 1e-11
+    H.symmetrize(A, n)
+    H.sync()
+    full = A.cpu().numpy()[:n, :n]
+    assert np.max(np.abs(full - inv)) / np.max(np.abs(inv)) < 1e-11
+
+
+GOLD = ["G1_rbf_n500_d1.npz", "G2_rbf_n512_d3.npz", "G3_matern52_n512_d3.npz", "G6_rbf_2col_n300_d3.npz",
+        "G5_fvgp_4x64.npz", "G5n_fvgp_4x64_nan.npz"]
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_fused_loglik_grad_against_reference_vectors(H, name):
+    """fvgp_hip_loglik / _loglik_grad against the values the reference itself produced."""
+    from fvgp_amd import _lib
+    fx = load_golden(name)
+    x = fx["x"]; y = fx["y"].reshape(len(x), -1); n = len(x)
+    kid = _lib.KERNEL_IDS[str(fx["kernel"])]
+    ym = y - np.mean(y)
+    npad = _lib.pad128(n)
+    xd, vd, ymd = H.to_device(x), H.to_device(fx["noise_variances"]), H.to_device(ym)
+    KV = H.empty(npad, npad); W = H.empty(npad, npad); alpha = H.empty(npad, y.shape[1])
+    for theta, ll_ref in [(fx["theta"], float(fx["loglik_theta"]))] + list(zip(fx["thetas"], fx["logliks"])):
+        ll, logdet, quad, info = H.loglik(kid, xd, theta, vd, ymd, KV, alpha)
+        assert info == 0
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-10)       # log-lik rel <= 1e-10
+    ll, logdet, quad, info = H.loglik(kid, xd, fx["theta"], vd, ymd, KV, alpha)
+    np.testing.assert_allclose(logdet, float(fx["logdet"]), rtol=1e-10)
+    a = alpha.cpu().numpy()[:n]
+    assert np.max(np.abs(a - fx["KVinvY"])) / np.max(np.abs(fx["KVinvY"])) < 1e-8   # KVinvY rel <= 1e-8
+    Lg = np.tril(KV.cpu().numpy()[:n, :n])
+    np.testing.assert_allclose(np.diag(Lg), fx["L_diag"], rtol=1e-10)
+    np.testing.assert_allclose(Lg[-1, :], fx["L_row_last"], rtol=0, atol=1e-10 * np.max(np.abs(fx["L_diag"])))
+    g = H.loglik_grad(kid, xd, fx["theta"], alpha, y.shape[1], 0, KV, W)
+    np.testing.assert_allclose(g, fx["grad"], rtol=1e-8, atol=1e-9 * np.max(np.abs(fx["grad"])))
+    if "grad_c1" in fx:
+        ll, logdet, quad, info = H.loglik(kid, xd, fx["theta"], vd, ymd, KV, alpha)
+        g = H.loglik_grad(kid, xd, fx["theta"], alpha, y.shape[1], 1, KV, W)
+        np.testing.assert_allclose(g, fx["grad_c1"], rtol=1e-8, atol=1e-9 * np.max(np.abs(fx["grad_c1"])))
+
+
+@pytest.mark.parametrize("name", GOLD[:4])
+def test_posterior_against_reference_vectors(H, name):
+    from fvgp_amd import _lib
+    fx = load_golden(name)
+    x = fx["x"]; y = fx["y"].reshape(len(x), -1); n = len(x); c = y.shape[1]
+    kid = _lib.KERNEL_IDS[str(fx["kernel"])]
+    m = np.mean(y)
+    npad = _lib.pad128(n)
+    xd, vd, ymd = H.to_device(x), H.to_device(fx["noise_variances"]), H.to_device(y - m)
+    KV = H.empty(npad, npad); alpha = H.empty(npad, c)
+    H.loglik(kid, xd, fx["theta"], vd, ymd, KV, alpha)
+    xp = fx["x_pred"]; P = len(xp); Pp = _lib.pad128(P)
+    kx = H.empty(npad, Pp); mean = H.empty(P, c); var = H.empty(P); S = H.empty(Pp, Pp)
+    H.posterior(kid, xd, fx["theta"], KV, alpha, c, H.to_device(xp), kx, mean, var, S)
+    H.sync()
+    pm = mean.cpu().numpy() + m
+    np.testing.assert_allclose(np.squeeze(pm), fx["pm_flat"], rtol=1e-8, atol=1e-10)
+    Sg = S.cpu().numpy()[:P, :P]
+    assert np.max(np.abs(Sg - fx["pS_flat"])) < 1e-10 * fx["theta"][0] + 1e-12
+    vflat = fx["pv_flat"] if fx["pv_flat"].ndim == 1 else fx["pv_flat"][:, 0]
+    assert np.max(np.abs(var.cpu().numpy() - vflat)) < 1e-10 * fx["theta"][0] + 1e-12   # variance abs <= 1e-10 sigma^2
+
+
+def test_loglik_matches_oracle_medium(H):
+    """N = 3000, d = 3 RBF on the bench generator: HIP path vs the oracle on the same inputs."""
+    from fvgp_amd import _lib
+    n = 3000
+    x, y = synth(n, 3)
+    nv = np.full(n, 0.01)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    ref, _ = orc.log_likelihood_once(x, y, nv, theta, "rbf_ard")
+    npad = _lib.pad128(n)
+    ym = (y - np.mean(y)).reshape(n, 1)
+    KV = H.empty(npad, npad); alpha = H.empty(npad, 1)
+    ll, logdet, quad, info = H.loglik(0, H.to_device(x), theta, H.to_device(nv), H.to_device(ym), KV, alpha)
+    assert info == 0
+    np.testing.assert_allclose(ll, ref, rtol=1e-10)
