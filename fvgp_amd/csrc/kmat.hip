@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void kmat_kernel(KArgs a) {
             }
         }
         double v0 = radial<KIND>(s0, a.sig), v1 = radial<KIND>(s1, a.sig);
-        if (!(rok && ok0)) v0 = (row == c0) ? 1.0 : 0.0;
-        if (!(rok && ok1)) v1 = (row == c1) ? 1.0 : 0.0;
+        if (!(rok && ok0)) v0 = (a.pad == 1 && row == c0) ? 1.0 : 0.0;
+        if (!(rok && ok1)) v1 = (a.pad == 1 && row == c1) ? 1.0 : 0.0;
         if (a.vdiag != nullptr && rok) {
             if (row == c0 && ok0) v0 += a.vdiag[row];
             if (row == c1 && ok1) v1 += a.vdiag[row];
