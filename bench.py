@@ -1,0 +1,171 @@
+"""Headline benchmark: log-marginal-likelihood evaluations / second, N=50 000, d=3, RBF, fp64.
+
+One "step" = one GP.log_likelihood(theta_t) with a NEW theta_t on data already resident in HBM:
+covariance assembly (+noise) -> blocked Cholesky -> two triangular solves -> log-det -> scalar
+(SURVEY 8d).  Usage (driver contract):
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: every rank evaluates its own theta sequence on its own GPU (independent replicas of the
+population of hyperparameter proposals a trainer evaluates -- SURVEY 8e "replicas-only"); no
+data-path collective, "scaling": "weak".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X dense fp64 matrix peak: 256 CU x 2.4 GHz x 128 flop/clk/CU
+PEAK_HBM_GBS = 8000.0
+
+
+def synth(n, d, seed=20240501):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, d))
+    y = np.sin(3.0 * np.sum(x, axis=1)) + 0.1 * rng.standard_normal(n)
+    return x, y
+
+
+def cpu_baseline(n_full, d, sample_n):
+    """The oracle (numpy/scipy restatement of the reference path) timed on this host on a bounded
+    sample, scaled to N = n_full with the stage exponents (assembly, addKV, solve: N^2; potrf: N^3)."""
+    from oracle import fvgp_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    x, y = synth(sample_n, d)
+    nv = np.full(sample_n, 0.01)
+    theta = np.array([1.0] + [0.3] * d)
+    t0 = time.perf_counter()
+    _, st = orc.log_likelihood_once(x, y, nv, theta, "rbf_ard")
+    wall = time.perf_counter() - t0
+    r = n_full / sample_n
+    est = (st["kmat"] + st["addKV"] + st["solve_logdet"]) * r ** 2 + st["potrf"] * r ** 3
+    return {
+        "value": 1.0 / est, "unit": "evals/s", "cores": int(threads), "kind": "port",
+        "sample": (f"oracle (numpy/scipy restatement) on N={sample_n}, d={d}: kmat {st['kmat']:.2f}s addKV "
+                   f"{st['addKV']:.2f}s potrf {st['potrf']:.2f}s solve+logdet {st['solve_logdet']:.2f}s "
+                   f"(wall {wall:.1f}s, BLAS threads {threads}, host cpus {os.cpu_count()}); scaled to N={n_full} "
+                   f"with N^2 (assembly, addKV, solve) and N^3 (potrf) -> {est:.0f}s per evaluation"),
+        "measured_seconds_at_sample": wall,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=50000)
+    ap.add_argument("--d", type=int, default=3)
+    ap.add_argument("--outer-block", type=int, default=0, help="K of the trailing SYRK (0 = library default)")
+    ap.add_argument("--cpu-sample-n", type=int, default=18000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from fvgp_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+
+    n, d = args.n, args.d
+    x, y = synth(n, d)
+    H = _lib.Handle(local)
+    if args.outer_block:
+        H.set_option("outer_block", args.outer_block)
+    npad = _lib.pad128(n)
+    xd = H.to_device(x)
+    vd = H.to_device(np.full(n, 0.01))
+    ymd = H.to_device((y - np.mean(y)).reshape(n, 1))
+    KV = H.empty(npad, npad)
+    alpha = H.empty(npad, 1)
+    theta0 = np.array([1.0] + [0.3] * d)
+
+    def theta_at(t):
+        # every rank walks its own slice of the proposal sequence
+        return theta0 * (1.0 + 0.02 * (t * world + rank))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    vals = []
+    for t in range(args.warmup):
+        vals.append(H.loglik(0, xd, theta_at(t), vd, ymd, KV, alpha))
+    H.set_option("profile", 1)
+    prof = {"launches": 0.0, "ms": 0.0, "flops": 0.0, "potrf_ms": 0.0}
+    sync_all()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        ll, logdet, quad, info = H.loglik(0, xd, theta_at(args.warmup + t), vd, ymd, KV, alpha)
+        if info != 0 or not np.isfinite(ll):
+            raise SystemExit(f"evaluation {t} failed: info={info} loglik={ll}")
+        p = H.get_profile()
+        for k in prof:
+            prof[k] += p[k]
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    H.set_option("profile", 0)
+
+    if rank == 0:
+        evals = args.steps * world
+        ms_per_step = 1e3 * elapsed / args.steps
+        syrk_tflops = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+        potrf_tflops = (args.steps * (n ** 3) / 3.0) / (prof["potrf_ms"] * 1e-3) / 1e12 if prof["potrf_ms"] > 0 else 0.0
+        out = {
+            "metric": "log_marginal_likelihood_evals_per_sec", "value": evals / elapsed, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"N={n} d={d} RBF(ARD) log_likelihood(theta): K-assembly+noise, Cholesky, "
+                                   f"2 triangular solves, log-det", "n": n, "d": d, "kernel": "rbf_ard",
+                       "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (one theta stream per GPU)"},
+            "cholesky_tflops": potrf_tflops,
+            "cholesky_frac_of_fp64_mfma_peak": potrf_tflops / PEAK_FP64_MFMA_TFLOPS,
+            "loglik_last": ll,
+            "roofline": {
+                "kernel": "gemm_f64_kernel<0,0> (trailing SYRK, lower tiles)",
+                "bound": "mfma", "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1.0),
+                "algorithmic_flops_per_launch": prof["flops"] / max(prof["launches"], 1.0),
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_sample_n)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    H.close()
+
+
+if __name__ == "__main__":
+    main()
