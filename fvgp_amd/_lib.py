@@ -26,7 +26,7 @@ SYMBOLS = [
     "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
     "fvgp_hip_potrf", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_posterior", "fvgp_hip_gemm",
-    "fvgp_hip_mfma_selftest", "fvgp_hip_symmetrize",
+    "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
     L.fvgp_hip_gemm.argtypes = [c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l]
     L.fvgp_hip_mfma_selftest.argtypes = [c_p, c_p, c_p, c_p]
     L.fvgp_hip_symmetrize.argtypes = [c_p, c_p, c_l, c_l]
+    L.fvgp_hip_mfma_peak.argtypes = [c_p, c_p, c_i, c_i]
     for s in SYMBOLS:
         if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim"):
             getattr(L, s).restype = c_i
@@ -225,6 +226,9 @@ class Handle:
 
     def mfma_selftest(self, A, B, D):
         _check(lib().fvgp_hip_mfma_selftest(self._h, _ptr(A), _ptr(B), _ptr(D)), "fvgp_hip_mfma_selftest")
+
+    def mfma_peak(self, out, blocks, iters):
+        _check(lib().fvgp_hip_mfma_peak(self._h, _ptr(out), int(blocks), int(iters)), "fvgp_hip_mfma_peak")
 
     def symmetrize(self, A, n):
         _check(lib().fvgp_hip_symmetrize(self._h, _ptr(A), int(n), A.stride(0)), "fvgp_hip_symmetrize")

@@ -550,6 +550,14 @@ int fvgp_hip_mfma_selftest(fvgp_handle *h, const double *A, const double *B, dou
     return launch_mfma_selftest(h, A, B, D);
 }
 
+int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters) {
+    if (!h) return -1;
+    if (!out) return -2;
+    if (blocks < 1 || iters < 1) return -3;
+    HIPCHK(hipSetDevice(h->device));
+    return launch_mfma_peak(h, out, blocks, iters);
+}
+
 int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda) {
     if (!h) return -1;
     if (!A) return -2;

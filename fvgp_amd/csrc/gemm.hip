@@ -215,7 +215,35 @@ __global__ void mfma_selftest_kernel(const double *A, const double *B, double *D
     for (int v = 0; v < 4; ++v) D[(q + 4 * v) * 16 + r] = acc[v];
 }
 
+// register-only MFMA stream (no memory traffic): the ceiling the chip sustains for this
+// instruction mix under its own clock management; used by tools/ and DESIGN.md, not by the path
+__global__ __launch_bounds__(256, 2) void mfma_peak_kernel(double *out, int iters, double seed) {
+    double4_t acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = seed * (threadIdx.x + i + 1) * 1e-3; b[i] = seed * (threadIdx.x * 3 + i + 7) * 1e-3; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i * 4 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i * 4 + j], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace
+
+int launch_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters) {
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, out, iters, 1.0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 
 int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D) {
     hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, h->stream, A, B, D);

@@ -135,6 +135,9 @@ int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t
                   double beta, double *C, int64_t ldc);
 /* one 64-lane wave: D = A(16x4) * B(4x16) with the lane maps the kernels assume */
 int fvgp_hip_mfma_selftest(fvgp_handle *h, const double *A16x4, const double *B4x16, double *D16x16);
+/* diagnostic: blocks x 256 threads each issue iters x 16 register-only fp64 MFMAs (2048 flop each per wave);
+ * out needs blocks*256 doubles.  Gives the sustained fp64 MFMA ceiling of the device. */
+int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);
 /* mirror the lower triangle into the upper (for exporting K / KV^-1 to numpy) */
 int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda);
 
