@@ -27,6 +27,7 @@ SYMBOLS = [
     "fvgp_hip_potrf", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize",
+    "fvgp_hip_debug_tile_map",
 ]
 
 
@@ -93,8 +94,10 @@ def lib():
     L.fvgp_hip_mfma_selftest.argtypes = [c_p, c_p, c_p, c_p]
     L.fvgp_hip_symmetrize.argtypes = [c_p, c_p, c_l, c_l]
     L.fvgp_hip_mfma_peak.argtypes = [c_p, c_p, c_i, c_i]
+    L.fvgp_hip_debug_tile_map.argtypes = [c_i, c_i, c_i, P_i, P_i, c_l]
+    L.fvgp_hip_debug_tile_map.restype = c_l
     for s in SYMBOLS:
-        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim"):
+        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map"):
             getattr(L, s).restype = c_i
     _lib = L
     return L

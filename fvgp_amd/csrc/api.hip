@@ -550,6 +550,11 @@ int fvgp_hip_mfma_selftest(fvgp_handle *h, const double *A, const double *B, dou
     return launch_mfma_selftest(h, A, B, D);
 }
 
+int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int *out_ti, int *out_tj, int64_t cap) {
+    if (tiles_m < 1 || tiles_n < 1 || !out_ti || !out_tj) return -1;
+    return gemm_debug_tile_map(tiles_m, tiles_n, lower, out_ti, out_tj, cap);
+}
+
 int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters) {
     if (!h) return -1;
     if (!out) return -2;

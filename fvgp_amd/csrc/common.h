@@ -63,6 +63,7 @@ struct GemmDesc {
     int64_t kb0 = 0, kbi = 0, kbj = 0, ke0 = -1, kei = 0, kej = 0;
 };
 int launch_gemm(fvgp_handle *h, const GemmDesc &g);
+long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int *out_ti, int *out_tj, long cap);
 
 struct KmatDesc {
     int kind;                 // 0 rbf, 1 matern 3/2, 2 matern 5/2

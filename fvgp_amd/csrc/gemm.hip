@@ -40,7 +40,7 @@ struct GemmArgs {
 // linear index -> (ti, tj).  Tiles are enumerated in super-tiles of 8 x SN (SN = min(8, tiles_n)),
 // row-major inside a super-tile; in lower mode only super-tiles that touch ti >= tj exist
 // (super-row si holds min(si+1, sn) of them), so neighbours in the order share operand slabs.
-__device__ inline void tile_of(long t, int tiles_m, int tiles_n, int lower, int &ti, int &tj) {
+__host__ __device__ inline void tile_of(long t, int tiles_m, int tiles_n, int lower, int &ti, int &tj) {
     constexpr int S = 8;
     const int SN = tiles_n < S ? tiles_n : S;
     const int sn = (tiles_n + SN - 1) / SN;
@@ -251,6 +251,32 @@ int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, doubl
     return 0;
 }
 
+static long gemm_grid_tiles(int tiles_m, int tiles_n, int lower) {
+    // whole super-tiles (out-of-range tiles exit at once); must mirror tile_of()
+    const long S = 8;
+    const long SN = tiles_n < S ? tiles_n : S;
+    const long sm = (tiles_m + S - 1) / S, sn = (tiles_n + SN - 1) / SN;
+    long nst;
+    if (lower && SN == S) {
+        if (sm <= sn) nst = sm * (sm + 1) / 2;
+        else nst = sn * (sn + 1) / 2 + (sm - sn) * sn;
+    } else nst = sm * sn;
+    return nst * S * SN;
+}
+
+// host-side replay of the blockIdx -> tile map (XCD remap included) for the CPU tests
+long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int *out_ti, int *out_tj, long cap) {
+    const long nwg = gemm_grid_tiles(tiles_m, tiles_n, lower);
+    for (long b = 0; b < nwg && b < cap; ++b) {
+        const long q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+        const long t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+        int ti, tj;
+        tile_of(t, tiles_m, tiles_n, lower, ti, tj);
+        out_ti[b] = ti; out_tj[b] = tj;
+    }
+    return nwg;
+}
+
 int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     if (d.M <= 0 || d.N <= 0) return 0;
     if (d.M % 128 || d.N % 128 || d.K % BK || d.K < 0) { fvgp_set_error("gemm: M,N must be multiples of 128 and K of 16"); return -5; }
@@ -262,16 +288,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.alpha = d.alpha; g.beta = d.beta; g.K = d.K;
     g.tiles_m = (int)(d.M / 128); g.tiles_n = (int)(d.N / 128); g.lower = d.lower;
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
-    // grid = whole super-tiles (out-of-range tiles exit at once); must mirror tile_of()
-    const long S = 8;
-    const long SN = g.tiles_n < S ? g.tiles_n : S;
-    const long sm = (g.tiles_m + S - 1) / S, sn = (g.tiles_n + SN - 1) / SN;
-    long nst;
-    if (d.lower && SN == S) {
-        if (sm <= sn) nst = sm * (sm + 1) / 2;
-        else nst = sn * (sn + 1) / 2 + (sm - sn) * sn;
-    } else nst = sm * sn;
-    g.ntiles = nst * S * SN;
+    g.ntiles = gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower);
     dim3 grid((unsigned)g.ntiles), block(256);
 #define GO(AK, BN) hipLaunchKernelGGL((gemm_f64_kernel<AK, BN>), grid, block, 0, h->stream, g)
     if (!d.a_kmajor && !d.b_nmajor) GO(0, 0);

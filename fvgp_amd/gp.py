@@ -1,0 +1,538 @@
+"""GP -- the drop-in facade for the hot path of fvgp.GP (fvgp/gp.py:26,419-439).
+
+Same constructor arguments, method names, argument meaning, return dictionaries and error
+behaviour as the reference for the path BASELINE.json's north_star names:
+
+    __init__ -> state build                         fvgp/gp.py:483-568, gp_kv.py:404-423
+    log_likelihood / neg_log_likelihood             fvgp/gp.py:1310, gp_marginal_likelihood.py:137-179
+    neg_log_likelihood_gradient                     fvgp/gp.py:1332, gp_marginal_likelihood.py:224-309
+    posterior_mean / posterior_covariance           fvgp/gp.py:1376,1433, gp_posterior.py:139-182,229-288
+    set_hyperparameters / update_gp_data            fvgp/gp.py:672-687,689
+    properties K, V, m, hyperparameters, x_data, y_data   fvgp/gp.py:576-647
+
+What differs, by design: x, y-m, V, the factor L and KVinvY live in HBM for the life of the
+object; an evaluation moves theta in and a scalar / (H,) / (P,) / (P,P) result out.  All of
+the arithmetic is in libfvgp_hip.so -- there is no CPU fallback (compute_device="cpu" raises).
+The kernel is one of the named stationary kernels of fvgp_amd.kernels (None = the reference
+default); any other callable is evaluated on the host exactly as the reference would and
+uploaded (slow path, one N^2 transfer per evaluation, warned once).
+"""
+import inspect
+import warnings
+
+import numpy as np
+
+from . import _lib
+from . import kernels as _kernels
+from .device import default_handle
+from .gp_lin_alg import NonPositiveDefiniteError, _non_pd_message
+
+
+class GP:
+    def __init__(
+        self,
+        x_data,
+        y_data,
+        init_hyperparameters=None,
+        noise_variances=None,
+        compute_device="gpu",
+        kernel_function=None,
+        kernel_function_grad=None,
+        noise_function=None,
+        noise_function_grad=None,
+        prior_mean_function=None,
+        prior_mean_function_grad=None,
+        gp2Scale=False,
+        dask_client=None,
+        gp2Scale_batch_size=10000,
+        gp2Scale_distribution="blockwise",
+        linalg_mode=None,
+        ram_economy=False,
+        args=None,
+    ):
+        # --- argument checks: fvgp/gp.py:441-452, gp_data.py:15-24 ---------------------------
+        assert isinstance(noise_variances, np.ndarray) or noise_variances is None, "wrong format in noise_variances"
+        assert init_hyperparameters is None or isinstance(init_hyperparameters, np.ndarray), "wrong init_hyperparameters"
+        assert isinstance(compute_device, str), "wrong format in compute_device"
+        assert (callable(kernel_function) or kernel_function is None
+                or isinstance(kernel_function, str)), "wrong format in kernel_function"
+        assert callable(noise_function) or noise_function is None, "wrong format in noise_function"
+        assert callable(prior_mean_function) or prior_mean_function is None, "wrong format in prior_mean_function"
+        assert isinstance(x_data, np.ndarray) and np.ndim(x_data) == 2, \
+            "Euclidean x_data must be 2-d (n_points x input_dim); non-Euclidean inputs are not on the native path"
+        assert isinstance(y_data, np.ndarray) and np.ndim(y_data) in (1, 2), "y_data must be a 1-d or 2-d np.ndarray"
+        assert len(x_data) == len(y_data), "x_data and y_data do not have the same lengths."
+        if compute_device not in ("gpu", "hip"):
+            raise Exception("No valid compute device found. fvgp_amd runs on the MI355X only: "
+                            "compute_device must be 'gpu' (there is no CPU path in this engine).")
+        if gp2Scale:
+            raise NotImplementedError("gp2Scale (sparse, Dask-distributed) is outside this engine's scope; "
+                                      "the dense path scales by sharding over GPUs (fvgp_amd.dist).")
+        if linalg_mode not in (None, "Chol"):
+            raise NotImplementedError("only the dense Cholesky mode ('Chol') runs natively")
+        if isinstance(noise_variances, np.ndarray):
+            assert np.ndim(noise_variances) == 1, "noise_variances must be 1-d"
+            assert len(noise_variances) == len(y_data), "noise_variances and y_data have different lengths"
+            assert np.all(noise_variances > 0.0), "all noise_variances must be positive"
+        if noise_variances is not None and callable(noise_function):
+            raise Exception("Noise function and measurement noise provided. Decide which one to use.")
+
+        self.args = {} if args is None else args
+        self.compute_device = "gpu"
+        self.ram_economy = ram_economy
+        self._H = default_handle()
+        self._set_data(x_data, y_data, noise_variances)
+        self.x_out = None
+
+        # --- kernel / mean / noise selection: gp_prior.py:57-93, gp_likelihood.py:27-38 -----------
+        self._native = _kernels.resolve(kernel_function)
+        self._kernel_callable = None if self._native is not None else kernel_function
+        self._k_n_params = 3 if self._native is not None else len(inspect.signature(kernel_function).parameters)
+        self._kernel_grad_callable = kernel_function_grad
+        self._mean_callable = prior_mean_function
+        self._m_n_params = 2 if prior_mean_function is None else len(inspect.signature(prior_mean_function).parameters)
+        self._mean_grad_callable = prior_mean_function_grad
+        self._noise_callable = noise_function
+        self._v_n_params = 2 if noise_function is None else len(inspect.signature(noise_function).parameters)
+        self._noise_grad_callable = noise_function_grad
+        if noise_function is None and noise_variances is None:
+            warnings.warn("No noise function or measurement noise provided. "
+                          "Noise variances will be set to (0.01 * mean(|y_data|))^2.", stacklevel=2)
+        if self._native is None:
+            warnings.warn("kernel_function is a Python callable: it is evaluated on the host and the N x N "
+                          "matrix is uploaded for every evaluation (slow path). Use a named kernel from "
+                          "fvgp_amd.kernels to assemble on the GPU.", stacklevel=2)
+
+        # --- hyperparameters: gp.py:488-505 ---------------------------------------------------
+        user_callables = (self._native is None) or callable(prior_mean_function) or callable(noise_function)
+        if init_hyperparameters is None:
+            if user_callables:
+                raise Exception("You have provided callables for kernel, mean, or noise functions but no "
+                                "initial hyperparameters.")
+            init_hyperparameters = np.ones(self._native.n_hyperparameters(self.index_set_dim))
+            warnings.warn("Hyperparameters initialized to a vector of ones.")
+        self._work = None      # scratch KV for evaluations at new theta (never the state)
+        self._work2 = None
+        self._alpha_work = None
+        self._K_host = None
+        self.set_hyperparameters(np.array(init_hyperparameters, dtype=np.float64))
+
+    # ------------------------------------------------------------------------------------------
+    # data
+    # ------------------------------------------------------------------------------------------
+    def _set_data(self, x_data, y_data, noise_variances):
+        if np.ndim(y_data) == 1:                                  # gp_data.py:24
+            y_data = y_data.reshape(len(y_data), 1)
+        self.x_data = np.ascontiguousarray(x_data, dtype=np.float64)
+        self.y_data = np.ascontiguousarray(y_data, dtype=np.float64)
+        self.noise_variances = noise_variances
+        self.index_set_dim = self.input_set_dim = self.x_data.shape[1]
+        self.point_number = len(self.x_data)
+        if self.index_set_dim > 16:
+            raise NotImplementedError("the assembly kernels take input dimension <= 16")
+        n = self.point_number
+        H = self._H
+        self._np = _lib.pad128(n)
+        self._x_dev = H.to_device(self.x_data)
+        self._L = H.empty(self._np, self._np)                     # state: factor of K+V at self.hyperparameters
+        self._alpha = H.empty(self._np, self.y_data.shape[1])     # state: KVinvY
+        self._work = self._work2 = self._alpha_work = None
+
+    @property
+    def hyperparameters(self):
+        return self._hps
+
+    # ------------------------------------------------------------------------------------------
+    # mean / noise on the host (O(N)), exactly the reference's rules
+    # ------------------------------------------------------------------------------------------
+    def _mean(self, x, hps):
+        """gp_prior.py:226-234,449-458: default = mean over ALL y entries, also at prediction points."""
+        if self._mean_callable is None:
+            m = np.zeros(len(x))
+            m[:] = np.mean(self.y_data)
+            return m
+        m = self._mean_callable(x, hps) if self._m_n_params == 2 else self._mean_callable(x, hps, self.args)
+        assert np.ndim(m) == 1, "mean function returned non-1-d result: " + str(m)
+        return np.asarray(m, dtype=np.float64)
+
+    def _noise(self, x, hps):
+        """gp_likelihood.py:89-110."""
+        if self._noise_callable is not None:
+            v = self._noise_callable(x, hps) if self._v_n_params == 2 else self._noise_callable(x, hps, self.args)
+            v = np.asarray(v, dtype=np.float64)
+            if np.ndim(v) != 1:
+                raise NotImplementedError("matrix-valued noise functions are not on the native path; return the 1-d diagonal")
+            return v
+        if self.noise_variances is not None:
+            if len(x) == len(self.noise_variances):
+                return self.noise_variances
+            return np.zeros(len(x)) + np.mean(self.noise_variances)
+        return np.ones(len(x)) * (np.mean(abs(self.y_data)) / 100.0) ** 2
+
+    def _host_kernel(self, x1, x2, hps):
+        k = self._kernel_callable(x1, x2, hps) if self._k_n_params == 3 else self._kernel_callable(x1, x2, hps, self.args)
+        return np.ascontiguousarray(k, dtype=np.float64)
+
+    # ------------------------------------------------------------------------------------------
+    # one full pass of the hot path into (KV buffer, alpha buffer); returns (loglik, logdet, m, V)
+    # ------------------------------------------------------------------------------------------
+    def _evaluate(self, hps, KV, alpha):
+        H, n = self._H, self.point_number
+        hps = np.asarray(hps, dtype=np.float64)
+        m = self._mean(self.x_data, hps)
+        V = self._noise(self.x_data, hps)
+        ymean = self.y_data - m[:, None]
+        ym_dev = H.to_device(ymean)
+        ncol = ymean.shape[1]
+        if self._native is not None and ncol <= _lib.MAX_RHS_VEC:
+            ll, logdet, quad, info = H.loglik(self._native.kernel_id, self._x_dev, hps, H.to_device(V), ym_dev, KV, alpha)
+        else:
+            if self._native is not None:
+                H.kmat(self._native.kernel_id, self._x_dev, self._x_dev, hps, KV, vdiag=H.to_device(V),
+                       uplo=_lib.LOWER, pad=_lib.PAD_IDENTITY)
+            else:
+                K = self._host_kernel(self.x_data, self.x_data, hps)     # slow path: N^2 over PCIe
+                KV[:n, :n] = H.to_device(K)
+                KV[:n, :n].diagonal().add_(H.to_device(V))
+            info = H.potrf(KV, n)
+            ll = logdet = float("nan")
+            if info == 0:
+                rhs = alpha if ncol <= _lib.MAX_RHS_VEC else H.zeros(self._np, _lib.pad128(ncol))
+                rhs[:n, :ncol] = ym_dev
+                H.potrs(KV, n, rhs, ncol if ncol <= _lib.MAX_RHS_VEC else _lib.pad128(ncol))
+                if rhs is not alpha:
+                    alpha[:n] = rhs[:n, :ncol]
+                logdet = H.logdet(KV, n)
+                quad = float((ym_dev * alpha[:n]).sum().item()) / ncol
+                ll = -0.5 * (quad + logdet + n * np.log(2.0 * np.pi))
+        if info != 0:
+            raise NonPositiveDefiniteError(_non_pd_message(n, info, float(np.min(V)) if self._native is not None else None, 0.0))
+        return ll, logdet, m, V
+
+    def _scratch(self):
+        if self._work is None:
+            self._work = self._H.empty(self._np, self._np)
+            self._alpha_work = self._H.empty(self._np, self.y_data.shape[1])
+        return self._work, self._alpha_work
+
+    # ------------------------------------------------------------------------------------------
+    # state
+    # ------------------------------------------------------------------------------------------
+    def set_hyperparameters(self, hps):
+        """fvgp/gp.py:672-687 -> prior, likelihood and KV state refresh (gp_kv.py:404-423)."""
+        assert isinstance(hps, np.ndarray), "wrong format in hyperparameters"
+        assert np.ndim(hps) == 1, "wrong format in hyperparameters"
+        self._hps = np.array(hps, dtype=np.float64)
+        ll, logdet, m, V = self._evaluate(self._hps, self._L, self._alpha)
+        self._loglik, self._logdet, self.m, self.V = ll, logdet, m, V
+        self._K_host = None
+
+    def get_hyperparameters(self):
+        return self._hps
+
+    def update_gp_data(self, x_new, y_new, noise_variances_new=None, append=True, rank_n_update=None):
+        """fvgp/gp.py:689-779.  The factor is rebuilt from scratch on the device (one potrf);
+        the reference's rank-n bordering update is a 'next' row."""
+        assert isinstance(x_new, np.ndarray) and isinstance(y_new, np.ndarray), "wrong format in new data"
+        if np.ndim(y_new) == 1:
+            y_new = y_new.reshape(len(y_new), 1)
+        if append:
+            x = np.vstack([self.x_data, x_new])
+            y = np.vstack([self.y_data, y_new])
+            if self.noise_variances is not None:
+                if noise_variances_new is None:
+                    raise Exception("Please provide noise_variances in the data update.")
+                nv = np.concatenate([self.noise_variances, noise_variances_new])
+            else:
+                nv = None
+        else:
+            x, y, nv = x_new, y_new, noise_variances_new
+        self._set_data(x, y, nv)
+        self.set_hyperparameters(self._hps)
+
+    @property
+    def K(self):
+        """Prior covariance at the current hyperparameters as a host array (fvgp/gp.py:625-627),
+        materialised on first access only."""
+        if self._K_host is None:
+            n = self.point_number
+            if self._native is not None:
+                buf = self._H.empty(n, n + (n & 1))
+                self._H.kmat(self._native.kernel_id, self._x_dev, self._x_dev, self._hps, buf)
+                self._H.sync()
+                self._K_host = buf[:, :n].cpu().numpy().copy()
+            else:
+                self._K_host = self._host_kernel(self.x_data, self.x_data, self._hps)
+        return self._K_host
+
+    @property
+    def KVinvY(self):
+        self._H.sync()
+        return self._alpha[:self.point_number].cpu().numpy()
+
+    @property
+    def Chol_factor(self):
+        """tril of the device factor (what np.tril(kv.Chol_factor) is in the reference)."""
+        self._H.sync()
+        n = self.point_number
+        return np.tril(self._L[:n, :n].cpu().numpy())
+
+    @property
+    def logdet_KV(self):
+        return self._logdet
+
+    # ------------------------------------------------------------------------------------------
+    # marginal likelihood
+    # ------------------------------------------------------------------------------------------
+    def log_likelihood(self, hyperparameters=None):
+        """fvgp/gp.py:1310-1330.  hyperparameters=None returns the cached value; otherwise a full
+        evaluation at the new theta that touches no state (gp_kv.py:574-578)."""
+        if hyperparameters is None:
+            return self._loglik
+        KV, aw = self._scratch()
+        try:
+            ll, _, _, _ = self._evaluate(hyperparameters, KV, aw)
+        except Exception as e:
+            raise Exception(f"Linear algebra failed for hyperparameters {hyperparameters}: {e}") from e
+        return ll
+
+    def neg_log_likelihood(self, hyperparameters=None):
+        return -self.log_likelihood(hyperparameters=hyperparameters)
+
+    def neg_log_likelihood_gradient(self, hyperparameters=None, component=0):
+        """fvgp/gp.py:1332-1353, gp_marginal_likelihood.py:224-309.
+        g_i = 1/2 (tr(KV^-1 dKV_i) - b^T dKV_i b) - dm_i^T b, kernel term dropped where the mean term
+        is non-zero (:301-308).  KV^-1 comes from POTRI on the device; dK/dtheta is re-evaluated inside
+        the trace kernel, never stored."""
+        H, n = self._H, self.point_number
+        if self._native is None and self._kernel_grad_callable is None:
+            raise NotImplementedError("gradient with a host kernel callable needs kernel_function_grad")
+        KV, aw = self._scratch()
+        if self._work2 is None:
+            self._work2 = H.empty(self._np, self._np)
+        hps = self._hps if hyperparameters is None else np.asarray(hyperparameters, dtype=np.float64)
+        self._evaluate(hps, KV, aw)
+        ncol = self.y_data.shape[1]
+        if self._native is not None:
+            g = H.loglik_grad(self._native.kernel_id, self._x_dev, hps, aw, ncol, component, KV, self._work2)
+            diag_inv = None
+        else:
+            H.potri(KV, n, self._work2)
+            H.symmetrize(KV, n)
+            H.sync()
+            Winv = KV[:n, :n]
+            b_dev = aw[:n, component]
+            dK = self._kernel_grad_callable(self.x_data, self.x_data, hps)
+            g = np.zeros(len(hps))
+            for i in range(len(hps)):
+                dKi = H.to_device(dK[i])
+                g[i] = 0.5 * float(((Winv * dKi).sum() - b_dev @ (dKi @ b_dev)).item())
+            diag_inv = None
+        g = np.asarray(g, dtype=np.float64)
+        if len(g) < len(hps):
+            g = np.concatenate([g, np.zeros(len(hps) - len(g))])
+        b = None
+        # noise-owned hyperparameters: d/dtheta_i of diag V enters exactly like dK (gp_marginal_likelihood.py:262-267)
+        if self._noise_callable is not None:
+            dV = self._noise_grad(hps)
+            if np.any(dV != 0.0):
+                H.sync()
+                b = aw[:n, component].cpu().numpy()
+                diag_inv = KV[:n, :n].diagonal().cpu().numpy() if diag_inv is None else diag_inv
+                g = g + 0.5 * (dV @ (diag_inv - b * b))
+        # mean-owned hyperparameters (:281,301-308)
+        if self._mean_callable is not None:
+            dm = self._mean_grad(hps)
+            if b is None:
+                H.sync()
+                b = aw[:n, component].cpu().numpy()
+            gm = -(dm @ b)
+            g = np.where(gm == 0.0, g, 0.0) + gm
+        return g
+
+    def _central_fd(self, f, hps):
+        """(H, N) central difference with step 1e-6 -- gp_likelihood.py:123-133, gp_prior.py:460-469."""
+        out = np.empty((len(hps), self.point_number))
+        for i in range(len(hps)):
+            tp, tm = np.array(hps, dtype=np.float64), np.array(hps, dtype=np.float64)
+            tp[i] += 1e-6
+            tm[i] -= 1e-6
+            out[i] = (f(self.x_data, tp) - f(self.x_data, tm)) / 2e-6
+        return out
+
+    def _noise_grad(self, hps):
+        if self._noise_grad_callable is not None:
+            return np.asarray(self._noise_grad_callable(self.x_data, hps), dtype=np.float64)
+        return self._central_fd(self._noise, hps)
+
+    def _mean_grad(self, hps):
+        if self._mean_grad_callable is not None:
+            return np.asarray(self._mean_grad_callable(self.x_data, hps), dtype=np.float64)
+        return self._central_fd(self._mean, hps)
+
+    # ------------------------------------------------------------------------------------------
+    # posterior
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def cartesian_product(x, y):
+        """Task-major product of points and task indices (gp_posterior.py:585-604), vectorised."""
+        assert isinstance(y, np.ndarray) and np.ndim(y) == 1, "x_out must be a 1-d np.ndarray for cartesian product"
+        x = np.asarray(x, dtype=np.float64)
+        return np.hstack([np.tile(x, (len(y), 1)), np.repeat(y.astype(np.float64), len(x))[:, None]])
+
+    def _perform_input_checks(self, x_pred, x_out):
+        assert isinstance(x_pred, np.ndarray), "wrong format in x_pred"
+        assert np.ndim(x_pred) == 2, "wrong dim in x_pred, has to be 2-d"
+        assert isinstance(x_out, np.ndarray) or x_out is None, "wrong format in x_out"
+        if isinstance(x_out, np.ndarray):
+            assert np.ndim(x_out) == 1, "wrong dim in x_out, has to be 1-d"
+
+    def _posterior_device(self, x_pred, hps, L, alpha, want_cov):
+        """k(x_data, x_pred) assembly, mean = k^T alpha, S = kk - k^T KV^-1 k on the device."""
+        H, n = self._H, self.point_number
+        P = len(x_pred)
+        Pp = _lib.pad128(P)
+        ncol = self.y_data.shape[1]
+        xp = H.to_device(x_pred)
+        mean = H.empty(P, ncol)
+        kx = H.empty(self._np, Pp)
+        if self._native is not None:
+            S = H.empty(Pp, Pp) if want_cov else None
+            H.posterior(self._native.kernel_id, self._x_dev, hps, L, alpha, ncol, xp, kx, mean, None, S)
+            H.sync()
+            return mean.cpu().numpy(), (None if S is None else S[:P, :P].cpu().numpy())
+        # slow path: host cross-covariances, device solves
+        k = self._host_kernel(self.x_data, x_pred, hps)
+        kdev = H.to_device(k)
+        mean_h = (kdev.T @ alpha[:n]).cpu().numpy()
+        if not want_cov:
+            return mean_h, None
+        kx.zero_()
+        kx[:n, :P] = kdev
+        H.trsm_lower(L, n, kx, Pp)
+        H.sync()
+        v = kx[:n, :P]
+        S = H.to_device(self._host_kernel(x_pred, x_pred, hps)) - v.T @ v
+        return mean_h, S.cpu().numpy()
+
+    def posterior_mean(self, x_pred, hyperparameters=None, x_out=None):
+        """fvgp/gp.py:1376-1431, gp_posterior.py:139-182."""
+        L, alpha, hps = self._L, self._alpha, self._hps
+        if hyperparameters is not None:
+            hps = np.asarray(hyperparameters, dtype=np.float64)
+            L, alpha = self._scratch()
+            self._evaluate(hps, L, alpha)
+        if x_out is None:
+            x_out = self.x_out
+        self._perform_input_checks(x_pred, x_out)
+        x_orig = x_pred.copy()
+        if isinstance(x_out, np.ndarray):
+            x_pred = self.cartesian_product(x_pred, x_out)
+        assert x_pred.shape[1] == self.input_set_dim, "wrong number of columns in x_pred"
+        A, _ = self._posterior_device(x_pred, hps, L, alpha, want_cov=False)
+        posterior_mean = self._mean(x_pred, hps)[:, None] + A
+        ncol = self.y_data.shape[1]
+        if isinstance(x_out, np.ndarray):
+            posterior_mean_re = posterior_mean.reshape(len(x_orig), len(x_out), order='F')
+        else:
+            posterior_mean_re = posterior_mean
+        if ncol == 1 and not isinstance(x_out, np.ndarray):
+            return {"x": x_orig, "m(x)": np.squeeze(posterior_mean_re), "m(x)_flat": np.squeeze(posterior_mean),
+                    "x_pred": x_pred}
+        if ncol == 1:
+            return {"x": x_orig, "m(x)": posterior_mean_re, "m(x)_flat": np.squeeze(posterior_mean), "x_pred": x_pred}
+        return {"x": x_orig, "m(x)": posterior_mean_re, "m(x)_flat": posterior_mean, "x_pred": x_pred}
+
+    def posterior_covariance(self, x_pred, x_out=None, variance_only=False, add_noise=False):
+        """fvgp/gp.py:1433-1480, gp_posterior.py:229-288 (Chol mode: S is always formed, :246)."""
+        if x_out is None:
+            x_out = self.x_out
+        self._perform_input_checks(x_pred, x_out)
+        x_orig = x_pred.copy()
+        if isinstance(x_out, np.ndarray):
+            x_pred = self.cartesian_product(x_pred, x_out)
+        assert x_pred.shape[1] == self.input_set_dim, "wrong number of columns in x_pred"
+        _, S = self._posterior_device(x_pred, self._hps, self._L, self._alpha, want_cov=True)
+        v = np.array(np.diag(S))
+        if np.any(v < -0.0001):
+            warnings.warn("Negative variances encountered. That normally means that the model is unstable. "
+                          "Rethink the kernel definition, add more noise to the data, "
+                          "or double check the hyperparameter optimization bounds. This will not "
+                          "terminate the algorithm, but expect anomalies.")
+        if np.any(v < 0.0):
+            v[v < 0.0] = 0.0
+            if not variance_only:
+                np.fill_diagonal(S, v)
+        if add_noise:
+            noise = self._noise(x_pred, self._hps)          # gp_posterior.py:554-569
+            v = v + noise
+            S = S + np.diag(noise)
+        if isinstance(x_out, np.ndarray):
+            v_re = v.reshape(len(x_orig), len(x_out), order='F')
+            S_re = S.reshape(len(x_orig), len(x_out), len(x_orig), len(x_out), order='F').transpose(0, 2, 1, 3)
+        else:
+            v_re, S_re = v, S
+            if self.y_data.shape[1] > 1:
+                v = np.tile(v[:, None], (1, self.y_data.shape[1]))
+                v_re = np.tile(v_re[:, None], (1, self.y_data.shape[1]))
+        return {"x": x_orig, "x_pred": x_pred, "v(x)": v_re, "S": S_re, "S_flat": S, "v_flat": v}
+
+    # ------------------------------------------------------------------------------------------
+    # training: the callers of the path -- device-resident objective, host optimiser
+    # ------------------------------------------------------------------------------------------
+    def train(self, hyperparameter_bounds=None, init_hyperparameters=None, method="mcmc", pop_size=20,
+              tolerance=0.0001, max_iter=10000, local_optimizer="L-BFGS-B", constraints=(), info=False,
+              dask_client=None, seed=None):
+        """fvgp/gp.py:781-1141 for the methods that run without Dask/HGDL: 'mcmc' (default),
+        'global' (differential evolution), 'local'.  Every objective call is one device evaluation;
+        x, y never leave HBM.  Returns the optimised hyperparameters and sets them (gp.py:1112)."""
+        from . import gp_training
+        if hyperparameter_bounds is None:
+            hyperparameter_bounds = self._default_bounds()
+        if init_hyperparameters is None:
+            init_hyperparameters = self._hps.copy()
+        hps = gp_training.train(self, np.asarray(hyperparameter_bounds, dtype=np.float64),
+                                np.asarray(init_hyperparameters, dtype=np.float64), method=method,
+                                pop_size=pop_size, tolerance=tolerance, max_iter=max_iter,
+                                local_optimizer=local_optimizer, constraints=constraints, info=info, seed=seed)
+        self.set_hyperparameters(np.asarray(hps, dtype=np.float64))
+        return self._hps
+
+    def _default_bounds(self):
+        """gp.py:752-774: signal variance from the data variance, length scales from the data ranges."""
+        if (self._native is None or self._native.isotropic or self._mean_callable is not None
+                or self._noise_callable is not None or len(self._hps) != self.index_set_dim + 1):
+            raise Exception("Please provide custom hyperparameter_bounds when kernel, mean or noise"
+                            " functions are customized")
+        b = np.zeros((self.index_set_dim + 1, 2))
+        b[0] = np.array([np.var(self.y_data) / 100., np.var(self.y_data) * 10.])
+        for i in range(self.index_set_dim):
+            range_xi = np.max(self.x_data[:, i]) - np.min(self.x_data[:, i])
+            b[i + 1] = np.array([range_xi / 100., range_xi * 10.])
+        return b
+
+    # ------------------------------------------------------------------------------------------
+    # pickling (fvgp/gp.py:2253-2266, gp_kv.py:718-765): host copies of the state, factor included
+    # ------------------------------------------------------------------------------------------
+    def __getstate__(self):
+        self._H.sync()
+        st = {k: v for k, v in self.__dict__.items()
+              if k not in ("_H", "_x_dev", "_L", "_alpha", "_work", "_work2", "_alpha_work")}
+        n = self.point_number
+        st["_L_host"] = np.tril(self._L[:n, :n].cpu().numpy())
+        st["_alpha_host"] = self._alpha[:n].cpu().numpy()
+        return st
+
+    def __setstate__(self, st):
+        L_host, a_host = st.pop("_L_host"), st.pop("_alpha_host")
+        self.__dict__.update(st)
+        self._H = default_handle()
+        H, n = self._H, self.point_number
+        self._x_dev = H.to_device(self.x_data)
+        self._L = H.zeros(self._np, self._np)
+        self._L[:n, :n] = H.to_device(L_host)
+        if self._np > n:
+            self._L[n:, n:] = H.to_device(np.eye(self._np - n))
+        self._alpha = H.zeros(self._np, self.y_data.shape[1])
+        self._alpha[:n] = H.to_device(a_host)
+        self._work = self._work2 = self._alpha_work = None

@@ -1,0 +1,95 @@
+"""Training drivers -- the callers of the hot path.  Host-side optimisers around a
+device-resident objective: every objective call is one fused evaluation in HBM, theta in and a
+scalar (or (H,) gradient) out.  Mirrors the Dask-free methods of GPtraining.train
+(fvgp/gp_training.py:28-196): 'mcmc' (the default, gp_mcmc.py:96-224), 'global', 'local'.
+"""
+import warnings
+
+import numpy as np
+
+
+def _in_bounds(theta, bounds):
+    return bool(np.all((theta >= bounds[:, 0]) & (theta <= bounds[:, 1])))
+
+
+def run_mcmc(log_likelihood, bounds, x0, n_updates=10000, info=False, rng=None, break_default=True):
+    """Adaptive Metropolis-Hastings with one normal proposal over all hyperparameters.
+
+    Follows gpMCMC.run_mcmc/_jump (gp_mcmc.py:96-224) and ProposalDistribution._adapt (:337-356):
+    uniform prior on the bounds box, initial proposal covariance diag((0.2*range/sqrt(12))^2)
+    (:84-87), covariance adapted every K=10 steps with gamma2 = 1/(i/K+3)^0.8, and the
+    'default' break condition (|mean of last 100 f - mean of previous 100| < 1e-3 after 1000
+    iterations, :181-190).  One likelihood evaluation per proposal.  Returns the reference's
+    info dict; GP.train takes "median(x)" = median of the last 1 % of the trace.
+    """
+    rng = np.random.default_rng() if rng is None else rng
+    n_updates = max(int(n_updates), 2)
+    dim = len(bounds)
+    std = (bounds[:, 1] - bounds[:, 0]) * 0.2 / np.sqrt(12)
+    prop_Sigma = np.diag(std ** 2)
+    K, c_1 = 10, 0.8
+    x = np.array(x0, dtype=np.float64)
+    f = log_likelihood(x)
+    trace_x, trace_f, jumps = [x.copy()], [], []
+    for i in range(1, n_updates):
+        x_star = rng.multivariate_normal(mean=x, cov=prop_Sigma)
+        jumped = 0.0
+        if _in_bounds(x_star, bounds):
+            f_star = log_likelihood(x_star)
+            if np.isnan(f_star):
+                raise Exception("Likelihood evaluation = NaN in gpMCMC")
+            expo = f_star - f
+            ratio = np.exp(expo) if expo < 50 else 1.1
+            if ratio > rng.uniform(0.0, 1.0):
+                x, f, jumped = x_star, f_star, 1.0
+        jumps.append(jumped)
+        if i % K == 0:
+            start = i - K + 1
+            gamma2 = 1.0 / ((i / K) + 3) ** c_1
+            seg = np.asarray(trace_x).T[:, start:i]
+            if seg.shape[1] > 1:
+                prop_Sigma = prop_Sigma + gamma2 * (np.atleast_2d(np.cov(seg)) - prop_Sigma)
+        trace_x.append(x.copy())
+        trace_f.append(f)
+        if info and i % 10 == 0:
+            print("Finished ", i, " out of ", n_updates, " iterations. f(x)= ", f)
+        if break_default and len(trace_f) >= 1000:
+            fl = np.asarray(trace_f)
+            if abs(fl[-100:].mean() - fl[-200:-100].mean()) < 1e-3:
+                break
+    xs = np.asarray(trace_x)
+    dist_index = int(len(xs) - (len(xs) / 100))
+    arg_max = int(np.argmax(trace_f))
+    return {"f(x)": trace_f, "max f(x)": trace_f[arg_max], "MAP": trace_f[arg_max], "max x": xs[arg_max], "x": xs,
+            "mean(x)": np.mean(xs[dist_index:], axis=0), "median(x)": np.median(xs[dist_index:], axis=0),
+            "var(x)": np.var(xs[dist_index:], axis=0), "acceptance": float(np.mean(jumps)) if jumps else 0.0}
+
+
+def train(gp, bounds, init_hyperparameters, method="mcmc", pop_size=20, tolerance=1e-4, max_iter=10000,
+          local_optimizer="L-BFGS-B", constraints=(), info=False, seed=None):
+    """Dispatch on `method` (fvgp/gp_training.py:58-162).  Bounds / init checks: gp.py:1019-1036."""
+    assert isinstance(bounds, np.ndarray) and bounds.ndim == 2 and bounds.shape[1] == 2, "wrong bounds format"
+    if len(bounds) != len(init_hyperparameters):
+        raise Exception("init_hyperparameters and hyperparameter_bounds have different lengths")
+    if not _in_bounds(init_hyperparameters, bounds):
+        raise Exception("Starting hyperparameters out of bounds")
+    if method == "mcmc":
+        res = run_mcmc(gp.log_likelihood, bounds, init_hyperparameters, n_updates=max_iter, info=info,
+                       rng=np.random.default_rng(seed))
+        gp.mcmc_info = res
+        return res["median(x)"]
+    if method == "global":
+        from scipy.optimize import differential_evolution
+        res = differential_evolution(gp.neg_log_likelihood, bounds, maxiter=max_iter, popsize=pop_size, tol=tolerance,
+                                     disp=info, polish=False, x0=init_hyperparameters.reshape(1, -1),
+                                     constraints=constraints, workers=1, seed=seed)
+        return np.array(res["x"])
+    if method == "local":
+        from scipy.optimize import minimize
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = minimize(gp.neg_log_likelihood, init_hyperparameters, method=local_optimizer,
+                           jac=gp.neg_log_likelihood_gradient, bounds=bounds, tol=tolerance,
+                           constraints=constraints, options={"maxiter": max_iter})
+        return res["x"]
+    raise NotImplementedError(f"train(method={method!r}): only 'mcmc', 'global' and 'local' run without Dask/HGDL")

@@ -135,6 +135,10 @@ int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t
                   double beta, double *C, int64_t ldc);
 /* one 64-lane wave: D = A(16x4) * B(4x16) with the lane maps the kernels assume */
 int fvgp_hip_mfma_selftest(fvgp_handle *h, const double *A16x4, const double *B4x16, double *D16x16);
+/* host-only replay of the GEMM kernel's blockIdx -> (tile row, tile col) map, XCD remap included
+ * (no GPU needed); returns the grid size, fills min(grid, cap) entries; out-of-range tiles are
+ * the ones the kernel exits on. */
+int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int *out_ti, int *out_tj, int64_t cap);
 /* diagnostic: blocks x 256 threads each issue iters x 16 register-only fp64 MFMAs (2048 flop each per wave);
  * out needs blocks*256 doubles.  Gives the sustained fp64 MFMA ceiling of the device. */
 int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);

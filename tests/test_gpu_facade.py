@@ -1,0 +1,209 @@
+"""fvgp_amd.GP / fvGP against the reference's own outputs (tests/golden) -- reads like the reference's
+tests: build a GP, call the public methods, compare.  Tolerances: SURVEY 8c / BASELINE.md section 5."""
+import pickle
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import fvgp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("G1_rbf_n500_d1.npz", {}), ("G2_rbf_n512_d3.npz", {}), ("G3_matern52_n512_d3.npz", {}),
+         ("G4_default_n256_d2.npz", {"default": True}), ("G6_rbf_2col_n300_d3.npz", {})]
+
+
+def _make(fx, opt):
+    import fvgp_amd
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if opt.get("default"):
+            return fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"])
+        return fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], noise_variances=fx["noise_variances"],
+                           kernel_function=str(fx["kernel"]))
+
+
+@pytest.mark.parametrize("name,opt", CASES)
+def test_gp_matches_reference(name, opt):
+    fx = load_golden(name)
+    gp = _make(fx, opt)
+    sig = fx["theta"][0]
+    # state
+    assert np.max(np.abs(gp.K[:8, :8] - fx["K_corner"])) <= 8e-16 * sig
+    np.testing.assert_allclose(gp.V, fx["V"], rtol=1e-15)
+    np.testing.assert_allclose(gp.m, fx["m"], rtol=1e-15)
+    np.testing.assert_allclose(np.diag(gp.Chol_factor), fx["L_diag"], rtol=1e-10)
+    assert np.max(np.abs(gp.KVinvY - fx["KVinvY"])) <= 1e-8 * np.max(np.abs(fx["KVinvY"]))
+    # likelihood: cached, explicit theta, sweep
+    np.testing.assert_allclose(gp.log_likelihood(), fx["loglik"], rtol=1e-10)
+    np.testing.assert_allclose(gp.log_likelihood(fx["theta"]), fx["loglik_theta"], rtol=1e-10)
+    np.testing.assert_allclose(gp.neg_log_likelihood(fx["thetas"][0]), -fx["logliks"][0], rtol=1e-10)
+    for t, ll in zip(fx["thetas"], fx["logliks"]):
+        np.testing.assert_allclose(gp.log_likelihood(t), ll, rtol=1e-10)
+    # an evaluation at another theta must not have touched the state (gp_kv.py:574-578)
+    np.testing.assert_allclose(gp.log_likelihood(), fx["loglik"], rtol=1e-10)
+    # gradient
+    np.testing.assert_allclose(gp.neg_log_likelihood_gradient(fx["theta"]), fx["grad"], rtol=1e-8,
+                               atol=1e-9 * np.max(np.abs(fx["grad"])))
+    np.testing.assert_allclose(gp.neg_log_likelihood_gradient(), fx["grad_cached"], rtol=1e-8,
+                               atol=1e-9 * np.max(np.abs(fx["grad"])))
+    if "grad_c1" in fx:
+        np.testing.assert_allclose(gp.neg_log_likelihood_gradient(fx["theta"], component=1), fx["grad_c1"], rtol=1e-8,
+                                   atol=1e-9 * np.max(np.abs(fx["grad_c1"])))
+    # posterior
+    xp = fx["x_pred"]
+    pm = gp.posterior_mean(xp)
+    assert set(pm) == {"x", "m(x)", "m(x)_flat", "x_pred"}
+    assert pm["m(x)"].shape == fx["pm"].shape and pm["m(x)_flat"].shape == fx["pm_flat"].shape
+    np.testing.assert_allclose(pm["m(x)"], fx["pm"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(gp.posterior_mean(xp, hyperparameters=fx["thetas"][0])["m(x)"], fx["pm_theta1"],
+                               rtol=1e-8, atol=1e-10)
+    pc = gp.posterior_covariance(xp)
+    pcn = gp.posterior_covariance(xp, add_noise=True)
+    assert set(pc) == {"x", "x_pred", "v(x)", "S", "S_flat", "v_flat"}
+    for key, tag in (("v(x)", "pv"), ("S", "pS"), ("S_flat", "pS_flat"), ("v_flat", "pv_flat")):
+        assert np.asarray(pc[key]).shape == fx[tag].shape
+        assert np.max(np.abs(pc[key] - fx[tag])) <= 1e-10 * sig + 1e-12
+        assert np.max(np.abs(pcn[key] - fx[tag + "_noise"])) <= 1e-10 * sig + 1e-12
+    pv = gp.posterior_covariance(xp, variance_only=True)
+    assert np.max(np.abs(pv["v(x)"] - fx["pv"])) <= 1e-10 * sig + 1e-12
+
+
+@pytest.mark.parametrize("name", ["G5_fvgp_4x64.npz", "G5n_fvgp_4x64_nan.npz"])
+def test_fvgp_multitask_matches_reference(name):
+    """MultiTaskTest shape: (V,Di) x (V,No) -> task-major index set; posterior reshapes of
+    gp_posterior.py:264-274 (pinned by tests/test_fvgp.py:1973-2012)."""
+    import fvgp_amd
+    fx = load_golden(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = fvgp_amd.fvGP(fx["fvgp_x"], fx["fvgp_y"], init_hyperparameters=fx["theta"], noise_variances=fx["fvgp_noise"])
+    assert np.array_equal(gp.x_data, fx["x"])
+    np.testing.assert_allclose(gp.log_likelihood(), fx["loglik"], rtol=1e-10)
+    for t, ll in zip(fx["thetas"], fx["logliks"]):
+        np.testing.assert_allclose(gp.log_likelihood(t), ll, rtol=1e-10)
+    np.testing.assert_allclose(gp.neg_log_likelihood_gradient(fx["theta"]), fx["grad"], rtol=1e-8,
+                               atol=1e-9 * np.max(np.abs(fx["grad"])))
+    xp = fx["x_pred"]
+    for kw in ({}, {"x_out": fx["x_out"]}):
+        pm = gp.posterior_mean(xp, **kw)
+        assert pm["m(x)"].shape == (len(xp), 4)
+        np.testing.assert_allclose(pm["m(x)"], fx["pm"], rtol=1e-8, atol=1e-10)
+        assert np.array_equal(pm["x_pred"], fx["pm_xpred"])
+        pc = gp.posterior_covariance(xp, **kw)
+        assert pc["S"].shape == (len(xp), len(xp), 4, 4) and pc["v(x)"].shape == (len(xp), 4)
+        assert np.max(np.abs(pc["S"] - fx["pS"])) <= 1e-10 and np.max(np.abs(pc["v(x)"] - fx["pv"])) <= 1e-10
+
+
+def test_nonpd_is_reported_like_the_reference():
+    """tests/test_fvgp.py:4653-4665,3738-3768: NonPositiveDefiniteError(LinAlgError) with diagnostics, and
+    log_likelihood(theta) re-raises as 'Linear algebra failed for hyperparameters ...'."""
+    import fvgp_amd
+    from fvgp_amd import gp_lin_alg
+    fx = load_golden("G7_nonpd.npz")
+    with pytest.raises(fvgp_amd.NonPositiveDefiniteError) as ei:
+        gp_lin_alg.calculate_Chol_factor(fx["M"])
+    assert isinstance(ei.value, np.linalg.LinAlgError)
+    assert f"the 96x96 prior covariance matrix is not positive definite" in str(ei.value)
+    assert f"{int(fx['info'])}-th leading minor" in str(ei.value)
+    f = gp_lin_alg.calculate_Chol_factor(fx["Mok"])
+    np.testing.assert_allclose(f.lower(), fx["Lok"], rtol=0, atol=1e-13 * np.max(fx["Lok"]))
+    np.testing.assert_allclose(gp_lin_alg.calculate_Chol_solve(f, fx["rhs"]), fx["sol"], rtol=1e-11, atol=1e-14)
+    assert gp_lin_alg.calculate_Chol_solve(f, fx["rhs"][:, 0]).shape == (96, 1)
+    np.testing.assert_allclose(gp_lin_alg.calculate_Chol_logdet(f), float(fx["logdet"]), rtol=1e-13)
+    # duplicate points + negligible noise: a numerically singular K inside GP.log_likelihood(theta)
+    rng = np.random.default_rng(0)
+    x = rng.random((200, 2)); x[150:] = x[:50]
+    y = np.sin(x.sum(axis=1))
+    gp = fvgp_amd.GP(x, y, init_hyperparameters=np.array([1.0, 5.0, 5.0]), noise_variances=np.full(200, 1e-2),
+                     kernel_function="rbf_ard")
+
+    def tiny_noise(xx, h):
+        return np.full(len(xx), 1e-300)
+    gp2 = fvgp_amd.GP(x, y, init_hyperparameters=np.array([1.0, 0.3, 0.3]), noise_function=lambda xx, h: np.full(len(xx), 1e-2),
+                      kernel_function="rbf_ard")
+    gp2._noise_callable = tiny_noise
+    with pytest.raises(Exception, match="Linear algebra failed for hyperparameters"):
+        gp2.log_likelihood(np.array([1.0, 50.0, 50.0]))
+    assert np.isfinite(gp.log_likelihood())
+
+
+def test_host_callable_kernel_slow_path_and_custom_mean_noise():
+    """An arbitrary Python kernel / mean / noise callable keeps working (gp.py:80-101): K comes from the
+    host, everything after addKV runs on the device."""
+    import fvgp_amd
+    fx = load_golden("G2_rbf_n512_d3.npz")
+    x, y, th = fx["x"], fx["y"], fx["theta"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=fx["noise_variances"],
+                         kernel_function=orc.rbf_ard, kernel_function_grad=orc.rbf_ard_grad)
+    np.testing.assert_allclose(gp.log_likelihood(), fx["loglik"], rtol=1e-10)
+    np.testing.assert_allclose(gp.log_likelihood(fx["thetas"][1]), fx["logliks"][1], rtol=1e-10)
+    np.testing.assert_allclose(gp.neg_log_likelihood_gradient(th), fx["grad"], rtol=1e-8, atol=1e-9 * np.max(np.abs(fx["grad"])))
+    np.testing.assert_allclose(gp.posterior_mean(fx["x_pred"])["m(x)"], fx["pm"], rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(gp.posterior_covariance(fx["x_pred"])["S"] - fx["pS"])) <= 1e-10
+    # hyperparameter-dependent mean and noise: theta = [sig, l1, l2, l3, mean level, noise level]
+    mean = lambda xx, h: np.full(len(xx), h[4])
+    noise = lambda xx, h: np.full(len(xx), h[5])
+    th6 = np.concatenate([th, [0.1, 0.02]])
+    gp = fvgp_amd.GP(x, y, init_hyperparameters=th6, kernel_function="rbf_ard", prior_mean_function=mean, noise_function=noise)
+    K = orc.rbf_ard(x, x, th6[:4]); KV = orc.addKV(K, noise(x, th6))
+    Lr = orc.calculate_Chol_factor(KV); ym = (y - mean(x, th6)).reshape(-1, 1)
+    ref = -0.5 * (np.sum(ym * orc.calculate_Chol_solve(Lr, ym)) + orc.calculate_Chol_logdet(Lr) + len(y) * np.log(2 * np.pi))
+    np.testing.assert_allclose(gp.log_likelihood(), ref, rtol=1e-10)
+    g = gp.neg_log_likelihood_gradient(th6)
+    fd = np.zeros(6)
+    for i in range(6):
+        e = np.zeros(6); e[i] = 1e-6 * max(1.0, abs(th6[i]))
+        fd[i] = -(gp.log_likelihood(th6 + e) - gp.log_likelihood(th6 - e)) / (2 * e[i])
+    np.testing.assert_allclose(g, fd, rtol=2e-5, atol=1e-4)
+
+
+def test_pickle_roundtrip_and_update():
+    """tests/test_fvgp.py:1108-1244: an unpickled GP answers posterior queries from the pickled factor."""
+    import fvgp_amd
+    fx = load_golden("G3_matern52_n512_d3.npz")
+    gp = fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], noise_variances=fx["noise_variances"],
+                     kernel_function="matern52_ard")
+    gp2 = pickle.loads(pickle.dumps(gp))
+    np.testing.assert_allclose(gp2.posterior_mean(fx["x_pred"])["m(x)"], fx["pm"], rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(gp2.posterior_covariance(fx["x_pred"])["S"] - fx["pS"])) <= 1e-10
+    np.testing.assert_allclose(gp2.log_likelihood(), fx["loglik"], rtol=1e-10)
+    # append == rebuild on the union
+    x, y, nv = fx["x"], fx["y"], fx["noise_variances"]
+    a = fvgp_amd.GP(x[:400], y[:400], init_hyperparameters=fx["theta"], noise_variances=nv[:400], kernel_function="matern52_ard")
+    a.update_gp_data(x[400:], y[400:], noise_variances_new=nv[400:], append=True)
+    np.testing.assert_allclose(a.log_likelihood(), fx["loglik"], rtol=1e-10)
+    a.set_hyperparameters(fx["thetas"][2])
+    np.testing.assert_allclose(a.log_likelihood(), fx["logliks"][2], rtol=1e-10)
+
+
+def test_train_methods_improve_the_likelihood():
+    """GP.train (gp.py:781) with the Dask-free methods; every objective call is a device evaluation."""
+    import fvgp_amd
+    fx = load_golden("G2_rbf_n512_d3.npz")
+    gp = fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=np.array([0.5, 0.8, 0.8, 0.8]),
+                     noise_variances=fx["noise_variances"], kernel_function="rbf_ard")
+    start = gp.log_likelihood()
+    bounds = np.array([[0.05, 5.0]] + [[0.05, 2.0]] * 3)
+    hps = gp.train(hyperparameter_bounds=bounds, method="local", max_iter=40)
+    assert gp.log_likelihood() > start + 1.0 and np.allclose(hps, gp.hyperparameters)
+    gp.set_hyperparameters(np.array([0.5, 0.8, 0.8, 0.8]))
+    gp.train(hyperparameter_bounds=bounds, method="mcmc", max_iter=150, seed=1)
+    assert gp.log_likelihood() > start
+    assert "median(x)" in gp.mcmc_info
+    gp.set_hyperparameters(np.array([0.5, 0.8, 0.8, 0.8]))
+    gp.train(hyperparameter_bounds=bounds, method="global", max_iter=2, pop_size=4, seed=1)
+    assert gp.log_likelihood() > start
+
+
+def test_named_kernel_is_a_reference_style_callable():
+    from fvgp_amd import kernels
+    fx = load_golden("G8_iso_and_units.npz")
+    for nm in ("rbf_iso", "matern32_iso", "matern52_iso"):
+        K = kernels.NATIVE[nm](fx["x"], fx["x"], fx["theta"])
+        assert np.max(np.abs(K[:8, :8] - fx[nm + "_K_corner"])) <= 8e-16 * fx["theta"][0]
+        np.testing.assert_allclose(np.linalg.norm(K), float(fx[nm + "_K_fro"]), rtol=1e-13)

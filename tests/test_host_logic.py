@@ -1,0 +1,116 @@
+"""CPU-only checks: the C-ABI library builds, loads and exports every symbol the header declares;
+host-side logic (tile map, index-set transform, MCMC driver, argument rules) -- no GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import fvgp_oracle as orc
+
+
+@pytest.fixture(scope="module")
+def L():
+    from fvgp_amd import _lib
+    _lib.build()
+    return _lib.lib()
+
+
+def test_header_symbols_are_exported(L):
+    from fvgp_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "fvgp_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(fvgp_hip_\w+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    assert sorted(_lib.SYMBOLS) == declared
+    for s in declared:
+        assert hasattr(L, s), f"libfvgp_hip.so does not export {s}"
+    assert L.fvgp_hip_version() >= 100
+    assert L.fvgp_hip_padded_dim(1) == 128 and L.fvgp_hip_padded_dim(128) == 128 and L.fvgp_hip_padded_dim(50000) == 50048
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    from fvgp_amd import _lib
+    with pytest.raises(_lib.HipExtensionError):
+        _lib.Handle(0)
+    import fvgp_amd
+    x = np.random.default_rng(0).random((20, 2)); y = np.sin(x[:, 0])
+    with pytest.raises(_lib.HipExtensionError):
+        fvgp_amd.GP(x, y, init_hyperparameters=np.ones(3), noise_variances=np.full(20, 0.01))
+
+
+def test_cpu_device_is_refused():
+    """tests/test_fvgp.py:4682-4702 analogue: an unknown/unsupported compute device is an exception, never
+    a silent fallback."""
+    import fvgp_amd
+    x = np.random.default_rng(0).random((20, 2)); y = np.sin(x[:, 0])
+    with pytest.raises(Exception, match="No valid compute device"):
+        fvgp_amd.GP(x, y, init_hyperparameters=np.ones(3), noise_variances=np.full(20, 0.01), compute_device="cpu")
+    with pytest.raises(NotImplementedError):
+        fvgp_amd.GP(x, y, init_hyperparameters=np.ones(3), noise_variances=np.full(20, 0.01), gp2Scale=True)
+    with pytest.raises(Exception, match="Decide which one"):
+        fvgp_amd.GP(x, y, init_hyperparameters=np.ones(3), noise_variances=np.full(20, 0.01),
+                    noise_function=lambda x, h: np.ones(len(x)))
+
+
+@pytest.mark.parametrize("tm,tn,lower", [(1, 1, 0), (3, 1, 0), (391, 1, 0), (5, 3, 1), (12, 3, 1), (8, 8, 1), (9, 9, 1),
+                                         (23, 23, 1), (40, 16, 1), (17, 5, 0), (16, 24, 0), (391, 391, 1), (100, 7, 1)])
+def test_gemm_tile_map_covers_each_tile_once(L, tm, tn, lower):
+    """The blockIdx -> tile map (8xSN super-tiles + XCD remap) must hit every wanted tile exactly once."""
+    cap = 400000
+    ti = (ctypes.c_int * cap)(); tj = (ctypes.c_int * cap)()
+    nwg = L.fvgp_hip_debug_tile_map(tm, tn, lower, ti, tj, cap)
+    assert 0 < nwg <= cap
+    got = {}
+    for b in range(nwg):
+        i, j = ti[b], tj[b]
+        if i >= tm or j >= tn or (lower and j > i):
+            continue
+        assert (i, j) not in got, f"tile {(i, j)} mapped twice"
+        got[(i, j)] = b
+    want = {(i, j) for i in range(tm) for j in range(tn) if not lower or j <= i}
+    assert set(got) == want
+    # blocks b and b+8 share an XCD: their tiles should be neighbours in the enumeration
+    if nwg >= 64 and tn >= 8:
+        i0, j0, i1, j1 = ti[0], tj[0], ti[8], tj[8]
+        assert abs(i0 - i1) <= 8 and abs(j0 - j1) <= 8
+
+
+def test_index_set_transform_and_cartesian_product():
+    from fvgp_amd.fvgp import transform_index_set
+    from fvgp_amd.gp import GP
+    for name in ("G5_fvgp_4x64.npz", "G5n_fvgp_4x64_nan.npz"):
+        fx = load_golden(name)
+        x, y, v = transform_index_set(fx["fvgp_x"], fx["fvgp_y"], fx["fvgp_noise"], 4)
+        assert np.array_equal(x, fx["x"]) and np.array_equal(y, fx["y"]) and np.array_equal(v, fx["noise_variances"])
+        assert np.array_equal(GP.cartesian_product(fx["x_pred"], fx["x_out"]), fx["pm_xpred"])
+        assert np.array_equal(GP.cartesian_product(fx["x_pred"], fx["x_out"]), orc.cartesian_product(fx["x_pred"], fx["x_out"]))
+
+
+def test_mcmc_driver_on_a_toy_posterior():
+    """run_mcmc (gp_mcmc.py:96-224 restated) finds the mode of a Gaussian log-density in a box."""
+    from fvgp_amd import gp_training
+    mu = np.array([1.0, 2.0])
+    f = lambda t: -0.5 * np.sum(((t - mu) / 0.1) ** 2)
+    bounds = np.array([[0.0, 4.0], [0.0, 4.0]])
+    res = gp_training.run_mcmc(f, bounds, np.array([3.0, 0.5]), n_updates=3000, rng=np.random.default_rng(3))
+    assert np.all(np.abs(res["median(x)"] - mu) < 0.1)
+    assert res["max f(x)"] > -0.5
+    assert np.all(res["x"] >= bounds[:, 0]) and np.all(res["x"] <= bounds[:, 1])
+    with pytest.raises(Exception, match="out of bounds"):
+        gp_training.train(None, bounds, np.array([5.0, 1.0]))
+
+
+def test_named_kernel_resolution():
+    from fvgp_amd import kernels
+    assert kernels.resolve(None) is kernels.matern32_ard          # gp_prior.py:62-63 default
+    assert kernels.resolve("rbf_ard") is kernels.rbf_ard
+    assert kernels.resolve(kernels.matern52_iso).kernel_id == 5
+    assert kernels.resolve(lambda a, b, h: None) is None
+    with pytest.raises(ValueError):
+        kernels.resolve("nope")
+    assert kernels.rbf_ard.n_hyperparameters(3) == 4 and kernels.rbf_iso.n_hyperparameters(3) == 2
