@@ -428,7 +428,7 @@ class GP:
         x_orig = x_pred.copy()
         if isinstance(x_out, np.ndarray):
             x_pred = self.cartesian_product(x_pred, x_out)
-        assert x_pred.shape[1] == self.input_set_dim, "wrong number of columns in x_pred"
+        assert x_pred.shape[1] == self.index_set_dim, "wrong number of columns in x_pred"
         A, _ = self._posterior_device(x_pred, hps, L, alpha, want_cov=False)
         posterior_mean = self._mean(x_pred, hps)[:, None] + A
         ncol = self.y_data.shape[1]
@@ -451,7 +451,7 @@ class GP:
         x_orig = x_pred.copy()
         if isinstance(x_out, np.ndarray):
             x_pred = self.cartesian_product(x_pred, x_out)
-        assert x_pred.shape[1] == self.input_set_dim, "wrong number of columns in x_pred"
+        assert x_pred.shape[1] == self.index_set_dim, "wrong number of columns in x_pred"
         _, S = self._posterior_device(x_pred, self._hps, self._L, self._alpha, want_cov=True)
         v = np.array(np.diag(S))
         if np.any(v < -0.0001):
