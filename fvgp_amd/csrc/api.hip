@@ -65,6 +65,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
         return 0;
     }
     if (!strcmp(key, "profile")) { h->profile = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "gemm_variant")) { h->gemm_variant = (int)value; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
     return -2;
 }

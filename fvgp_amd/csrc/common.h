@@ -31,8 +31,9 @@ struct fvgp_handle {
     double *vec = nullptr;
     size_t vec_cap = 0;
     // options
-    int64_t outer_block = 512;
+    int64_t outer_block = 1024;
     int profile = 0;
+    int gemm_variant = 0;
     // profile of the last potrf
     std::vector<hipEvent_t> ev;
     std::vector<double> ev_flops;

@@ -64,20 +64,31 @@ __host__ __device__ inline void tile_of(long t, int tiles_m, int tiles_n, int lo
     ti = si * S + in / SN; tj = sj * SN + in % SN;
 }
 
-template <int AKM, int BNM>
+__host__ __device__ inline long xcd_remap(long b, long nwg, int tiles_n) {
+    const long per = 8L * (tiles_n < 8 ? tiles_n : 8);      // tiles per super-tile
+    const long nst = nwg / per;                             // grid is a whole number of super-tiles
+    const long xcd = b % 8, idx = b / 8;                    // idx-th block of this XCD
+    const long full = nst / 8 * 8;                          // super-tiles dealt round-robin
+    const long st = (idx / per) * 8 + xcd;
+    if (st < full) return st * per + idx % per;
+    // leftover super-tiles (< 8): spread their tiles over all XCDs in plain order
+    const long rem_blocks = nwg - full * per;
+    const long k = b - (nwg - rem_blocks);                  // only reached by the last rem_blocks blocks
+    return full * per + (k >= 0 ? k : 0);
+}
+
+template <int AKM, int BNM, int PIPE, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     __shared__ double smem[2][2][IMG];
 
-    // XCD-aware remap: hardware deals block b to XCD b%8; give each XCD a contiguous run of tiles
-    const long nwg = gridDim.x;
-    const long b = blockIdx.x;
-    const long q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
-    const long t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    // XCD-aware remap: hardware deals block b to XCD b%8.  Blocks b, b+8, b+16, .. (one XCD) walk whole
+    // super-tiles: the 8*SN tiles of a super-tile run together on one L2, and super-tiles are dealt
+    // round-robin over the XCDs so every XCD gets the same mix of full and diagonal (half-empty) ones.
+    const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
     int ti, tj;
     tile_of(t, g.tiles_m, g.tiles_n, g.lower, ti, tj);
     if (ti >= g.tiles_m || tj >= g.tiles_n) return;
     if (g.lower && tj > ti) return;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -150,6 +161,54 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     __syncthreads();
 
+    if (!PIPE) {
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more && !(ABL & 1)) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                ga[p] += astep; gb[p] += bstep;
+                ra[p] = *reinterpret_cast<const double2_t *>(ga[p]);
+                rb[p] = *reinterpret_cast<const double2_t *>(gb[p]);
+            }
+        }
+        const double *pa = &smem[cur][0][0];
+        const double *pb = &smem[cur][1][0];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            double a[4], bv[4];
+            if (ABL & 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a[i] = ra[i][0] + s; bv[i] = rb[i][1] + s; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a[i] = pa[fa[i] + s * SA]; bv[i] = pb[fb[i] + s * SB]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more && !(ABL & 2)) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][0][sa[p]]) = ra[p];
+                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][1][sb[p]]) = rb[p];
+            }
+        }
+        if (!(ABL & 4)) __syncthreads();
+    }
+    } else {
+    // software-pipelined K loop: the fragments of sub-step s+1 are read from LDS while the 16 MFMAs of
+    // sub-step s run; the register->LDS stores of the next K-step ride in the shadow of the last
+    // sub-step's MFMAs, so the only exposed latency per K-step is barrier + one fragment read.
+    double ca[4], cb[4];
+    if (nk > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ca[i] = smem[0][0][fa[i]]; cb[i] = smem[0][1][fb[i]]; }
+    }
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
@@ -164,45 +223,74 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const double *pa = &smem[cur][0][0];
         const double *pb = &smem[cur][1][0];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            double a[4], bv[4];
+        for (int s = 0; s < 3; ++s) {
+            double na[4], nb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = pa[fa[i] + s * SA]; bv[i] = pb[fb[i] + s * SB]; }
+            for (int i = 0; i < 4; ++i) { na[i] = pa[fa[i] + (s + 1) * SA]; nb[i] = pb[fb[i] + (s + 1) * SB]; }
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMAs it hides under
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i], cb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][0][sa[p]]) = ra[p];
-                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][1][sb[p]]) = rb[p];
+            for (int i = 0; i < 4; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
+        }
+        // last sub-step: MFMAs with the LDS stores of the next K-step interleaved (2 MFMAs : 1 store)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i], cb[j], acc[i][j], 0, 0, 0);
+            if (more) {
+                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][0][sa[i]]) = ra[i];
+                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][1][sb[i]]) = rb[i];
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ca[i] = smem[cur ^ 1][0][fa[i]]; cb[i] = smem[cur ^ 1][1][fb[i]]; }
+        }
+    }
     }
 
-    // epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile
+    // epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile.  The read-modify-write of C
+    // is done in two batches of 32 loads per lane, all issued before the first use, so a tile pays two
+    // memory round trips instead of sixteen.
     const double alpha = g.alpha, beta = g.beta;
+    double *cbase = g.C + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r;
+    if (beta != 0.0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+        for (int ih = 0; ih < 2; ++ih) {
+            double old[2][4][4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const long row = m0 + wm * 64 + i * 16 + q + 4 * v;
-            double *crow = g.C + row * g.ldc + n0 + wn * 64 + r;
-            if (beta != 0.0) {
-                double old[4];
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) old[j] = crow[j * 16];
+                for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) crow[j * 16] = alpha * acc[i][j][v] + beta * old[j];
-            } else {
+                    for (int j = 0; j < 4; ++j)
+                        old[ii][v][j] = cbase[((ih * 2 + ii) * 16 + 4 * v) * g.ldc + j * 16];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) crow[j * 16] = alpha * acc[i][j][v];
-            }
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        cbase[((ih * 2 + ii) * 16 + 4 * v) * g.ldc + j * 16] = alpha * acc[ih * 2 + ii][j][v] + beta * old[ii][v][j];
+            __builtin_amdgcn_sched_barrier(0);
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cbase[(i * 16 + 4 * v) * g.ldc + j * 16] = alpha * acc[i][j][v];
     }
 }
 
@@ -268,8 +356,7 @@ static long gemm_grid_tiles(int tiles_m, int tiles_n, int lower) {
 long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int *out_ti, int *out_tj, long cap) {
     const long nwg = gemm_grid_tiles(tiles_m, tiles_n, lower);
     for (long b = 0; b < nwg && b < cap; ++b) {
-        const long q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
-        const long t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+        const long t = xcd_remap(b, nwg, tiles_n);
         int ti, tj;
         tile_of(t, tiles_m, tiles_n, lower, ti, tj);
         out_ti[b] = ti; out_tj[b] = tj;
@@ -290,7 +377,18 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
     g.ntiles = gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower);
     dim3 grid((unsigned)g.ntiles), block(256);
-#define GO(AK, BN) hipLaunchKernelGGL((gemm_f64_kernel<AK, BN>), grid, block, 0, h->stream, g)
+#define GO(AK, BN) do { if (h->gemm_variant == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 1>), grid, block, 0, h->stream, g); \
+                        else hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 0>), grid, block, 0, h->stream, g); } while (0)
+    if (h->gemm_variant >= 100 && !d.a_kmajor && !d.b_nmajor) {   // timing-only ablations of the K loop (results are wrong)
+        switch (h->gemm_variant - 100) {
+#define AB(X) case X: hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 0, X>), grid, block, 0, h->stream, g); break;
+            AB(1) AB(2) AB(3) AB(4) AB(7) AB(8) AB(11) AB(15) AB(12) AB(6)
+#undef AB
+            default: break;
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (!d.a_kmajor && !d.b_nmajor) GO(0, 0);
     else if (!d.a_kmajor && d.b_nmajor) GO(0, 1);
     else if (d.a_kmajor && !d.b_nmajor) GO(1, 0);

@@ -11,30 +11,50 @@
 
 namespace {
 
+// wave-wide sum of R independent values per column: all R rows are in flight before any reduction
+template <int C, int R>
+__device__ __forceinline__ void wave_reduce(double (&acc)[R][C]) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) acc[rr][cc] += __shfl_down(acc[rr][cc], off, 64);
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void fwd_step_kernel(const double *L, long ldl, long np, long k0, const double *linv,
                                                        double *B, long ldb, double *Y, int c_used) {
     __shared__ double sb[128 * C];
     __shared__ double sy[128 * C];
+    constexpr int R = 8;                       // rows in flight per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < 128 * C; e += 256) {
         const int i = e / C, cc = e - i * C;
         sb[e] = cc < c_used ? B[(k0 + i) * ldb + cc] : 0.0;
     }
     __syncthreads();
-    // y = Linv * b : wave handles rows wave, wave+4, ...; lanes hold 2 columns each
-    for (int i = wave; i < 128; i += 4) {
-        const double2_t l2 = *reinterpret_cast<const double2_t *>(linv + i * 128 + 2 * lane);
-        double acc[C];
+    // y = Linv * b : wave handles 32 rows, 8 at a time; lanes hold 2 columns each
+    {
+        double b0[C], b1[C];
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) acc[cc] = l2[0] * sb[(2 * lane) * C + cc] + l2[1] * sb[(2 * lane + 1) * C + cc];
+        for (int cc = 0; cc < C; ++cc) { b0[cc] = sb[(2 * lane) * C + cc]; b1[cc] = sb[(2 * lane + 1) * C + cc]; }
+        for (int i0 = wave * 32; i0 < wave * 32 + 32; i0 += R) {
+            double2_t l2[R];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
+            for (int rr = 0; rr < R; ++rr) l2[rr] = *reinterpret_cast<const double2_t *>(linv + (i0 + rr) * 128 + 2 * lane);
+            double acc[R][C];
 #pragma unroll
-            for (int cc = 0; cc < C; ++cc) acc[cc] += __shfl_down(acc[cc], off, 64);
-        if (lane == 0)
+            for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-            for (int cc = 0; cc < C; ++cc) sy[i * C + cc] = acc[cc];
+                for (int cc = 0; cc < C; ++cc) acc[rr][cc] = l2[rr][0] * b0[cc] + l2[rr][1] * b1[cc];
+            wave_reduce<C, R>(acc);
+            if (lane == 0)
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < C; ++cc) sy[(i0 + rr) * C + cc] = acc[rr][cc];
+        }
     }
     __syncthreads();
     if (blockIdx.x == 0) {
@@ -43,24 +63,27 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const double *L, long ldl
             if (cc < c_used) Y[(k0 + i) * C + cc] = sy[e];
         }
     }
-    // rows below: each wave takes rows r0 + gw, stride = total waves
+    // rows below: each wave takes R consecutive rows per pass
     double y0[C], y1[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) { y0[cc] = sy[(2 * lane) * C + cc]; y1[cc] = sy[(2 * lane + 1) * C + cc]; }
     const long r0 = k0 + 128;
-    const long nw = (long)gridDim.x * 4;
-    for (long row = r0 + (long)blockIdx.x * 4 + wave; row < np; row += nw) {
-        const double2_t l2 = *reinterpret_cast<const double2_t *>(L + row * ldl + k0 + 2 * lane);
-        double acc[C];
+    const long stride = (long)gridDim.x * 4 * R;
+    for (long rb = r0 + ((long)blockIdx.x * 4 + wave) * R; rb < np; rb += stride) {   // np - r0 is a multiple of 128
+        double2_t l2[R];
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) acc[cc] = l2[0] * y0[cc] + l2[1] * y1[cc];
+        for (int rr = 0; rr < R; ++rr) l2[rr] = *reinterpret_cast<const double2_t *>(L + (rb + rr) * ldl + k0 + 2 * lane);
+        double acc[R][C];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
+        for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-            for (int cc = 0; cc < C; ++cc) acc[cc] += __shfl_down(acc[cc], off, 64);
+            for (int cc = 0; cc < C; ++cc) acc[rr][cc] = l2[rr][0] * y0[cc] + l2[rr][1] * y1[cc];
+        wave_reduce<C, R>(acc);
         if (lane == 0)
 #pragma unroll
-            for (int cc = 0; cc < C; ++cc) if (cc < c_used) B[row * ldb + cc] -= acc[cc];
+            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < C; ++cc) if (cc < c_used) B[(rb + rr) * ldb + cc] -= acc[rr][cc];
     }
 }
 
@@ -68,40 +91,53 @@ template <int C>
 __global__ __launch_bounds__(256) void bwd_step_kernel(const double *L, long ldl, long np, long k0, const double *linv,
                                                        double *Yres, double *X, long ldx, int c_used) {
     __shared__ double sy[128 * C];
-    __shared__ double sxv[128 * C];
+    __shared__ double sxv[2][128 * C];
     const int tid = threadIdx.x;
     for (int e = tid; e < 128 * C; e += 256) sy[e] = Yres[k0 * C + e];
     __syncthreads();
-    // x = Linv^T y : thread i (<128) walks down column i (coalesced across threads)
-    if (tid < 128) {
+    // x = Linv^T y : thread (i, half) walks half of column i of Linv (coalesced across i), 16 loads in flight
+    {
+        const int i = tid & 127, half = tid >> 7;
         double acc[C];
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) acc[cc] = 0.0;
-        for (int j = tid; j < 128; ++j) {       // Linv is lower: Linv[j][i] = 0 for j < i
-            const double l = linv[j * 128 + tid];
+        for (int j0 = half * 64; j0 < half * 64 + 64; j0 += 16) {
+            double l[16];
 #pragma unroll
-            for (int cc = 0; cc < C; ++cc) acc[cc] = fma(l, sy[j * C + cc], acc[cc]);
+            for (int u = 0; u < 16; ++u) l[u] = linv[(j0 + u) * 128 + i];      // Linv[j][i] = 0 for j < i
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int cc = 0; cc < C; ++cc) acc[cc] = fma(l[u], sy[(j0 + u) * C + cc], acc[cc]);
         }
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) sxv[tid * C + cc] = acc[cc];
+        for (int cc = 0; cc < C; ++cc) sxv[half][i * C + cc] = acc[cc];
     }
+    __syncthreads();
+    for (int e = tid; e < 128 * C; e += 256) sxv[0][e] += sxv[1][e];
     __syncthreads();
     if (blockIdx.x == 0) {
         for (int e = tid; e < 128 * C; e += 256) {
             const int i = e / C, cc = e - i * C;
-            if (cc < c_used) X[(k0 + i) * ldx + cc] = sxv[e];
+            if (cc < c_used) X[(k0 + i) * ldx + cc] = sxv[0][e];
         }
     }
-    // columns to the left: thread owns 2 adjacent columns, walks the 128 rows of the block
+    // columns to the left: thread owns 2 adjacent columns and walks the 128 rows, 16 loads in flight
     for (long c2 = ((long)blockIdx.x * 256 + tid) * 2; c2 < k0; c2 += (long)gridDim.x * 512) {
         double a0[C], a1[C];
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) { a0[cc] = 0.0; a1[cc] = 0.0; }
-#pragma unroll 4
-        for (int rr = 0; rr < 128; ++rr) {
-            const double2_t l2 = *reinterpret_cast<const double2_t *>(L + (k0 + rr) * ldl + c2);
+        for (int r0 = 0; r0 < 128; r0 += 16) {
+            double2_t l2[16];
 #pragma unroll
-            for (int cc = 0; cc < C; ++cc) { a0[cc] = fma(l2[0], sxv[rr * C + cc], a0[cc]); a1[cc] = fma(l2[1], sxv[rr * C + cc], a1[cc]); }
+            for (int u = 0; u < 16; ++u) l2[u] = *reinterpret_cast<const double2_t *>(L + (k0 + r0 + u) * ldl + c2);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int cc = 0; cc < C; ++cc) {
+                    a0[cc] = fma(l2[u][0], sxv[0][(r0 + u) * C + cc], a0[cc]);
+                    a1[cc] = fma(l2[u][1], sxv[0][(r0 + u) * C + cc], a1[cc]);
+                }
         }
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) { Yres[c2 * C + cc] -= a0[cc]; Yres[(c2 + 1) * C + cc] -= a1[cc]; }
@@ -211,7 +247,7 @@ int launch_pad_identity(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_
 template <int C>
 static int fwd_go(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv, double *B, int64_t ldb, double *Y, int c) {
     long rows = np - k0 - 128;
-    long blocks = rows > 0 ? (rows + 15) / 16 : 1;   // 4 rows per wave-pass, 4 waves
+    long blocks = rows > 0 ? (rows + 31) / 32 : 1;   // 8 rows per wave-pass, 4 waves
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL((fwd_step_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, h->stream, L, (long)ldl, (long)np, (long)k0, linv, B, (long)ldb, Y, c);
     return 0;
@@ -229,7 +265,7 @@ int launch_fwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, in
 
 template <int C>
 static int bwd_go(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv, double *Yres, double *X, int64_t ldx, int c) {
-    long blocks = k0 > 0 ? (k0 + 511) / 512 : 1;
+    long blocks = k0 > 0 ? (k0 + 511) / 512 : 1;     // 2 columns per thread
     hipLaunchKernelGGL((bwd_step_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, h->stream, L, (long)ldl, (long)np, (long)k0, linv, Yres, X, (long)ldx, c);
     return 0;
 }
