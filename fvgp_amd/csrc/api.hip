@@ -154,7 +154,9 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
         const int64_t Jend = (J0 + NB < np) ? J0 + NB : np;
         for (int64_t k0 = J0; k0 < Jend; k0 += TILE) {
             const int64_t kb = k0 / TILE;
-            rc = launch_leaf(h, A + k0 * lda + k0, lda, h->linv + kb * LEAF_DOUBLES, h->logdet_parts + kb, (int)k0, 1);
+            const int64_t nv = n - k0;
+            rc = launch_leaf(h, A + k0 * lda + k0, lda, h->linv + kb * LEAF_DOUBLES, h->logdet_parts + kb, (int)k0, 1,
+                             nv >= TILE ? TILE : (nv > 0 ? (int)nv : 0));
             if (rc) return rc;
             const int64_t r0 = k0 + TILE, R = np - r0;
             if (R <= 0) continue;
@@ -412,7 +414,6 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     if (ncol < 1 || ncol > FVGP_MAX_RHS_VEC) { fvgp_set_error("1 <= ncol <= 8"); return -10; }
     int rc = check_square(KV, n, ld, 11, 4, 12);
     if (rc) return rc;
-    if (!alpha) return -13;
     if (!out_host) return -14;
     HIPCHK(hipSetDevice(h->device));
     const int64_t np = pad128(n);
@@ -420,14 +421,42 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &k); if (rc) return rc;
     k.x1 = x; k.n1 = n; k.x2 = x; k.n2 = n; k.vdiag = vdiag; k.K = KV; k.ldk = ld; k.uplo = FVGP_LOWER; k.pad = 1;
     rc = launch_kmat(h, k); if (rc) return rc;
+    // forward solve fused into the factorisation: (y-m)^T is appended as rows n..n+ncol-1 of the padded
+    // matrix (diagonal entry large enough to keep the block PD); the panel TRSM / trailing updates then
+    // leave z^T = (L^-1 (y-m))^T in those rows and quad = |z|^2.  Needs ncol free padding rows.
+    const bool fused = (np - n) >= ncol;
+    if (fused) { rc = launch_rhs_rows(h, KV, n, ld, ymean, ncol, vdiag); if (rc) return rc; }
     int info = 0;
     rc = potrf_driver(h, KV, n, ld, &info); if (rc) return rc;
     if (info_host) *info_host = info;
     if (info != 0) { out_host[0] = out_host[1] = out_host[2] = NAN; return 0; }
-    rc = launch_copy_cols(h, ymean, ncol, alpha, ncol, n, ncol, np, ncol); if (rc) return rc;
-    rc = potrs_vec(h, KV, n, ld, alpha, ncol, ncol, true); if (rc) return rc;
     rc = launch_sum(h, h->logdet_parts, np / TILE, h->red); if (rc) return rc;
-    rc = launch_dot_rows(h, ymean, ncol, alpha, ncol, n, ncol, h->red + 1); if (rc) return rc;
+    if (fused) {
+        rc = launch_rowsumsq(h, KV, ld, n, ncol, n, h->red + 1); if (rc) return rc;
+        const int C = ncol <= 1 ? 1 : ncol <= 2 ? 2 : ncol <= 4 ? 4 : 8;
+        if (alpha) {
+            // z (rows of L) -> (np x C) vector layout for the backward sweep
+            rc = ensure_scratch(h, np); if (rc) return rc;
+            rc = launch_rows_to_vec(h, KV, ld, n, ncol, h->vec, C, np); if (rc) return rc;
+        }
+        // hand back the clean factor of blockdiag(K+V, I): identity padding rows again, and the inverse of
+        // the last diagonal block recomputed without the appended rows
+        rc = launch_pad_identity(h, KV, n, np, ld); if (rc) return rc;
+        rc = launch_leaf(h, KV + (np - TILE) * ld + (np - TILE), ld, h->linv + (np / TILE - 1) * LEAF_DOUBLES, nullptr, 0, 0, TILE);
+        if (rc) return rc;
+        if (alpha) {
+            rc = launch_copy_cols(h, alpha, ncol, alpha, ncol, 0, 0, np, ncol); if (rc) return rc;
+            for (int64_t k0 = np - TILE; k0 >= 0; k0 -= TILE) {
+                rc = launch_bwd_step(h, KV, ld, np, k0, h->linv + (k0 / TILE) * LEAF_DOUBLES, h->vec, alpha, ncol, ncol);
+                if (rc) return rc;
+            }
+        }
+    } else {
+        if (!alpha) { fvgp_set_error("loglik without alpha needs ncol free padding rows (n % 128 <= 128 - ncol)"); return -13; }
+        rc = launch_copy_cols(h, ymean, ncol, alpha, ncol, n, ncol, np, ncol); if (rc) return rc;
+        rc = potrs_vec(h, KV, n, ld, alpha, ncol, ncol, true); if (rc) return rc;
+        rc = launch_dot_rows(h, ymean, ncol, alpha, ncol, n, ncol, h->red + 1); if (rc) return rc;
+    }
     double r[2];
     rc = read_back(h, h->red, r, 2); if (rc) return rc;
     const double logdet = 2.0 * r[0], quad = r[1] / (double)ncol;

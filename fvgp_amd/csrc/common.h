@@ -90,7 +90,7 @@ struct GradDesc {
 };
 int launch_grad_trace(fvgp_handle *h, const GradDesc &g, int *nblocks_out);
 
-int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor);
+int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid);
 int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, int64_t nblk, double *linv);
 
 int launch_fwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,
@@ -101,6 +101,9 @@ int launch_diag_logsum(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, 
 int launch_sum(fvgp_handle *h, const double *v, int64_t n, double *out_dev);
 int launch_dot_rows(fvgp_handle *h, const double *a, int64_t lda, const double *b, int64_t ldb, int64_t n, int c, double *out_dev);
 int launch_pad_identity(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda);
+int launch_rhs_rows(fvgp_handle *h, double *A, int64_t n, int64_t lda, const double *ymean, int ncol, const double *vdiag);
+int launch_rows_to_vec(fvgp_handle *h, const double *A, int64_t lda, int64_t row0, int nrows, double *vec, int C, int64_t np);
+int launch_rowsumsq(fvgp_handle *h, const double *A, int64_t lda, int64_t row0, int nrows, int64_t ncols, double *out_dev);
 int launch_copy_cols(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t rows, int64_t cols,
                      int64_t rows_pad, int64_t cols_pad);
 int launch_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda);

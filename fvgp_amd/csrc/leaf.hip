@@ -32,6 +32,7 @@ struct LeafArgs {
     double *logdet_part;          // 1 double out (may be null)
     int *info; int info_base;
     int do_factor;
+    int nvalid;                   // rows of this block that count for log-det and info (rest is padding)
     long a_stride, linv_stride;   // batched mode: block b at A + b*a_stride
 };
 
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(LeafArgs g) {
         for (int p = 0; p < 8; ++p) {
             if (wave == 0) {
                 const int bad = diag_tile<true>(&sA[(16 * p) * LS + 16 * p], &sD[p * 16 * DS], lane);
-                if (bad >= 0 && lane == 0) atomicCAS(g.info, 0, g.info_base + (int)blockIdx.x * 128 + 16 * p + bad + 1);
+                if (bad >= 0 && lane == 0 && 16 * p + bad < g.nvalid) atomicCAS(g.info, 0, g.info_base + (int)blockIdx.x * 128 + 16 * p + bad + 1);
             }
             __syncthreads();
             // TRSM: X_t = A_t * Dinv_p^T for tiles t = p+1..7
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(LeafArgs g) {
         }
         if (g.logdet_part != nullptr) {
             double s = 0.0;
-            if (tid < 128) s = log(fabs(sA[tid * LS + tid]));
+            if (tid < g.nvalid) s = log(fabs(sA[tid * LS + tid]));
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0) slog[wave] = s;
@@ -214,10 +215,10 @@ __global__ __launch_bounds__(256) void leaf_kernel(LeafArgs g) {
 
 }  // namespace
 
-int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor) {
+int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid) {
     LeafArgs g;
     g.A = A; g.lda = lda; g.linv = linv; g.logdet_part = logdet_part; g.info = h->dinfo; g.info_base = info_base;
-    g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0;
+    g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid;
     hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
@@ -227,7 +228,7 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
     if (nblk <= 0) return 0;
     LeafArgs g;
     g.A = const_cast<double *>(L); g.lda = ldl; g.linv = linv; g.logdet_part = nullptr; g.info = h->dinfo; g.info_base = 0;
-    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES;
+    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128;
     hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)nblk), dim3(256), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;

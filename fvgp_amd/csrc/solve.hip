@@ -233,7 +233,75 @@ __global__ void pad_identity_kernel(double *A, long n, long np, long lda) {
     }
 }
 
+// rows n..n+ncol-1 of the padded K+V <- (y-m)^T with a diagonal entry 1 + sum|y-m|^2 / min(V), which
+// dominates |L^-1 (y-m)|^2 <= |y-m|^2 / lambda_min(K+V) and so keeps the appended block positive definite
+__global__ void rhs_rows_kernel(double *A, long n, long lda, const double *ymean, int ncol, const double *vdiag) {
+    __shared__ double ssum[16], smin[16];
+    __shared__ double sbig;
+    double s = 0.0, mn = 1e300;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        for (int c = 0; c < ncol; ++c) { const double v = ymean[i * ncol + c]; s = fma(v, v, s); }
+        const double vv = vdiag[i]; mn = vv < mn ? vv : mn;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); const double o = __shfl_down(mn, off, 64); mn = o < mn ? o : mn; }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; smin[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0, m2 = 1e300;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t += ssum[w]; m2 = smin[w] < m2 ? smin[w] : m2; }
+        sbig = 1.0 + t / m2;
+    }
+    __syncthreads();
+    const double big = sbig;
+    for (long e = threadIdx.x; e < (long)ncol * (n + ncol); e += blockDim.x) {
+        const int c = (int)(e / (n + ncol)); const long j = e % (n + ncol);
+        double v;
+        if (j < n) v = ymean[j * ncol + c];
+        else v = (j - n == c) ? big : 0.0;
+        if (j <= n + c) A[(n + c) * lda + j] = v;
+    }
+}
+
+// out[0] = sum over rows row0..row0+nrows-1, cols 0..ncols-1 of A^2
+__global__ void rowsumsq_kernel(const double *A, long lda, long row0, int nrows, long ncols, double *out) {
+    __shared__ double sw[16];
+    double s = 0.0;
+    for (int rr = 0; rr < nrows; ++rr)
+        for (long j = threadIdx.x; j < ncols; j += blockDim.x) { const double v = A[(row0 + rr) * lda + j]; s = fma(v, v, s); }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sw[w]; out[0] = t; }
+}
+
+// vec (np x C) <- transpose of rows row0.. of A (first row0 columns), zero elsewhere
+__global__ void rows_to_vec_kernel(const double *A, long lda, long row0, int nrows, double *vec, int C, long np) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < np * C; e += (long)gridDim.x * blockDim.x) {
+        const long i = e / C; const int c = (int)(e % C);
+        vec[e] = (i < row0 && c < nrows) ? A[(row0 + c) * lda + i] : 0.0;
+    }
+}
+
 }  // namespace
+
+int launch_rhs_rows(fvgp_handle *h, double *A, int64_t n, int64_t lda, const double *ymean, int ncol, const double *vdiag) {
+    hipLaunchKernelGGL(rhs_rows_kernel, dim3(1), dim3(1024), 0, h->stream, A, (long)n, (long)lda, ymean, ncol, vdiag);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_rowsumsq(fvgp_handle *h, const double *A, int64_t lda, int64_t row0, int nrows, int64_t ncols, double *out_dev) {
+    hipLaunchKernelGGL(rowsumsq_kernel, dim3(1), dim3(1024), 0, h->stream, A, (long)lda, (long)row0, nrows, (long)ncols, out_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_to_vec(fvgp_handle *h, const double *A, int64_t lda, int64_t row0, int nrows, double *vec, int C, int64_t np) {
+    long tot = np * C; long blocks = (tot + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(rows_to_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, (long)lda, (long)row0, nrows, vec, C, (long)np);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 
 int launch_pad_identity(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda) {
     if (np <= n) return 0;
