@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--d", type=int, default=3)
     ap.add_argument("--outer-block", type=int, default=0, help="K of the trailing SYRK (0 = library default)")
+    ap.add_argument("--lookahead", type=int, default=-1, help="1/0: factor the next panel on a side stream (-1 = library default)")
+    ap.add_argument("--reserve-cus", type=int, default=-1)
     ap.add_argument("--cpu-sample-n", type=int, default=18000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -95,6 +97,10 @@ def main():
     H = _lib.Handle(local)
     if args.outer_block:
         H.set_option("outer_block", args.outer_block)
+    if args.reserve_cus >= 0:
+        H.set_option("reserve_cus", args.reserve_cus)
+    if args.lookahead >= 0:
+        H.set_option("lookahead", args.lookahead)
     npad = _lib.pad128(n)
     xd = H.to_device(x)
     vd = H.to_device(np.full(n, 0.01))

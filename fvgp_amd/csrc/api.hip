@@ -40,6 +40,11 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
+    if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
+    if (h->ev_cols) (void)hipEventDestroy(h->ev_cols);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->bulk) (void)hipStreamDestroy(h->bulk);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->linv) (void)hipFree(h->linv);
     if (h->logdet_parts) (void)hipFree(h->logdet_parts);
     if (h->red) (void)hipFree(h->red);
@@ -65,6 +70,8 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
         return 0;
     }
     if (!strcmp(key, "profile")) { h->profile = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "lookahead")) { h->lookahead = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "reserve_cus")) { h->reserve_cus = (int)value; return 0; }
     if (!strcmp(key, "gemm_variant")) { h->gemm_variant = (int)value; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
     return -2;
@@ -133,6 +140,70 @@ static int check_square(const void *A, int64_t n, int64_t ld, int argA, int argn
 //              the remaining columns of the current outer panel (K = 128);
 //   outer NB : one trailing SYRK per outer panel with K = NB, which carries ~all the flops
 //              and keeps the C-tile read-modify-write traffic at 8/NB bytes per flop.
+// factor the outer panel [J0, Jend): leaf / TRSM / in-panel update per 128 columns, on h->stream
+static int panel_factor(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+    int rc;
+    for (int64_t k0 = J0; k0 < Jend; k0 += TILE) {
+        const int64_t kb = k0 / TILE;
+        const int64_t nv = n - k0;
+        rc = launch_leaf(h, A + k0 * lda + k0, lda, h->linv + kb * LEAF_DOUBLES, h->logdet_parts + kb, (int)k0, 1,
+                         nv >= TILE ? TILE : (nv > 0 ? (int)nv : 0));
+        if (rc) return rc;
+        const int64_t r0 = k0 + TILE, R = np - r0;
+        if (R <= 0) continue;
+        // panel TRSM in place: A[r0:, k0:k0+128] <- A[r0:, k0:k0+128] * inv(L_kk)^T
+        GemmDesc t{};
+        t.a_kmajor = 0; t.b_nmajor = 0; t.lower = 0; t.M = R; t.N = TILE; t.K = TILE;
+        t.alpha = 1.0; t.beta = 0.0;
+        t.A = A + r0 * lda + k0; t.lda = lda;
+        t.B = h->linv + kb * LEAF_DOUBLES; t.ldb = TILE;
+        t.C = A + r0 * lda + k0; t.ldc = lda;
+        rc = launch_gemm(h, t);
+        if (rc) return rc;
+        // update of the rest of the outer panel: A[r0:, r0:Jend] -= P P[0:Jend-r0]^T (lower tiles)
+        const int64_t W = Jend - r0;
+        if (W > 0) {
+            GemmDesc u{};
+            u.a_kmajor = 0; u.b_nmajor = 0; u.lower = 1; u.M = R; u.N = W; u.K = TILE;
+            u.alpha = -1.0; u.beta = 1.0;
+            u.A = A + r0 * lda + k0; u.lda = lda;
+            u.B = A + r0 * lda + k0; u.ldb = lda;
+            u.C = A + r0 * lda + r0; u.ldc = lda;
+            rc = launch_gemm(h, u);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+// trailing update with the factored panel [J0, Jend): block columns [c0, c1) of the trailing matrix
+// (rows c0..np), lower tiles only:  A[c0:, c0:c1] -= L[c0:, J0:Jend] L[c0:c1, J0:Jend]^T
+static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, int64_t J0, int64_t Jend, int64_t c0, int64_t c1) {
+    if (c1 <= c0 || np <= c0) return 0;
+    GemmDesc s{};
+    s.a_kmajor = 0; s.b_nmajor = 0; s.lower = 1; s.M = np - c0; s.N = c1 - c0; s.K = Jend - J0;
+    s.alpha = -1.0; s.beta = 1.0;
+    s.A = A + c0 * lda + J0; s.lda = lda;
+    s.B = A + c0 * lda + J0; s.ldb = lda;
+    s.C = A + c0 * lda + c0; s.ldc = lda;
+    return launch_gemm(h, s);
+}
+
+static double lower_flops(int64_t M, int64_t N, int64_t K) {     // algorithmic flops of a lower-tile update
+    const double tm = (double)(M / TILE), tn = (double)(N / TILE);
+    const double tiles = tn * (tn + 1.0) * 0.5 + (tm - tn) * tn;
+    return tiles * 128.0 * 128.0 * 2.0 * (double)K;
+}
+
+// ---------------------------------------------------------------------------------------
+// blocked right-looking Cholesky, two block sizes:
+//   inner 128: leaf (potf2 + trtri in LDS) -> panel TRSM as GEMM with inv(L_kk) -> update of
+//              the remaining columns of the current outer panel (K = 128);
+//   outer NB : one trailing SYRK per outer panel with K = NB, which carries ~all the flops
+//              and keeps the C-tile read-modify-write traffic at 8/NB bytes per flop.
+// look-ahead (option "lookahead"): the trailing update of panel J is split into the block columns of
+// panel J+1 (done first) and the rest; panel J+1 is then factored on a second, high-priority stream
+// while the rest of the update runs on the main stream.
 static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host) {
     const int64_t np = pad128(n), nblk = np / TILE;
     int rc = ensure_blocks(h, nblk);
@@ -149,56 +220,74 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
         return 0;
     };
     if (h->profile) { rc = get_event(&e_begin); if (rc) return rc; HIPCHK(hipEventRecord(e_begin, h->stream)); }
+    auto timed_update = [&](int64_t J0, int64_t Jend, int64_t c0, int64_t c1) -> int {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->profile) { int r = get_event(&e0); if (r) return r; HIPCHK(hipEventRecord(e0, h->stream)); }
+        int r = trailing_update(h, A, np, lda, J0, Jend, c0, c1);
+        if (r) return r;
+        if (h->profile) {
+            r = get_event(&e1); if (r) return r; HIPCHK(hipEventRecord(e1, h->stream));
+            h->ev_flops.push_back(lower_flops(np - c0, c1 - c0, Jend - J0));
+        }
+        return 0;
+    };
 
-    for (int64_t J0 = 0; J0 < np; J0 += NB) {
-        const int64_t Jend = (J0 + NB < np) ? J0 + NB : np;
-        for (int64_t k0 = J0; k0 < Jend; k0 += TILE) {
-            const int64_t kb = k0 / TILE;
-            const int64_t nv = n - k0;
-            rc = launch_leaf(h, A + k0 * lda + k0, lda, h->linv + kb * LEAF_DOUBLES, h->logdet_parts + kb, (int)k0, 1,
-                             nv >= TILE ? TILE : (nv > 0 ? (int)nv : 0));
-            if (rc) return rc;
-            const int64_t r0 = k0 + TILE, R = np - r0;
-            if (R <= 0) continue;
-            // panel TRSM in place: A[r0:, k0:k0+128] <- A[r0:, k0:k0+128] * inv(L_kk)^T
-            GemmDesc t{};
-            t.a_kmajor = 0; t.b_nmajor = 0; t.lower = 0; t.M = R; t.N = TILE; t.K = TILE;
-            t.alpha = 1.0; t.beta = 0.0;
-            t.A = A + r0 * lda + k0; t.lda = lda;
-            t.B = h->linv + kb * LEAF_DOUBLES; t.ldb = TILE;
-            t.C = A + r0 * lda + k0; t.ldc = lda;
-            rc = launch_gemm(h, t);
-            if (rc) return rc;
-            // update of the rest of the outer panel: A[r0:, r0:Jend] -= P P[0:Jend-r0]^T (lower tiles)
-            const int64_t W = Jend - r0;
-            if (W > 0) {
-                GemmDesc u{};
-                u.a_kmajor = 0; u.b_nmajor = 0; u.lower = 1; u.M = R; u.N = W; u.K = TILE;
-                u.alpha = -1.0; u.beta = 1.0;
-                u.A = A + r0 * lda + k0; u.lda = lda;
-                u.B = A + r0 * lda + k0; u.ldb = lda;
-                u.C = A + r0 * lda + r0; u.ldc = lda;
-                rc = launch_gemm(h, u);
-                if (rc) return rc;
+    const bool la = h->lookahead && np > 2 * NB;
+    if (!la) {
+        for (int64_t J0 = 0; J0 < np; J0 += NB) {
+            const int64_t Jend = (J0 + NB < np) ? J0 + NB : np;
+            rc = panel_factor(h, A, n, np, lda, J0, Jend); if (rc) return rc;
+            if (np > Jend) { rc = timed_update(J0, Jend, Jend, np); if (rc) return rc; }
+        }
+    } else {
+        if (!h->side) {
+            int lo = 0, hi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_cols, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+            if (h->reserve_cus > 0) {
+                // trailing updates run on a stream whose CU mask leaves a few CUs free, so the
+                // single-workgroup leaf of the look-ahead panel (151 KB LDS) always finds an empty CU
+                uint32_t mask[8];
+                for (int i = 0; i < 8; ++i) mask[i] = 0xFFFFFFFFu;
+                for (int i = 0; i < h->reserve_cus && i < 64; ++i) mask[(i * 37 % 256) / 32] &= ~(1u << ((i * 37 % 256) % 32));
+                if (hipExtStreamCreateWithCUMask(&h->bulk, 8, mask) != hipSuccess) { (void)hipGetLastError(); h->bulk = nullptr; }
             }
         }
-        const int64_t R = np - Jend;
-        if (R > 0) {
-            GemmDesc s{};
-            s.a_kmajor = 0; s.b_nmajor = 0; s.lower = 1; s.M = R; s.N = R; s.K = Jend - J0;
-            s.alpha = -1.0; s.beta = 1.0;
-            s.A = A + Jend * lda + J0; s.lda = lda;
-            s.B = A + Jend * lda + J0; s.ldb = lda;
-            s.C = A + Jend * lda + Jend; s.ldc = lda;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (h->profile) { rc = get_event(&e0); if (rc) return rc; HIPCHK(hipEventRecord(e0, h->stream)); }
-            rc = launch_gemm(h, s);
+        hipStream_t userS = h->stream;
+        hipStream_t mainS = h->bulk ? h->bulk : h->stream, sideS = h->side;
+        if (h->bulk) {
+            HIPCHK(hipEventRecord(h->ev_join, userS));
+            HIPCHK(hipStreamWaitEvent(mainS, h->ev_join, 0));
+            h->stream = mainS;
+        }
+        // panel 0 on the main stream
+        rc = panel_factor(h, A, n, np, lda, 0, NB < np ? NB : np); if (rc) return rc;
+        for (int64_t J0 = 0; J0 < np; J0 += NB) {
+            const int64_t Jend = (J0 + NB < np) ? J0 + NB : np;
+            if (np <= Jend) break;
+            const int64_t Nend = (Jend + NB < np) ? Jend + NB : np;      // next panel = [Jend, Nend)
+            // (1) main: bring the next panel's block columns up to date with panel J
+            rc = timed_update(J0, Jend, Jend, Nend); if (rc) return rc;
+            HIPCHK(hipEventRecord(h->ev_cols, mainS));
+            // (2) side: factor the next panel as soon as (1) is done ...
+            HIPCHK(hipStreamWaitEvent(sideS, h->ev_cols, 0));
+            h->stream = sideS;
+            rc = panel_factor(h, A, n, np, lda, Jend, Nend);
+            h->stream = mainS;
             if (rc) return rc;
-            if (h->profile) {
-                rc = get_event(&e1); if (rc) return rc; HIPCHK(hipEventRecord(e1, h->stream));
-                const double T = (double)(R / TILE);
-                h->ev_flops.push_back(T * (T + 1.0) * 0.5 * 128.0 * 128.0 * 2.0 * (double)(Jend - J0));
-            }
+            HIPCHK(hipEventRecord(h->ev_panel, sideS));
+            // (3) ... while main applies panel J to everything right of the next panel
+            if (np > Nend) { rc = timed_update(J0, Jend, Nend, np); if (rc) return rc; }
+            // the next iteration's updates use panel J+1: wait for its factorisation
+            HIPCHK(hipStreamWaitEvent(mainS, h->ev_panel, 0));
+        }
+        if (h->bulk) {
+            HIPCHK(hipEventRecord(h->ev_join, mainS));
+            h->stream = userS;
+            HIPCHK(hipStreamWaitEvent(userS, h->ev_join, 0));
         }
     }
     if (h->profile) { rc = get_event(&e_end); if (rc) return rc; HIPCHK(hipEventRecord(e_end, h->stream)); }

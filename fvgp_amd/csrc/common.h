@@ -34,6 +34,11 @@ struct fvgp_handle {
     int64_t outer_block = 1024;
     int profile = 0;
     int gemm_variant = 0;
+    int lookahead = 0;
+    hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel
+    hipEvent_t ev_panel = nullptr, ev_cols = nullptr, ev_join = nullptr;
+    hipStream_t bulk = nullptr;       // CU-masked stream for the trailing updates (look-ahead mode)
+    int reserve_cus = 0;
     // profile of the last potrf
     std::vector<hipEvent_t> ev;
     std::vector<double> ev_flops;

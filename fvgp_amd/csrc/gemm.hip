@@ -79,7 +79,9 @@ __host__ __device__ inline long xcd_remap(long b, long nwg, int tiles_n) {
 
 template <int AKM, int BNM, int PIPE, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
-    __shared__ double smem[2][2][IMG];
+    // 76 KB, a little more than the 72 KB of operand images: the look-ahead leaf kernel (73 KB) must fit
+    // into the LDS range one retiring workgroup of this kernel frees
+    __shared__ double smem[2][2][IMG + 128];
 
     // XCD-aware remap: hardware deals block b to XCD b%8.  Blocks b, b+8, b+16, .. (one XCD) walk whole
     // super-tiles: the 8*SN tiles of a super-tile run together on one L2, and super-tiles are dealt

@@ -2,29 +2,38 @@
 //
 // Stands in for the unblocked dpotf2 / dtrtri steps inside LAPACK dpotrf that
 // scipy.linalg.cho_factor reaches (fvgp/gp_lin_alg.py:245).  The blocked driver
-// (potrf.hip) calls it once per 128 columns; its outputs are
+// (api.hip: panel_factor) calls it once per 128 columns; its outputs are
 //   * L11 in place (lower triangle of the block only -- the strict upper is never read or
 //     written, matching cho_factor's "upper is unspecified"),
 //   * inv(L11) as a dense 128x128 (upper = 0) so that the panel TRSM  A21 * L11^-T  and the
 //     block substitutions of potrs become plain MFMA GEMMs,
-//   * sum(log L_ii) of the block (feeds calculate_Chol_logdet, gp_lin_alg.py:337-338),
+//   * sum(log L_ii) of the block's valid rows (feeds calculate_Chol_logdet, gp_lin_alg.py:337-338),
 //   * info: 1-based global index of the first non-positive pivot (dpotrf's info > 0).
 //
-// Algorithm (16-wide blocks, fp64 MFMA 16x16x4 for every tile product):
-//   for p = 0..7:  wave 0 factors the 16x16 diagonal tile with lane-shuffles (row per lane,
-//                  left-looking) and inverts it (column per lane);  all waves: tile TRSM
-//                  X = A * Dinv^T;  trailing tiles C -= X_i X_j^T.
-//   inverse:       block column j of inv(L) by forward block substitution
-//                  X_ij = -Dinv_i * sum_{k=j..i-1} L_ik X_kj ; the MFMA accumulator layout
-//                  (row = q+4v) is exactly the next MFMA's B-operand layout, so the product
-//                  chains in registers.  X is kept transposed in the (otherwise unused)
-//                  upper triangle of the LDS image.
+// Resource shape matters as much as speed: under look-ahead this kernel must start while the
+// trailing SYRK occupies every CU with two 72 KB workgroups, so it is built to fit into what ONE
+// retiring SYRK workgroup frees: the lower triangle is held as 36 packed 16x16 tiles
+// (36 x 2048 B = 72 KB + 1 KB, below the 76 KB a SYRK workgroup holds), 512 threads at <= 128 VGPRs.
+//
+// Algorithm (16-wide blocks):
+//   for p = 0..7:  TRSM of the rows below by per-row forward substitution against L_pp;
+//                  trailing tiles C_ij -= X_i X_j^T on fp64 MFMA 16x16x4; wave 0 takes tile
+//                  (p+1,p+1) first and factors it (lane-broadcast left-looking Cholesky, Newton
+//                  reciprocal square roots) while the other waves finish the update.
+//   inverse:       wave j owns block column j of inv(L):  X_jj = inv(L_jj),
+//                  X_ij = -inv(L_ii) * sum_{k=j..i-1} L_ik X_kj.  The f64 MFMA accumulator layout
+//                  (row = q+4v) is exactly the next MFMA's B-operand layout, so the whole column
+//                  stays in registers and goes straight to global memory.
 #include "common.h"
 
 namespace {
 
-constexpr int LS = 130;   // LDS row stride (doubles): 260 dwords == 4 mod 64 -> conflict-free fragment reads
-constexpr int DS = 18;    // stride of the 16x16 diagonal-inverse tiles
+constexpr int TSZ = 256;          // a packed 16x16 tile, unpadded: 36 tiles = exactly 72 KB
+constexpr int NT = 36;            // tiles (i,j), j <= i < 8
+
+// element (a, b) of a tile: columns XOR-swizzled by an even mask so that both MFMA fragment read
+// patterns (16 rows x one column pair, one row pair x 16 columns) are LDS bank-conflict free
+__device__ __forceinline__ int el(int a, int b) { return a * 16 + (b ^ (((a >> 1) & 7) << 1)); }
 
 struct LeafArgs {
     double *A; long lda;          // block origin
@@ -40,176 +49,235 @@ __device__ __forceinline__ double4_t mfma(double a, double b, double4_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// one wave: factor (optional) and invert the 16x16 tile at sT (stride LS); inverse -> sDt (stride DS)
-// returns the first bad pivot column (0..15) or -1
-template <bool do_factor>
-__device__ __forceinline__ int diag_tile(double *sT, double *sDt, int lane) {
+__device__ __forceinline__ int tix(int i, int j) { return (i * (i + 1) / 2 + j) * TSZ; }
+
+// value of `v` in lane SRC (compile-time constant) broadcast to the whole wave through SGPRs
+template <int SRC>
+__device__ __forceinline__ double bcast(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(x) to fp64 accuracy: hardware estimate + two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    double e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+
+template <int J>
+struct Col {
+    // column J of the left-looking factorisation; lane `row` holds row `row` of the tile in a[]
+    static __device__ __forceinline__ void step(double (&a)[16], double (&rd)[16], int row, int &bad) {
+        double s = a[J];
+#pragma unroll
+        for (int k = 0; k < J; ++k) s = fma(-a[k], bcast<J>(a[k]), s);
+        const double dj = bcast<J>(s);
+        if (!(dj > 0.0) && bad < 0) bad = J;
+        const double y = rsqrt_nr(dj);
+        double piv = dj * y;                                   // sqrt(dj), one correction step
+        piv = fma(fma(-piv, piv, dj), 0.5 * y, piv);
+        rd[J] = y;
+        a[J] = (row == J) ? piv : (row > J ? s * y : 0.0);
+        if constexpr (J < 15) Col<J + 1>::step(a, rd, row, bad);
+    }
+};
+
+template <int I>
+struct InvRow {
+    // row I of inv(tile): lane c holds column c of the inverse in x[]
+    static __device__ __forceinline__ void step(const double (&a)[16], const double (&rd)[16], double (&x)[16], int c) {
+        double s = (I == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < I; ++k) s = fma(-bcast<I>(a[k]), x[k], s);
+        x[I] = s * rd[I];
+        if constexpr (I < 15) InvRow<I + 1>::step(a, rd, x, c);
+    }
+};
+
+// one wave: Cholesky of the 16x16 tile at sT (lower part), in place; 1/diag -> srd[0..15]
+// returns the first bad pivot column or -1
+__device__ __forceinline__ int diag_factor(double *sT, double *srd, int lane) {
     const int row = lane & 15;
-    double a[16];
+    double a[16], rd[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = (k <= row) ? sT[row * LS + k] : 0.0;
+    for (int k = 0; k < 16; ++k) a[k] = (k <= row) ? sT[el(row, k)] : 0.0;
     int bad = -1;
-    if (do_factor) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            double s = a[j];
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < j) s -= a[k] * __shfl(a[k], j, 64);
-            const double dj = __shfl(s, j, 64);
-            if (!(dj > 0.0) && bad < 0) bad = j;
-            const double piv = sqrt(dj);
-            a[j] = (row == j) ? piv : (row > j ? s / piv : 0.0);
-        }
-    }
-    double x[16];
-    const int c = row;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        double s = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (k < i) s -= __shfl(a[k], i, 64) * x[k];
-        x[i] = s / __shfl(a[i], i, 64);
-    }
+    Col<0>::step(a, rd, row, bad);
     if (lane < 16) {
-        if (do_factor) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) if (k <= row) sT[row * LS + k] = a[k];
-        }
+        for (int k = 0; k < 16; ++k) if (k <= row) sT[el(row, k)] = a[k];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sDt[i * DS + c] = x[i];
+        for (int k = 0; k < 16; ++k) if (k == row) srd[k] = rd[k];
     }
     return bad;
 }
 
-__global__ __launch_bounds__(256) void leaf_kernel(LeafArgs g) {
-    __shared__ double sA[128 * LS];
-    __shared__ double sD[8 * 16 * DS];
-    __shared__ double slog[4];
+__global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
+    __shared__ double sT[NT * TSZ];      // 73,728 B
+    __shared__ double srd[128];          // 1 / L_aa
+    __shared__ double slog[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     double *A = g.A + (long)blockIdx.x * g.a_stride;
     double *linv = g.linv + (long)blockIdx.x * g.linv_stride;
 
-    // load the lower triangle; zero the strict upper (it becomes the workspace for inv(L)^T)
-    for (int e = tid; e < 128 * 64; e += 256) {
+    // ---- load the lower triangle into packed tiles; strict upper of diagonal tiles <- 0 ----------
+    for (int e = tid; e < 128 * 64; e += 512) {
         const int row = e >> 6, c2 = (e & 63) * 2;
-        double2_t v = {0.0, 0.0};
-        if (c2 <= row) v = *reinterpret_cast<const double2_t *>(A + (long)row * g.lda + c2);
+        const int ti = row >> 4, tj = c2 >> 4;
+        if (tj > ti) continue;
+        double2_t v = *reinterpret_cast<const double2_t *>(A + (long)row * g.lda + c2);
         if (c2 + 1 > row) v[1] = 0.0;
         if (c2 > row) v[0] = 0.0;
-        sA[row * LS + c2] = v[0];
-        sA[row * LS + c2 + 1] = v[1];
+        double *dst = &sT[tix(ti, tj)];
+        dst[el(row & 15, c2 & 15)] = v[0]; dst[el(row & 15, (c2 & 15) + 1)] = v[1];
     }
     __syncthreads();
 
     if (g.do_factor) {
+        if (wave == 0) {
+            const int bad = diag_factor(&sT[tix(0, 0)], &srd[0], lane);
+            if (bad >= 0 && lane == 0 && bad < g.nvalid) atomicCAS(g.info, 0, g.info_base + (int)blockIdx.x * 128 + bad + 1);
+        }
+        __syncthreads();
         for (int p = 0; p < 8; ++p) {
-            if (wave == 0) {
-                const int bad = diag_tile<true>(&sA[(16 * p) * LS + 16 * p], &sD[p * 16 * DS], lane);
-                if (bad >= 0 && lane == 0 && 16 * p + bad < g.nvalid) atomicCAS(g.info, 0, g.info_base + (int)blockIdx.x * 128 + 16 * p + bad + 1);
-            }
-            __syncthreads();
-            // TRSM: X_t = A_t * Dinv_p^T for tiles t = p+1..7
-            for (int t = p + 1 + wave; t < 8; t += 4) {
-                double a[4], b[4];
+            // ---- TRSM: rows below the diagonal tile, one thread per row, x <- a * L_pp^-T ------------
+            const int R = 112 - 16 * p;
+            if (tid < R) {
+                const int i = p + 1 + (tid >> 4), a = tid & 15;
+                double *rowp = &sT[tix(i, p)];
+                const double *Lp = &sT[tix(p, p)];
+                double x[16];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    a[s] = sA[(16 * t + r) * LS + 16 * p + 4 * s + q];
-                    b[s] = sD[p * 16 * DS + r * DS + 4 * s + q];
+                for (int c = 0; c < 16; ++c) x[c] = rowp[el(a, c)];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    double s = x[j];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) if (k < j) s = fma(-x[k], Lp[el(j, k)], s);
+                    x[j] = s * srd[16 * p + j];
                 }
-                double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc = mfma(a[s], b[s], acc);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) sA[(16 * t + q + 4 * v) * LS + 16 * p + r] = acc[v];
+                for (int c = 0; c < 16; ++c) rowp[el(a, c)] = x[c];
             }
             __syncthreads();
-            // trailing update: C_ij -= X_i X_j^T for p < j <= i <= 7
+            // ---- trailing update C_ij -= X_i X_j^T, p < j <= i <= 7 ---------------------------------------
             const int T = 7 - p;
             const int ntile = T * (T + 1) / 2;
-            for (int idx = wave; idx < ntile; idx += 4) {
+            // wave 0: tile (p+1,p+1) only, then it factors that tile; waves 1..7 share the rest
+            for (int idx = wave; idx < ntile; idx += (wave == 0 ? 1000 : 7)) {
                 int ii = 0;
                 while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
                 const int jj = idx - ii * (ii + 1) / 2;
                 const int i = p + 1 + ii, j = p + 1 + jj;
+                double *C = &sT[tix(i, j)];
+                const double *Xi = &sT[tix(i, p)], *Xj = &sT[tix(j, p)];
                 double4_t acc;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc[v] = sA[(16 * i + q + 4 * v) * LS + 16 * j + r];
+                for (int v = 0; v < 4; ++v) acc[v] = C[el(q + 4 * v, r)];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const double a = -sA[(16 * i + r) * LS + 16 * p + 4 * s + q];
-                    const double b = sA[(16 * j + r) * LS + 16 * p + 4 * s + q];
-                    acc = mfma(a, b, acc);
-                }
+                for (int s = 0; s < 4; ++s) acc = mfma(-Xi[el(r, 4 * s + q)], Xj[el(r, 4 * s + q)], acc);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) sA[(16 * i + q + 4 * v) * LS + 16 * j + r] = acc[v];
+                for (int v = 0; v < 4; ++v) if (i != j || r <= q + 4 * v) C[el(q + 4 * v, r)] = acc[v];
+            }
+            if (wave == 0 && p < 7) {
+                const int bad = diag_factor(&sT[tix(p + 1, p + 1)], &srd[16 * (p + 1)], lane);
+                if (bad >= 0 && lane == 0 && 16 * (p + 1) + bad < g.nvalid)
+                    atomicCAS(g.info, 0, g.info_base + (int)blockIdx.x * 128 + 16 * (p + 1) + bad + 1);
             }
             __syncthreads();
         }
-        // the trailing updates also touched the strict upper part of diagonal tiles; re-zero it
-        for (int e = tid; e < 8 * 256; e += 256) {
-            const int t = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
-            if (cc > rr) sA[(16 * t + rr) * LS + 16 * t + cc] = 0.0;
-        }
-        __syncthreads();
-    } else {
-        // inverse only: invert the 8 diagonal tiles of the given factor
-        for (int p = wave; p < 8; p += 4) diag_tile<false>(&sA[(16 * p) * LS + 16 * p], &sD[p * 16 * DS], lane);
-        __syncthreads();
-    }
-
-    // write L back (lower triangle only) and its log-diagonal sum
-    if (g.do_factor) {
-        for (int e = tid; e < 128 * 128; e += 256) {
+        // ---- L back to global (lower triangle only) and the log-diagonal sum ---------------------------
+        for (int e = tid; e < 128 * 128; e += 512) {
             const int row = e >> 7, col = e & 127;
-            if (col <= row) A[(long)row * g.lda + col] = sA[row * LS + col];
+            if (col <= row) A[(long)row * g.lda + col] = sT[tix(row >> 4, col >> 4) + el(row & 15, col & 15)];
         }
         if (g.logdet_part != nullptr) {
             double s = 0.0;
-            if (tid < g.nvalid) s = log(fabs(sA[tid * LS + tid]));
+            if (tid < g.nvalid) s = -log(srd[tid]);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0) slog[wave] = s;
             __syncthreads();
             if (tid == 0) g.logdet_part[blockIdx.x] = slog[0] + slog[1];
         }
-    }
-
-    // inv(L): block column j, block rows i = j+1..7, X_ij^T stored at tile (j,i)
-    for (int i = 1; i < 8; ++i) {
-        for (int j = wave; j < i; j += 4) {
-            double4_t t4 = {0.0, 0.0, 0.0, 0.0};
-            for (int k = j; k < i; ++k) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const double a = sA[(16 * i + r) * LS + 16 * k + 4 * s + q];              // L_ik[r][4s+q]
-                    const double b = (k == j) ? sD[j * 16 * DS + (4 * s + q) * DS + r]          // Dinv_j[4s+q][r]
-                                              : sA[(16 * j + r) * LS + 16 * k + 4 * s + q];     // X_kj[4s+q][r] (transposed store)
-                    t4 = mfma(a, b, t4);
-                }
-            }
-            double4_t x4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double a = -sD[i * 16 * DS + r * DS + 4 * s + q];                        // -Dinv_i[r][4s+q]
-                x4 = mfma(a, t4[s], x4);                                                       // T[4s+q][r] == acc register s
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) sA[(16 * j + r) * LS + 16 * i + q + 4 * v] = x4[v];    // X_ij[q+4v][r] -> transposed
-        }
+    } else {
+        if (tid < 128) srd[tid] = 1.0 / sT[tix(tid >> 4, tid >> 4) + el(tid & 15, tid & 15)];
         __syncthreads();
     }
 
-    // write inv(L) (dense, upper = 0)
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int row = e >> 7, col = e & 127;
-        const int tr = row >> 4, tc = col >> 4;
-        double v = 0.0;
-        if (tr == tc) v = sD[tr * 16 * DS + (row & 15) * DS + (col & 15)];
-        else if (tr > tc) v = sA[col * LS + row];
-        linv[(long)row * 128 + col] = v;
+    // ---- inverse of the 8 diagonal tiles: wave w inverts tile (w,w); its strictly-lower part goes,
+    //      transposed, into the tile's (unused) strict upper half, the diagonal is srd -------------------
+    double x[16];
+    {
+        const int c = lane & 15;
+        double a[16], rd[16];
+        const double *Tw = &sT[tix(wave, wave)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { a[k] = (k <= c) ? Tw[el(c, k)] : 0.0; rd[k] = srd[16 * wave + k]; }
+        InvRow<0>::step(a, rd, x, c);
+        if (lane < 16) {
+            double *Tm = &sT[tix(wave, wave)];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (i > c) Tm[el(c, i)] = x[i];      // Dinv[i][c] at [c][i]
+        }
+    }
+    __syncthreads();
+
+    // ---- block column `wave` of inv(L), kept in registers in MFMA B-operand layout -----------------------
+    {
+        const int j = wave;
+        double4_t xb[8];
+        // X_jj[4s+q][r]: lane (q, r) holds column r of inv(L_jj) in x[]; pick rows 4s+q
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double v0 = x[4 * s], v1 = x[4 * s + 1], v2 = x[4 * s + 2], v3 = x[4 * s + 3];
+            xb[0][s] = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
+        }
+#pragma unroll
+        for (int m = 1; m < 8; ++m) {
+            const int i = j + m;
+            if (i < 8) {
+                double4_t t4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < m; ++kk) {
+                    const double *Lik = &sT[tix(i, j + kk)];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) t4 = mfma(Lik[el(r, 4 * s + q)], xb[kk][s], t4);
+                }
+                const double *Dii = &sT[tix(i, i)];
+                double4_t x4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int cc = 4 * s + q;                       // inv(L_ii)[r][cc]
+                    double d = 0.0;
+                    if (r > cc) d = Dii[el(cc, r)];
+                    else if (r == cc) d = srd[16 * i + r];
+                    x4 = mfma(-d, t4[s], x4);
+                }
+                xb[m] = x4;
+            } else {
+                xb[m] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            }
+        }
+        // write block column j: zero tiles above the diagonal, X_jj, then X_ij
+        for (int i = 0; i < j; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) linv[(long)(16 * i + q + 4 * v) * 128 + 16 * j + r] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int i = j + m;
+            if (i < 8) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) linv[(long)(16 * i + q + 4 * v) * 128 + 16 * j + r] = xb[m][v];
+            }
+        }
     }
 }
 
@@ -219,7 +287,7 @@ int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *lo
     LeafArgs g;
     g.A = A; g.lda = lda; g.linv = linv; g.logdet_part = logdet_part; g.info = h->dinfo; g.info_base = info_base;
     g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid;
-    hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, h->stream, g);
+    hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -229,7 +297,7 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
     LeafArgs g;
     g.A = const_cast<double *>(L); g.lda = ldl; g.linv = linv; g.logdet_part = nullptr; g.info = h->dinfo; g.info_base = 0;
     g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128;
-    hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)nblk), dim3(256), 0, h->stream, g);
+    hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)nblk), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
 }
