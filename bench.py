@@ -157,7 +157,7 @@ def main():
             "cholesky_frac_of_fp64_mfma_peak": potrf_tflops / PEAK_FP64_MFMA_TFLOPS,
             "loglik_last": ll,
             "roofline": {
-                "kernel": "gemm_f64_kernel<0,0> (trailing SYRK, lower tiles)",
+                "kernel": "gemm_f64_kernel<0, 0, 1> (trailing update of the blocked Cholesky, lower tiles)",
                 "bound": "mfma", "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                 "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1.0),

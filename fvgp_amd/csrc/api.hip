@@ -72,7 +72,6 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "profile")) { h->profile = value ? 1 : 0; return 0; }
     if (!strcmp(key, "lookahead")) { h->lookahead = value ? 1 : 0; return 0; }
     if (!strcmp(key, "reserve_cus")) { h->reserve_cus = (int)value; return 0; }
-    if (!strcmp(key, "gemm_variant")) { h->gemm_variant = (int)value; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
     return -2;
 }
@@ -182,7 +181,7 @@ static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, i
     if (c1 <= c0 || np <= c0) return 0;
     GemmDesc s{};
     s.a_kmajor = 0; s.b_nmajor = 0; s.lower = 1; s.M = np - c0; s.N = c1 - c0; s.K = Jend - J0;
-    s.alpha = -1.0; s.beta = 1.0;
+    s.alpha = -1.0; s.beta = 1.0; s.role = 1;
     s.A = A + c0 * lda + J0; s.lda = lda;
     s.B = A + c0 * lda + J0; s.ldb = lda;
     s.C = A + c0 * lda + c0; s.ldc = lda;

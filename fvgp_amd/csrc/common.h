@@ -33,8 +33,7 @@ struct fvgp_handle {
     // options
     int64_t outer_block = 1024;
     int profile = 0;
-    int gemm_variant = 0;
-    int lookahead = 0;
+    int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel
     hipEvent_t ev_panel = nullptr, ev_cols = nullptr, ev_join = nullptr;
     hipStream_t bulk = nullptr;       // CU-masked stream for the trailing updates (look-ahead mode)
@@ -59,7 +58,9 @@ static inline int64_t pad128(int64_t n) { return (n + TILE - 1) / TILE * TILE; }
 
 // ---- launches implemented in the .hip units ------------------------------------------------
 struct GemmDesc {
-    int a_kmajor, b_nmajor, lower;
+    int a_kmajor, b_nmajor, lower;    // lower: 0 all tiles, 1 tile row >= tile col, 2 tile col <= tile row * lower_scale + lower_off
+    int lower_scale = 1, lower_off = 0;
+    int role = 0;                     // 1 = trailing update of the Cholesky (own kernel symbol for profilers)
     int64_t M, N, K;
     double alpha, beta;
     const double *A; int64_t lda;

@@ -31,7 +31,8 @@ struct GemmArgs {
     const double *A; const double *B; double *C;
     long lda, ldb, ldc;
     double alpha, beta;
-    int tiles_m, tiles_n, lower;
+    int tiles_m, tiles_n, lower;      // lower: 0 all tiles, 1 tj <= ti, 2 tj <= ti*ls + lo (row-sharded trailing update)
+    int ls, lo;
     long K;
     long kb0, kbi, kbj, ke0, kei, kej;
     long ntiles;
@@ -77,7 +78,9 @@ __host__ __device__ inline long xcd_remap(long b, long nwg, int tiles_n) {
     return full * per + (k >= 0 ? k : 0);
 }
 
-template <int AKM, int BNM, int PIPE, int ABL = 0>
+// ROLE only names the instantiation (0 generic, 1 trailing update of the Cholesky) so that profilers list
+// the kernel the metric lives in under its own symbol
+template <int AKM, int BNM, int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // 76 KB, a little more than the 72 KB of operand images: the look-ahead leaf kernel (73 KB) must fit
     // into the LDS range one retiring workgroup of this kernel frees
@@ -88,9 +91,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // round-robin over the XCDs so every XCD gets the same mix of full and diagonal (half-empty) ones.
     const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
     int ti, tj;
-    tile_of(t, g.tiles_m, g.tiles_n, g.lower, ti, tj);
+    tile_of(t, g.tiles_m, g.tiles_n, g.lower == 1, ti, tj);
     if (ti >= g.tiles_m || tj >= g.tiles_n) return;
-    if (g.lower && tj > ti) return;
+    if (g.lower == 1 && tj > ti) return;
+    if (g.lower == 2 && tj > ti * g.ls + g.lo) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -163,11 +167,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     __syncthreads();
 
-    if (!PIPE) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
-        if (more && !(ABL & 1)) {
+        if (more) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 ga[p] += astep; gb[p] += bstep;
@@ -180,83 +183,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             double a[4], bv[4];
-            if (ABL & 8) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a[i] = ra[i][0] + s; bv[i] = rb[i][1] + s; }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { a[i] = pa[fa[i] + s * SA]; bv[i] = pb[fb[i] + s * SB]; }
-            }
+            for (int i = 0; i < 4; ++i) { a[i] = pa[fa[i] + s * SA]; bv[i] = pb[fb[i] + s * SB]; }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (more && !(ABL & 2)) {
+        if (more) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 *reinterpret_cast<double2_t *>(&smem[cur ^ 1][0][sa[p]]) = ra[p];
                 *reinterpret_cast<double2_t *>(&smem[cur ^ 1][1][sb[p]]) = rb[p];
             }
         }
-        if (!(ABL & 4)) __syncthreads();
-    }
-    } else {
-    // software-pipelined K loop: the fragments of sub-step s+1 are read from LDS while the 16 MFMAs of
-    // sub-step s run; the register->LDS stores of the next K-step ride in the shadow of the last
-    // sub-step's MFMAs, so the only exposed latency per K-step is barrier + one fragment read.
-    double ca[4], cb[4];
-    if (nk > 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { ca[i] = smem[0][0][fa[i]]; cb[i] = smem[0][1][fb[i]]; }
-    }
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = (kt + 1 < nk);
-        if (more) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                ga[p] += astep; gb[p] += bstep;
-                ra[p] = *reinterpret_cast<const double2_t *>(ga[p]);
-                rb[p] = *reinterpret_cast<const double2_t *>(gb[p]);
-            }
-        }
-        const double *pa = &smem[cur][0][0];
-        const double *pb = &smem[cur][1][0];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            double na[4], nb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { na[i] = pa[fa[i] + (s + 1) * SA]; nb[i] = pb[fb[i] + (s + 1) * SB]; }
-            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMAs it hides under
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i], cb[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
-        }
-        // last sub-step: MFMAs with the LDS stores of the next K-step interleaved (2 MFMAs : 1 store)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i], cb[j], acc[i][j], 0, 0, 0);
-            if (more) {
-                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][0][sa[i]]) = ra[i];
-                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][1][sb[i]]) = rb[i];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
         __syncthreads();
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { ca[i] = smem[cur ^ 1][0][fa[i]]; cb[i] = smem[cur ^ 1][1][fb[i]]; }
-        }
-    }
     }
 
     // epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile.  The read-modify-write of C
@@ -375,22 +317,12 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     GemmArgs g;
     g.A = d.A; g.B = d.B; g.C = d.C; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
     g.alpha = d.alpha; g.beta = d.beta; g.K = d.K;
-    g.tiles_m = (int)(d.M / 128); g.tiles_n = (int)(d.N / 128); g.lower = d.lower;
+    g.tiles_m = (int)(d.M / 128); g.tiles_n = (int)(d.N / 128); g.lower = d.lower; g.ls = d.lower_scale; g.lo = d.lower_off;
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
-    g.ntiles = gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower);
+    g.ntiles = gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
     dim3 grid((unsigned)g.ntiles), block(256);
-#define GO(AK, BN) do { if (h->gemm_variant == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 1>), grid, block, 0, h->stream, g); \
+#define GO(AK, BN) do { if (d.role == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 1>), grid, block, 0, h->stream, g); \
                         else hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 0>), grid, block, 0, h->stream, g); } while (0)
-    if (h->gemm_variant >= 100 && !d.a_kmajor && !d.b_nmajor) {   // timing-only ablations of the K loop (results are wrong)
-        switch (h->gemm_variant - 100) {
-#define AB(X) case X: hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 0, X>), grid, block, 0, h->stream, g); break;
-            AB(1) AB(2) AB(3) AB(4) AB(7) AB(8) AB(11) AB(15) AB(12) AB(6)
-#undef AB
-            default: break;
-        }
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
     if (!d.a_kmajor && !d.b_nmajor) GO(0, 0);
     else if (!d.a_kmajor && d.b_nmajor) GO(0, 1);
     else if (d.a_kmajor && !d.b_nmajor) GO(1, 0);
