@@ -142,6 +142,12 @@ def main():
     H.set_option("profile", 0)
 
     if rank == 0:
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+        if os.path.exists(tfile) and n == 50000:
+            # HBM-side bytes per trailing-update launch from the committed rocprofv3 --pmc passes of this same
+            # command (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); not re-measured live
+            traffic = json.load(open(tfile)).get("bytes_per_launch")
         evals = args.steps * world
         ms_per_step = 1e3 * elapsed / args.steps
         syrk_tflops = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
@@ -159,7 +165,7 @@ def main():
             "roofline": {
                 "kernel": "gemm_f64_kernel<0, 0, 1> (trailing update of the blocked Cholesky, lower tiles)",
                 "bound": "mfma", "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                 "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1.0),
                 "algorithmic_flops_per_launch": prof["flops"] / max(prof["launches"], 1.0),
             },
