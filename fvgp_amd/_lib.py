@@ -27,7 +27,7 @@ SYMBOLS = [
     "fvgp_hip_potrf", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize",
-    "fvgp_hip_debug_tile_map",
+    "fvgp_hip_debug_tile_map", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_syrk_rowshard",
 ]
 
 
@@ -94,6 +94,9 @@ def lib():
     L.fvgp_hip_mfma_selftest.argtypes = [c_p, c_p, c_p, c_p]
     L.fvgp_hip_symmetrize.argtypes = [c_p, c_p, c_l, c_l]
     L.fvgp_hip_mfma_peak.argtypes = [c_p, c_p, c_i, c_i]
+    L.fvgp_hip_trsm_lower_t.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
+    L.fvgp_hip_panel_trsm.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
+    L.fvgp_hip_syrk_rowshard.argtypes = [c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i]
     L.fvgp_hip_debug_tile_map.argtypes = [c_i, c_i, c_i, P_i, P_i, c_l]
     L.fvgp_hip_debug_tile_map.restype = c_l
     for s in SYMBOLS:
@@ -186,6 +189,18 @@ class Handle:
     def trsm_lower(self, L, n, B, nrhs):
         _check(lib().fvgp_hip_trsm_lower(self._h, _ptr(L), int(n), L.stride(0), _ptr(B), int(nrhs), B.stride(0)),
                "fvgp_hip_trsm_lower")
+
+    def trsm_lower_t(self, L, n, B, nrhs):
+        _check(lib().fvgp_hip_trsm_lower_t(self._h, _ptr(L), int(n), L.stride(0), _ptr(B), int(nrhs), B.stride(0)),
+               "fvgp_hip_trsm_lower_t")
+
+    def panel_trsm(self, D, nd, P, rows):
+        _check(lib().fvgp_hip_panel_trsm(self._h, _ptr(D), int(nd), D.stride(0), _ptr(P), int(rows), P.stride(0)),
+               "fvgp_hip_panel_trsm")
+
+    def syrk_rowshard(self, M, N, K, A, B, C, scale, off):
+        _check(lib().fvgp_hip_syrk_rowshard(self._h, int(M), int(N), int(K), _ptr(A), A.stride(0), _ptr(B), B.stride(0),
+                                            _ptr(C), C.stride(0), int(scale), int(off)), "fvgp_hip_syrk_rowshard")
 
     def logdet(self, L, n):
         out = ctypes.c_double(0.0)

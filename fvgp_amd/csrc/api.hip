@@ -648,6 +648,63 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
     return 0;
 }
 
+int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
+                            const double *B, int64_t ldb, double *C, int64_t ldc, int scale, int off) {
+    if (!h) return -1;
+    if (!A) return -5;
+    if (!B) return -7;
+    if (!C) return -9;
+    if (scale < 1) return -11;
+    if (off < 0) return -12;
+    HIPCHK(hipSetDevice(h->device));
+    GemmDesc g{};
+    g.a_kmajor = 0; g.b_nmajor = 0; g.lower = 2; g.lower_scale = scale; g.lower_off = off; g.role = 1;
+    g.M = M; g.N = N; g.K = K; g.alpha = -1.0; g.beta = 1.0;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    return launch_gemm(h, g);
+}
+
+int fvgp_hip_panel_trsm(fvgp_handle *h, const double *D, int64_t nd, int64_t ldd, double *P, int64_t rows, int64_t ldp) {
+    if (!h) return -1;
+    int rc = check_square(D, nd, ldd, 2, 3, 4);
+    if (rc) return rc;
+    if (nd % TILE) { fvgp_set_error("panel_trsm: the diagonal block must be a multiple of 128"); return -3; }
+    if (!P) return -5;
+    if (rows < 0 || rows % TILE) return -6;
+    if (ldp < nd || (ldp & 1) || ((uintptr_t)P & 15)) return -7;
+    if (rows == 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    rc = ensure_linv(h, D, nd, ldd); if (rc) return rc;
+    // X = P * L^-T by 128-column blocks:  X_k = (P_k - sum_{j<k} X_j L_kj^T) * inv(L_kk)^T
+    for (int64_t k0 = 0; k0 < nd; k0 += TILE) {
+        if (k0 > 0) {
+            GemmDesc u{};
+            u.a_kmajor = 0; u.b_nmajor = 0; u.lower = 0; u.M = rows; u.N = TILE; u.K = k0; u.alpha = -1.0; u.beta = 1.0;
+            u.A = P; u.lda = ldp; u.B = D + k0 * ldd; u.ldb = ldd; u.C = P + k0; u.ldc = ldp;
+            rc = launch_gemm(h, u); if (rc) return rc;
+        }
+        GemmDesc t{};
+        t.a_kmajor = 0; t.b_nmajor = 0; t.lower = 0; t.M = rows; t.N = TILE; t.K = TILE; t.alpha = 1.0; t.beta = 0.0;
+        t.A = P + k0; t.lda = ldp; t.B = h->linv + (k0 / TILE) * LEAF_DOUBLES; t.ldb = TILE; t.C = P + k0; t.ldc = ldp;
+        rc = launch_gemm(h, t); if (rc) return rc;
+    }
+    return 0;
+}
+
+int fvgp_hip_trsm_lower_t(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb) {
+    if (!h) return -1;
+    int rc = check_square(L, n, ldl, 2, 3, 4);
+    if (rc) return rc;
+    if (!B) return -5;
+    if (nrhs <= 0) return -6;
+    if (ldb < nrhs) return -7;
+    if (nrhs % 128 || (ldb & 1) || ((uintptr_t)B & 15)) { fvgp_set_error("trsm_lower_t needs nrhs % 128 == 0, even ldb, 16-byte aligned B"); return -6; }
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t np = pad128(n);
+    if (np > n) { rc = launch_copy_cols(h, B, ldb, B + n * ldb, ldb, 0, 0, np - n, nrhs); if (rc) return rc; }
+    return trsm_bwd_gemm(h, L, n, ldl, B, nrhs, ldb);
+}
+
 int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t M, int64_t N, int64_t K,
                   double alpha, const double *A, int64_t lda, const double *B, int64_t ldb,
                   double beta, double *C, int64_t ldc) {

@@ -93,6 +93,21 @@ int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *wo
 /* forward half only: B <- L^-1 B (used by the posterior covariance, gp_posterior.py:120-136) */
 int fvgp_hip_trsm_lower(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb);
 
+/* backward half only: B <- L^-T B, nrhs a multiple of 128 (GEMM path) */
+int fvgp_hip_trsm_lower_t(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb);
+
+/* ---- row-sharded (multi-GPU) building blocks: the gp2Scale partitioning pattern -----------
+ * (fvgp/gp2Scale_covariance.py:381-396, gp_prior.py:319-322) applied to a DENSE factorisation:
+ * 128-row blocks of K+V are dealt block-cyclically to the ranks, x is replicated.
+ * panel_trsm   : P (rows, nd) <- P * L_D^-T with D the factored nd x nd diagonal block (nd % 128 == 0)
+ * syrk_rowshard: C[ti][tj] -= A[ti] B[tj]^T for the 128x128 tiles with tj <= ti*scale + off, i.e. the
+ *                lower-triangular part of the trailing update restricted to this rank's block rows
+ *                (scale = number of ranks, off = global offset of the first local block row);
+ *                A (M,K), B (N,K), C (M,N) row-major. */
+int fvgp_hip_panel_trsm(fvgp_handle *h, const double *D, int64_t nd, int64_t ldd, double *P, int64_t rows, int64_t ldp);
+int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
+                            const double *B, int64_t ldb, double *C, int64_t ldc, int scale, int off);
+
 /* ---- fused evaluations ----------------------------------------------------------------
  * loglik: GPMarginalLikelihood.log_likelihood(theta)  gp_marginal_likelihood.py:137-179
  *         = kernel -> addKV -> potrf -> potrs -> logdet -> scalar, nothing leaves HBM.

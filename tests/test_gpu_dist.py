@@ -1,0 +1,69 @@
+"""Row-sharded path with the real HIP ops: one rank (no process group) and two ranks sharing the one GPU of
+the test box over gloo (RCCL refuses two ranks on one device; the collectives' semantics are the same)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, synth
+from oracle import fvgp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from conftest import synth
+from fvgp_amd.dist import ShardedGP
+torch.cuda.set_device(0)
+dist.init_process_group(backend="gloo")
+n, d = {n}, 3
+x, y = synth(n, d)
+gp = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel={panel})
+out = [gp.log_likelihood(np.array([1.0, 0.3, 0.3, 0.3]) * (1 + 0.02 * t)) for t in range(2)]
+if dist.get_rank() == 0:
+    print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def test_single_rank_hip_ops_match_fused_path():
+    from fvgp_amd import _lib
+    from fvgp_amd.dist import ShardedGP
+    from fvgp_amd.device import default_handle
+    n = 3000
+    x, y = synth(n, 3)
+    nv = np.full(n, 0.01)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    gp = ShardedGP(x, y, nv, kernel="rbf_ard", panel=512, rank=0, world=1)
+    ll, logdet, quad = gp.log_likelihood(theta)
+    H = default_handle()
+    npad = _lib.pad128(n)
+    KV = H.empty(npad, npad); alpha = H.empty(npad, 1)
+    ref = H.loglik(0, H.to_device(x), theta, H.to_device(nv), H.to_device((y - y.mean()).reshape(n, 1)), KV, alpha)
+    np.testing.assert_allclose(ll, ref[0], rtol=1e-11)
+    np.testing.assert_allclose(logdet, ref[1], rtol=1e-11)
+    oracle, _ = orc.log_likelihood_once(x, y, nv, theta, "rbf_ard")
+    np.testing.assert_allclose(ll, oracle, rtol=1e-10)
+
+
+@pytest.mark.parametrize("world,n,panel", [(2, 2000, 256), (3, 1700, 384)])
+def test_ranks_sharing_one_gpu_over_gloo(tmp_path, world, n, panel):
+    f = tmp_path / "worker.py"
+    f.write_text(WORKER.format(root=ROOT, n=n, panel=panel))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(f)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    import json
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    x, y = synth(n, 3)
+    for t, (ll, logdet, quad) in enumerate(out):
+        ref, _ = orc.log_likelihood_once(x, y, np.full(n, 0.01), np.array([1.0, 0.3, 0.3, 0.3]) * (1 + 0.02 * t), "rbf_ard")
+        np.testing.assert_allclose(ll, ref, rtol=1e-10)
