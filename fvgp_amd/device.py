@@ -7,8 +7,8 @@ _default = None
 
 
 def local_device():
-    """cuda index for this process: LOCAL_RANK under torchrun, else 0."""
-    return int(os.environ.get("LOCAL_RANK", "0"))
+    """cuda index for this process: FVGP_DEVICE if set, else LOCAL_RANK under torchrun, else 0."""
+    return int(os.environ.get("FVGP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 
 
 def default_handle():

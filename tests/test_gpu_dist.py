@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 WORKER = r'''
 import os, sys, json
+os.environ["FVGP_DEVICE"] = "0"          # every rank on the one GPU of the test box
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
 import numpy as np, torch, torch.distributed as dist
 from conftest import synth
