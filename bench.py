@@ -117,7 +117,6 @@ def main():
     ap.add_argument("--d", type=int, default=3)
     ap.add_argument("--outer-block", type=int, default=0, help="K of the trailing SYRK (0 = library default)")
     ap.add_argument("--lookahead", type=int, default=-1, help="1/0: factor the next panel on a side stream (-1 = library default)")
-    ap.add_argument("--reserve-cus", type=int, default=-1)
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="N>1: independent replicas (one theta stream per GPU, default) or ONE evaluation row-sharded "
                          "over the GPUs (block-cyclic rows, RCCL all-gather of panel factors; strong scaling)")
@@ -149,8 +148,6 @@ def main():
     H = _lib.Handle(local)
     if args.outer_block:
         H.set_option("outer_block", args.outer_block)
-    if args.reserve_cus >= 0:
-        H.set_option("reserve_cus", args.reserve_cus)
     if args.lookahead >= 0:
         H.set_option("lookahead", args.lookahead)
     npad = _lib.pad128(n)

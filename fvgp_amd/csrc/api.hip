@@ -43,8 +43,6 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
     if (h->ev_cols) (void)hipEventDestroy(h->ev_cols);
     if (h->side) (void)hipStreamDestroy(h->side);
-    if (h->bulk) (void)hipStreamDestroy(h->bulk);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->linv) (void)hipFree(h->linv);
     if (h->logdet_parts) (void)hipFree(h->logdet_parts);
     if (h->red) (void)hipFree(h->red);
@@ -71,7 +69,11 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     }
     if (!strcmp(key, "profile")) { h->profile = value ? 1 : 0; return 0; }
     if (!strcmp(key, "lookahead")) { h->lookahead = value ? 1 : 0; return 0; }
-    if (!strcmp(key, "reserve_cus")) { h->reserve_cus = (int)value; return 0; }
+    if (!strcmp(key, "outer_block_big")) {
+        if (value != 0 && (value < 128 || value % 128)) { fvgp_set_error("outer_block_big must be 0 or a multiple of 128"); return -3; }
+        h->outer_block_big = value; return 0;
+    }
+    if (!strcmp(key, "big_threshold")) { h->big_threshold = value; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
     return -2;
 }
@@ -231,12 +233,22 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
         return 0;
     };
 
-    const bool la = h->lookahead && np > 2 * NB;
+    // panel boundaries: width NB, or the wider `outer_block_big` while more than `big_threshold` rows remain
+    // (a wider panel halves the C read-modify-write passes of the trailing update; its longer factorisation
+    // chain only stays hidden behind the update while the trailing matrix is large)
+    std::vector<int64_t> bnd;
+    for (int64_t J0 = 0; J0 < np;) {
+        bnd.push_back(J0);
+        const int64_t w = (h->outer_block_big > NB && np - J0 > h->big_threshold) ? h->outer_block_big : NB;
+        J0 = (J0 + w < np) ? J0 + w : np;
+    }
+    bnd.push_back(np);
+    const size_t npan = bnd.size() - 1;
+    const bool la = h->lookahead && npan > 2;
     if (!la) {
-        for (int64_t J0 = 0; J0 < np; J0 += NB) {
-            const int64_t Jend = (J0 + NB < np) ? J0 + NB : np;
-            rc = panel_factor(h, A, n, np, lda, J0, Jend); if (rc) return rc;
-            if (np > Jend) { rc = timed_update(J0, Jend, Jend, np); if (rc) return rc; }
+        for (size_t J = 0; J < npan; ++J) {
+            rc = panel_factor(h, A, n, np, lda, bnd[J], bnd[J + 1]); if (rc) return rc;
+            if (np > bnd[J + 1]) { rc = timed_update(bnd[J], bnd[J + 1], bnd[J + 1], np); if (rc) return rc; }
         }
     } else {
         if (!h->side) {
@@ -245,29 +257,11 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
             HIPCHK(hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&h->ev_cols, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-            if (h->reserve_cus > 0) {
-                // trailing updates run on a stream whose CU mask leaves a few CUs free, so the
-                // single-workgroup leaf of the look-ahead panel (151 KB LDS) always finds an empty CU
-                uint32_t mask[8];
-                for (int i = 0; i < 8; ++i) mask[i] = 0xFFFFFFFFu;
-                for (int i = 0; i < h->reserve_cus && i < 64; ++i) mask[(i * 37 % 256) / 32] &= ~(1u << ((i * 37 % 256) % 32));
-                if (hipExtStreamCreateWithCUMask(&h->bulk, 8, mask) != hipSuccess) { (void)hipGetLastError(); h->bulk = nullptr; }
-            }
         }
-        hipStream_t userS = h->stream;
-        hipStream_t mainS = h->bulk ? h->bulk : h->stream, sideS = h->side;
-        if (h->bulk) {
-            HIPCHK(hipEventRecord(h->ev_join, userS));
-            HIPCHK(hipStreamWaitEvent(mainS, h->ev_join, 0));
-            h->stream = mainS;
-        }
-        // panel 0 on the main stream
-        rc = panel_factor(h, A, n, np, lda, 0, NB < np ? NB : np); if (rc) return rc;
-        for (int64_t J0 = 0; J0 < np; J0 += NB) {
-            const int64_t Jend = (J0 + NB < np) ? J0 + NB : np;
-            if (np <= Jend) break;
-            const int64_t Nend = (Jend + NB < np) ? Jend + NB : np;      // next panel = [Jend, Nend)
+        hipStream_t mainS = h->stream, sideS = h->side;
+        rc = panel_factor(h, A, n, np, lda, bnd[0], bnd[1]); if (rc) return rc;      // panel 0 on the main stream
+        for (size_t J = 0; J + 1 < npan; ++J) {
+            const int64_t J0 = bnd[J], Jend = bnd[J + 1], Nend = bnd[J + 2];           // next panel = [Jend, Nend)
             // (1) main: bring the next panel's block columns up to date with panel J
             rc = timed_update(J0, Jend, Jend, Nend); if (rc) return rc;
             HIPCHK(hipEventRecord(h->ev_cols, mainS));
@@ -282,11 +276,6 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             if (np > Nend) { rc = timed_update(J0, Jend, Nend, np); if (rc) return rc; }
             // the next iteration's updates use panel J+1: wait for its factorisation
             HIPCHK(hipStreamWaitEvent(mainS, h->ev_panel, 0));
-        }
-        if (h->bulk) {
-            HIPCHK(hipEventRecord(h->ev_join, mainS));
-            h->stream = userS;
-            HIPCHK(hipStreamWaitEvent(userS, h->ev_join, 0));
         }
     }
     if (h->profile) { rc = get_event(&e_end); if (rc) return rc; HIPCHK(hipEventRecord(e_end, h->stream)); }

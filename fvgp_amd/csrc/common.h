@@ -32,12 +32,11 @@ struct fvgp_handle {
     size_t vec_cap = 0;
     // options
     int64_t outer_block = 1024;
+    int64_t outer_block_big = 0, big_threshold = 24576;   // optional wider panels while the trailing matrix is large
     int profile = 0;
     int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel
-    hipEvent_t ev_panel = nullptr, ev_cols = nullptr, ev_join = nullptr;
-    hipStream_t bulk = nullptr;       // CU-masked stream for the trailing updates (look-ahead mode)
-    int reserve_cus = 0;
+    hipEvent_t ev_panel = nullptr, ev_cols = nullptr;
     // profile of the last potrf
     std::vector<hipEvent_t> ev;
     std::vector<double> ev_flops;

@@ -61,8 +61,10 @@ int64_t fvgp_hip_padded_dim(int64_t n);
 int fvgp_hip_create(fvgp_handle **out, int device, void *stream);
 int fvgp_hip_destroy(fvgp_handle *h);
 int fvgp_hip_sync(fvgp_handle *h);
-/* keys: "outer_block" (K of the trailing SYRK, multiple of 128), "profile" (0/1: time
- * the trailing-update launches with HIP events, read back by fvgp_hip_get_profile) */
+/* keys: "outer_block" (panel width = K of the trailing update, multiple of 128; default 1024),
+ *       "outer_block_big" / "big_threshold" (optional wider panels while more rows than the threshold remain),
+ *       "lookahead" (0/1: factor the next panel on a high-priority side stream under the trailing update),
+ *       "profile" (0/1: time the trailing-update launches with HIP events -> fvgp_hip_get_profile) */
 int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value);
 /* out[0] = number of trailing-update launches of the last potrf, out[1] = their summed
  * duration in ms, out[2] = their summed algorithmic flops, out[3] = whole-potrf ms */
