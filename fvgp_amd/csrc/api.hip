@@ -453,29 +453,54 @@ int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *wo
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
     const int64_t np = pad128(n);
+    const int64_t NB = h->outer_block;
     rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
-    // W = inv(L) into work, block row by block row:
-    //   W[i][0:i] = -inv(L_ii) * ( L[i][0:i] * W[0:i][0:i] ),  W[i][i] = inv(L_ii)
-    for (int64_t i0 = 0; i0 < np; i0 += TILE) {
-        const double *li = h->linv + (i0 / TILE) * LEAF_DOUBLES;
-        rc = launch_copy_cols(h, li, TILE, work + i0 * ldw + i0, ldw, TILE, TILE, TILE, TILE); if (rc) return rc;
-        if (i0 == 0) continue;
-        GemmDesc a{};   // T = L[i][0:i] * W[0:i][0:i]   (W lower-triangular: k starts at the column tile)
-        a.a_kmajor = 0; a.b_nmajor = 1; a.lower = 0; a.M = TILE; a.N = i0; a.K = i0; a.alpha = 1.0; a.beta = 0.0;
-        a.A = L + i0 * ldl; a.lda = ldl; a.B = work; a.ldb = ldw; a.C = work + i0 * ldw; a.ldc = ldw;
-        a.kb0 = 0; a.kbi = 0; a.kbj = TILE; a.ke0 = -1;
-        rc = launch_gemm(h, a); if (rc) return rc;
-        GemmDesc b{};   // W[i][0:i] = -inv(L_ii) * T  (in place)
-        b.a_kmajor = 0; b.b_nmajor = 1; b.lower = 0; b.M = TILE; b.N = i0; b.K = TILE; b.alpha = -1.0; b.beta = 0.0;
-        b.A = li; b.lda = TILE; b.B = work + i0 * ldw; b.ldb = ldw; b.C = work + i0 * ldw; b.ldc = ldw;
-        rc = launch_gemm(h, b); if (rc) return rc;
+    // ---- W = inv(L), written over L panel by panel from the bottom-right corner (dtrtri, lower):
+    //        W_JJ  = inv(L_JJ)                               (block rows of 128 from the leaf inverses)
+    //        W_2J  = -W_22 * (L_2J * W_JJ)                   (two large GEMMs per panel)
+    //      `work` holds W_JJ and the intermediate L_2J * W_JJ.
+    const int64_t npan = (np + NB - 1) / NB;
+    for (int64_t J = npan - 1; J >= 0; --J) {
+        const int64_t J0 = J * NB, Jend = (J0 + NB < np) ? J0 + NB : np, w = Jend - J0;
+        double *Wjj = work + J0 * ldw + J0;
+        const double *Ljj = L + J0 * ldl + J0;
+        for (int64_t i0 = 0; i0 < w; i0 += TILE) {
+            const double *li = h->linv + ((J0 + i0) / TILE) * LEAF_DOUBLES;
+            rc = launch_copy_cols(h, li, TILE, Wjj + i0 * ldw + i0, ldw, TILE, TILE, TILE, TILE); if (rc) return rc;
+            if (i0 == 0) continue;
+            GemmDesc a{};   // T = L_JJ[i][0:i] * W_JJ[0:i][0:i]   (W lower-triangular: k starts at the column tile)
+            a.a_kmajor = 0; a.b_nmajor = 1; a.lower = 0; a.M = TILE; a.N = i0; a.K = i0; a.alpha = 1.0; a.beta = 0.0;
+            a.A = Ljj + i0 * ldl; a.lda = ldl; a.B = Wjj; a.ldb = ldw; a.C = Wjj + i0 * ldw; a.ldc = ldw;
+            a.kb0 = 0; a.kbi = 0; a.kbj = TILE; a.ke0 = -1;
+            rc = launch_gemm(h, a); if (rc) return rc;
+            GemmDesc b{};   // W_JJ[i][0:i] = -inv(L_ii) * T  (in place: each tile reads only its own columns)
+            b.a_kmajor = 0; b.b_nmajor = 1; b.lower = 0; b.M = TILE; b.N = i0; b.K = TILE; b.alpha = -1.0; b.beta = 0.0;
+            b.A = li; b.lda = TILE; b.B = Wjj + i0 * ldw; b.ldb = ldw; b.C = Wjj + i0 * ldw; b.ldc = ldw;
+            rc = launch_gemm(h, b); if (rc) return rc;
+        }
+        const int64_t R = np - Jend;
+        if (R > 0) {
+            GemmDesc t{};   // T = L_2J * W_JJ -> work   (W_JJ lower: k >= column tile)
+            t.a_kmajor = 0; t.b_nmajor = 1; t.lower = 0; t.M = R; t.N = w; t.K = w; t.alpha = 1.0; t.beta = 0.0;
+            t.A = L + Jend * ldl + J0; t.lda = ldl; t.B = Wjj; t.ldb = ldw; t.C = work + Jend * ldw + J0; t.ldc = ldw;
+            t.kb0 = 0; t.kbi = 0; t.kbj = TILE; t.ke0 = -1;
+            rc = launch_gemm(h, t); if (rc) return rc;
+            GemmDesc u{};   // W_2J = -W_22 * T -> over L_2J   (W_22 lower: k <= row tile)
+            u.a_kmajor = 0; u.b_nmajor = 1; u.lower = 0; u.M = R; u.N = w; u.K = R; u.alpha = -1.0; u.beta = 0.0;
+            u.A = L + Jend * ldl + Jend; u.lda = ldl; u.B = work + Jend * ldw + J0; u.ldb = ldw; u.C = L + Jend * ldl + J0; u.ldc = ldl;
+            u.kb0 = 0; u.ke0 = TILE; u.kei = TILE; u.kej = 0;
+            rc = launch_gemm(h, u); if (rc) return rc;
+        }
+        // W_JJ over L_JJ (its 128-tiles above the block diagonal are never read)
+        rc = launch_copy_lower_tiles(h, Wjj, ldw, L + J0 * ldl + J0, ldl, w); if (rc) return rc;
     }
-    // KV^-1 = W^T W, lower tiles, k >= row tile
+    // ---- KV^-1 = W^T W, lower tiles, k >= row tile; into work, then back over L
     GemmDesc s{};
     s.a_kmajor = 1; s.b_nmajor = 1; s.lower = 1; s.M = np; s.N = np; s.K = np; s.alpha = 1.0; s.beta = 0.0;
-    s.A = work; s.lda = ldw; s.B = work; s.ldb = ldw; s.C = L; s.ldc = ldl;
+    s.A = L; s.lda = ldl; s.B = L; s.ldb = ldl; s.C = work; s.ldc = ldw;
     s.kb0 = 0; s.kbi = TILE; s.kbj = 0; s.ke0 = -1;
     rc = launch_gemm(h, s); if (rc) return rc;
+    rc = launch_copy_lower_tiles(h, work, ldw, L, ldl, np); if (rc) return rc;
     h->linv_L = nullptr;   // L is gone
     return 0;
 }

@@ -214,13 +214,15 @@ __global__ void colsumsq_kernel(const double *V, long rows, long ldv, long P, do
     if (ty == 0 && p < P) { double t = 0.0; for (int k = 0; k < 8; ++k) t += sp[k][tx]; out[p] = base - t; }
 }
 
-// zero the 128x128 tiles strictly above the block diagonal (POTRI needs a clean upper half)
-__global__ void zero_upper_tiles_kernel(double *A, long np, long lda) {
+// copy the 128x128 tiles on and below the block diagonal (np a multiple of 128)
+__global__ void copy_lower_tiles_kernel(const double *src, long lds, double *dst, long ldd) {
     const int tj = blockIdx.x, ti = blockIdx.y;
-    if (tj <= ti) return;
+    if (tj > ti) return;
     for (int e = threadIdx.x; e < 128 * 64; e += blockDim.x) {
         const int rr = e >> 6, c2 = (e & 63) * 2;
-        *reinterpret_cast<double2_t *>(A + ((long)ti * 128 + rr) * lda + (long)tj * 128 + c2) = (double2_t){0.0, 0.0};
+        const long off_s = ((long)ti * 128 + rr) * lds + (long)tj * 128 + c2;
+        const long off_d = ((long)ti * 128 + rr) * ldd + (long)tj * 128 + c2;
+        *reinterpret_cast<double2_t *>(dst + off_d) = *reinterpret_cast<const double2_t *>(src + off_s);
     }
 }
 
@@ -389,9 +391,10 @@ int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, 
     return 0;
 }
 
-int launch_zero_upper_tiles(fvgp_handle *h, double *A, int64_t np, int64_t lda) {
+int launch_copy_lower_tiles(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t np) {
     unsigned nb = (unsigned)(np / 128);
-    hipLaunchKernelGGL(zero_upper_tiles_kernel, dim3(nb, nb), dim3(256), 0, h->stream, A, (long)np, (long)lda);
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL(copy_lower_tiles_kernel, dim3(nb, nb), dim3(256), 0, h->stream, src, (long)lds, dst, (long)ldd);
     HIPCHK(hipGetLastError());
     return 0;
 }
