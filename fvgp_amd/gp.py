@@ -231,24 +231,89 @@ class GP:
         return self._hps
 
     def update_gp_data(self, x_new, y_new, noise_variances_new=None, append=True, rank_n_update=None):
-        """fvgp/gp.py:689-779.  The factor is rebuilt from scratch on the device (one potrf);
-        the reference's rank-n bordering update is a 'next' row."""
+        """fvgp/gp.py:689-779.  append=True extends the data; with rank_n_update (default = append) the factor is
+        extended by bordering on the device -- v = L^-1 k(x_old, x_new), L22 = chol(K22 + V22 - v^T v)
+        (cholesky_update_rank_n, gp_lin_alg.py:1310-1477; GPkv.update_KV, gp_kv.py:462-476) -- O(n^2 m) instead of
+        the O(n^3) refactorisation; KVinvY and log|KV| are then refreshed from the new factor (gp_kv.py:404-423)."""
         assert isinstance(x_new, np.ndarray) and isinstance(y_new, np.ndarray), "wrong format in new data"
         if np.ndim(y_new) == 1:
             y_new = y_new.reshape(len(y_new), 1)
-        if append:
-            x = np.vstack([self.x_data, x_new])
-            y = np.vstack([self.y_data, y_new])
-            if self.noise_variances is not None:
-                if noise_variances_new is None:
-                    raise Exception("Please provide noise_variances in the data update.")
-                nv = np.concatenate([self.noise_variances, noise_variances_new])
-            else:
-                nv = None
+        if rank_n_update is None:
+            rank_n_update = append
+        if not append:
+            self._set_data(x_new, y_new, noise_variances_new)
+            self.set_hyperparameters(self._hps)
+            return
+        assert len(x_new) == len(y_new), "x_new and y_new do not have the same lengths."
+        x = np.vstack([self.x_data, x_new])
+        y = np.vstack([self.y_data, y_new])
+        if self.noise_variances is not None:
+            if noise_variances_new is None:
+                raise Exception("Please provide noise_variances in the data update.")
+            nv = np.concatenate([self.noise_variances, noise_variances_new])
         else:
-            x, y, nv = x_new, y_new, noise_variances_new
-        self._set_data(x, y, nv)
-        self.set_hyperparameters(self._hps)
+            nv = None
+        n_old = self.point_number
+        if not (rank_n_update and self._native is not None and len(x_new) > 0):
+            self._set_data(x, y, nv)
+            self.set_hyperparameters(self._hps)
+            return
+        self._append_factor(x, y, nv, n_old)
+
+    def _append_factor(self, x, y, nv, n_old):
+        H, hps, kid = self._H, self._hps, self._native.kernel_id
+        L_old, np_old = self._L, self._np
+        n, m = len(x), len(x) - n_old
+        self.x_data = np.ascontiguousarray(x, dtype=np.float64)
+        self.y_data = np.ascontiguousarray(y, dtype=np.float64)
+        self.noise_variances = nv
+        self.point_number = n
+        V = self._noise(self.x_data, hps)
+        mean = self._mean(self.x_data, hps)
+        x_old_dev = self._x_dev
+        x_new_dev = H.to_device(self.x_data[n_old:])
+        mp, np_new = _lib.pad128(m), _lib.pad128(n)
+        # v = L^-1 k(x_old, x_new)
+        B = H.zeros(np_old, mp)
+        H.kmat(kid, x_old_dev, x_new_dev, hps, B, pad=_lib.PAD_ZERO)
+        H.trsm_lower(L_old, n_old, B, mp)
+        # Schur complement of the new block and its factor
+        S = H.zeros(mp, mp)
+        H.kmat(kid, x_new_dev, x_new_dev, hps, S, vdiag=H.to_device(V[n_old:]), uplo=_lib.LOWER, pad=_lib.PAD_IDENTITY)
+        H.gemm(1, 1, 0, mp, mp, np_old, -1.0, B, B, 1.0, S)
+        info = H.potrf(S, m)
+        if info != 0:
+            raise NonPositiveDefiniteError(
+                "Cholesky rank-n update failed: the Schur complement of the appended block is not positive definite "
+                f"(leading minor {info}). This usually indicates the new data rows are linearly dependent on old rows "
+                "or the kernel is not PD on the augmented set.")
+        # assemble the bordered factor [[L, 0], [v^T, L22]] in a buffer of the new padded size
+        Lnew = H.zeros(np_new, np_new)
+        Lnew[:n_old, :n_old] = L_old[:n_old, :n_old]
+        Lnew[n_old:n, :n_old] = B[:n_old, :m].T
+        Lnew[n_old:n, n_old:n] = S[:m, :m]
+        if np_new > n:
+            Lnew[n:, n:].fill_diagonal_(1.0)
+        del B, S
+        self._np, self._L = np_new, Lnew
+        self._x_dev = H.to_device(self.x_data)
+        ncol = self.y_data.shape[1]
+        ymean = self.y_data - mean[:, None]
+        self._alpha = H.zeros(np_new, ncol)
+        self._alpha[:n] = H.to_device(ymean)
+        if ncol <= _lib.MAX_RHS_VEC:
+            H.potrs(Lnew, n, self._alpha, ncol)
+        else:
+            rhs = H.zeros(np_new, _lib.pad128(ncol))
+            rhs[:n, :ncol] = self._alpha[:n]
+            H.potrs(Lnew, n, rhs, _lib.pad128(ncol))
+            self._alpha[:n] = rhs[:n, :ncol]
+        self._logdet = H.logdet(Lnew, n)
+        quad = float((H.to_device(ymean) * self._alpha[:n]).sum().item()) / ncol
+        self._loglik = -0.5 * (quad + self._logdet + n * np.log(2.0 * np.pi))
+        self.m, self.V = mean, V
+        self._K_host = None
+        self._work = self._work2 = self._alpha_work = None
 
     @property
     def K(self):

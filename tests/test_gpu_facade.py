@@ -181,6 +181,33 @@ def test_pickle_roundtrip_and_update():
     np.testing.assert_allclose(a.log_likelihood(), fx["logliks"][2], rtol=1e-10)
 
 
+def test_rank_n_append_equals_refactorisation():
+    """update_gp_data(append=True): bordering update of the device factor (gp_lin_alg.py:1310-1477) against a
+    from-scratch factorisation and the reference vectors; unaligned sizes on both sides of the 128 blocks."""
+    import fvgp_amd
+    fx = load_golden("G2_rbf_n512_d3.npz")
+    x, y, nv, th = fx["x"], fx["y"], fx["noise_variances"], fx["theta"]
+    for n0 in (475, 384, 130):
+        gp = fvgp_amd.GP(x[:n0], y[:n0], init_hyperparameters=th, noise_variances=nv[:n0], kernel_function="rbf_ard")
+        gp.update_gp_data(x[n0:500], y[n0:500], noise_variances_new=nv[n0:500])          # append, rank-n
+        gp.update_gp_data(x[500:], y[500:], noise_variances_new=nv[500:])                # a second, small append
+        assert gp.point_number == 512
+        np.testing.assert_allclose(gp.log_likelihood(), fx["loglik"], rtol=1e-10)
+        np.testing.assert_allclose(np.diag(gp.Chol_factor), fx["L_diag"], rtol=1e-10)
+        assert np.max(np.abs(gp.KVinvY - fx["KVinvY"])) <= 1e-8 * np.max(np.abs(fx["KVinvY"]))
+        np.testing.assert_allclose(gp.posterior_mean(fx["x_pred"])["m(x)"], fx["pm"], rtol=1e-8, atol=1e-10)
+        assert np.max(np.abs(gp.posterior_covariance(fx["x_pred"])["S"] - fx["pS"])) <= 1e-10
+        np.testing.assert_allclose(gp.log_likelihood(fx["thetas"][0]), fx["logliks"][0], rtol=1e-10)
+    full = fvgp_amd.GP(x[:300], y[:300], init_hyperparameters=th, noise_variances=nv[:300], kernel_function="rbf_ard")
+    full.update_gp_data(x[300:], y[300:], noise_variances_new=nv[300:], rank_n_update=False)
+    np.testing.assert_allclose(full.log_likelihood(), fx["loglik"], rtol=1e-10)
+    # an appended block whose Schur complement is not positive definite (negative "noise" on the new rows)
+    bad = fvgp_amd.GP(x[:200], y[:200], init_hyperparameters=th, kernel_function="rbf_ard",
+                      noise_function=lambda xx, h: np.where(xx[:, 0] > 2.0, -1.5, 1e-2))
+    with pytest.raises(fvgp_amd.NonPositiveDefiniteError):
+        bad.update_gp_data(x[:5] + 3.0, y[:5])
+
+
 def test_train_methods_improve_the_likelihood():
     """GP.train (gp.py:781) with the Dask-free methods; every objective call is a device evaluation."""
     import fvgp_amd
