@@ -68,8 +68,10 @@ class GP:
         if gp2Scale:
             raise NotImplementedError("gp2Scale (sparse, Dask-distributed) is outside this engine's scope; "
                                       "the dense path scales by sharding over GPUs (fvgp_amd.dist).")
-        if linalg_mode not in (None, "Chol"):
-            raise NotImplementedError("only the dense Cholesky mode ('Chol') runs natively")
+        if linalg_mode not in (None, "Chol", "CholInv"):
+            raise NotImplementedError("only the dense Cholesky modes ('Chol', 'CholInv') run natively")
+        self.linalg_mode = linalg_mode or "Chol"
+        self._KVinv = None
         if isinstance(noise_variances, np.ndarray):
             assert np.ndim(noise_variances) == 1, "noise_variances must be 1-d"
             assert len(noise_variances) == len(y_data), "noise_variances and y_data have different lengths"
@@ -226,6 +228,22 @@ class GP:
         ll, logdet, m, V = self._evaluate(self._hps, self._L, self._alpha)
         self._loglik, self._logdet, self.m, self.V = ll, logdet, m, V
         self._K_host = None
+        self._refresh_inverse()
+
+    def _refresh_inverse(self):
+        """CholInv mode (gp_kv.py:429-432): keep KV^-1 = POTRI(L), full symmetric, next to the factor."""
+        if self.linalg_mode != "CholInv":
+            self._KVinv = None
+            return
+        H, n = self._H, self.point_number
+        inv = self._L.clone()
+        work = H.empty(self._np, self._np)
+        H.potri(inv, n, work)
+        H.symmetrize(inv, n)
+        if self._np > n:
+            inv[n:, :] = 0.0
+            inv[:, n:] = 0.0
+        self._KVinv = inv
 
     def get_hyperparameters(self):
         return self._hps
@@ -314,6 +332,7 @@ class GP:
         self.m, self.V = mean, V
         self._K_host = None
         self._work = self._work2 = self._alpha_work = None
+        self._refresh_inverse()
 
     @property
     def K(self):
@@ -480,6 +499,17 @@ class GP:
         S = H.to_device(self._host_kernel(x_pred, x_pred, hps)) - v.T @ v
         return mean_h, S.cpu().numpy()
 
+    def _variance_from_inverse(self, x_pred):
+        H, n = self._H, self.point_number
+        P = len(x_pred)
+        Pp = _lib.pad128(P)
+        kx = H.empty(self._np, Pp)
+        H.kmat(self._native.kernel_id, self._x_dev, H.to_device(x_pred), self._hps, kx, pad=_lib.PAD_ZERO)
+        Wk = H.empty(self._np, Pp)
+        H.gemm(0, 1, 0, self._np, Pp, self._np, 1.0, self._KVinv, kx, 0.0, Wk)        # KVinv @ k on MFMA
+        H.sync()
+        return self._hps[0] - (kx[:n, :P] * Wk[:n, :P]).sum(dim=0).cpu().numpy()
+
     def posterior_mean(self, x_pred, hyperparameters=None, x_out=None):
         """fvgp/gp.py:1376-1431, gp_posterior.py:139-182."""
         L, alpha, hps = self._L, self._alpha, self._hps
@@ -517,8 +547,13 @@ class GP:
         if isinstance(x_out, np.ndarray):
             x_pred = self.cartesian_product(x_pred, x_out)
         assert x_pred.shape[1] == self.index_set_dim, "wrong number of columns in x_pred"
-        _, S = self._posterior_device(x_pred, self._hps, self._L, self._alpha, want_cov=True)
-        v = np.array(np.diag(S))
+        if self._KVinv is not None and variance_only and self.y_data.shape[1] == 1 and self._native is not None:
+            # gp_posterior.py:238-244: v = diag(kk) - einsum('ij,jk,ki->i', k^T, KVinv, k), S never formed
+            S = None
+            v = self._variance_from_inverse(x_pred)
+        else:
+            _, S = self._posterior_device(x_pred, self._hps, self._L, self._alpha, want_cov=True)
+            v = np.array(np.diag(S))
         if np.any(v < -0.0001):
             warnings.warn("Negative variances encountered. That normally means that the model is unstable. "
                           "Rethink the kernel definition, add more noise to the data, "
@@ -531,10 +566,12 @@ class GP:
         if add_noise:
             noise = self._noise(x_pred, self._hps)          # gp_posterior.py:554-569
             v = v + noise
-            S = S + np.diag(noise)
+            if S is not None:
+                S = S + np.diag(noise)
         if isinstance(x_out, np.ndarray):
             v_re = v.reshape(len(x_orig), len(x_out), order='F')
-            S_re = S.reshape(len(x_orig), len(x_out), len(x_orig), len(x_out), order='F').transpose(0, 2, 1, 3)
+            S_re = None if S is None else \
+                S.reshape(len(x_orig), len(x_out), len(x_orig), len(x_out), order='F').transpose(0, 2, 1, 3)
         else:
             v_re, S_re = v, S
             if self.y_data.shape[1] > 1:
@@ -582,7 +619,7 @@ class GP:
     def __getstate__(self):
         self._H.sync()
         st = {k: v for k, v in self.__dict__.items()
-              if k not in ("_H", "_x_dev", "_L", "_alpha", "_work", "_work2", "_alpha_work")}
+              if k not in ("_H", "_x_dev", "_L", "_alpha", "_work", "_work2", "_alpha_work", "_KVinv")}
         n = self.point_number
         st["_L_host"] = np.tril(self._L[:n, :n].cpu().numpy())
         st["_alpha_host"] = self._alpha[:n].cpu().numpy()
@@ -601,3 +638,5 @@ class GP:
         self._alpha = H.zeros(self._np, self.y_data.shape[1])
         self._alpha[:n] = H.to_device(a_host)
         self._work = self._work2 = self._alpha_work = None
+        self._KVinv = None
+        self._refresh_inverse()

@@ -208,6 +208,28 @@ def test_rank_n_append_equals_refactorisation():
         bad.update_gp_data(x[:5] + 3.0, y[:5])
 
 
+def test_cholinv_mode_variance_fast_path():
+    """linalg_mode='CholInv' (gp.py:226-228, gp_kv.py:429-432, gp_posterior.py:238-244): cached KV^-1,
+    variance_only posterior without forming S; everything else as in 'Chol'."""
+    import fvgp_amd
+    fx = load_golden("G3_matern52_n512_d3.npz")
+    gp = fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], noise_variances=fx["noise_variances"],
+                     kernel_function="matern52_ard", linalg_mode="CholInv")
+    inv = np.linalg.inv(orc.addKV(orc.matern52_ard(fx["x"], fx["x"], fx["theta"]), fx["noise_variances"]))
+    got = gp._KVinv[:512, :512].cpu().numpy()
+    assert np.max(np.abs(got - inv)) <= 1e-9 * np.max(np.abs(inv))
+    pv = gp.posterior_covariance(fx["x_pred"], variance_only=True)
+    assert pv["S"] is None and pv["S_flat"] is None
+    assert np.max(np.abs(pv["v(x)"] - fx["pv"])) <= 1e-10
+    pvn = gp.posterior_covariance(fx["x_pred"], variance_only=True, add_noise=True)
+    assert np.max(np.abs(pvn["v(x)"] - fx["pv_noise"])) <= 1e-10
+    full = gp.posterior_covariance(fx["x_pred"])
+    assert np.max(np.abs(full["S"] - fx["pS"])) <= 1e-10
+    np.testing.assert_allclose(gp.log_likelihood(fx["thetas"][1]), fx["logliks"][1], rtol=1e-10)
+    with pytest.raises(NotImplementedError):
+        fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], noise_variances=fx["noise_variances"], linalg_mode="sparseCG")
+
+
 def test_train_methods_improve_the_likelihood():
     """GP.train (gp.py:781) with the Dask-free methods; every objective call is a device evaluation."""
     import fvgp_amd
