@@ -85,7 +85,7 @@ int fvgp_hip_kmat(fvgp_handle *h, int kernel_id, const double *x1, int64_t n1, c
  * potrf  : calculate_Chol_factor   gp_lin_alg.py:237-269   (scipy cho_factor -> dpotrf)
  * potrs  : calculate_Chol_solve    gp_lin_alg.py:289-328   (cho_solve -> dpotrs)
  * logdet : calculate_Chol_logdet   gp_lin_alg.py:331-360   (2*sum(log|diag|))
- * potri  : calculate_inv_from_chol gp_lin_alg.py:1558-1578 (KV^-1 from L), lower triangle
+ * potri  : calculate_inv_from_chol gp_lin_alg.py:1558-1566 (KV^-1 from L), lower triangle
  * A / L: padded_dim(n) rows, lda >= padded_dim(n).  B: (padded_dim(n), ldb) row-major,
  * nrhs columns used; rows >= n of B are overwritten with zeros. */
 int fvgp_hip_potrf(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host);
