@@ -230,6 +230,35 @@ def test_cholinv_mode_variance_fast_path():
         fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], noise_variances=fx["noise_variances"], linalg_mode="sparseCG")
 
 
+def test_tiny_and_many_column_problems():
+    """Edge sizes: fewer points than one 128 tile, a single point, and more y columns than the vector-solve path takes."""
+    import fvgp_amd
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 5, 127, 129):
+        x = rng.random((n, 2)); y = np.sin(x.sum(axis=1)) + 0.01 * rng.standard_normal(n)
+        nv = np.full(n, 0.05); th = np.array([0.8, 0.4, 0.6])
+        gp = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function="matern32_ard")
+        ref = orc.OracleGP(x, y, th, nv, kernel="matern32_ard")
+        np.testing.assert_allclose(gp.log_likelihood(), ref.log_likelihood(), rtol=1e-11)
+        np.testing.assert_allclose(gp.log_likelihood(th * 1.1), ref.log_likelihood(th * 1.1), rtol=1e-11)
+        np.testing.assert_allclose(gp.neg_log_likelihood_gradient(th), ref.neg_log_likelihood_gradient(th), rtol=1e-8, atol=1e-10)
+        xp = rng.random((3, 2))
+        np.testing.assert_allclose(gp.posterior_mean(xp)["m(x)"], ref.posterior_mean(xp)["m(x)"], rtol=1e-9, atol=1e-12)
+        assert np.max(np.abs(gp.posterior_covariance(xp)["S"] - ref.posterior_covariance(xp)["S"])) < 1e-11
+    n, c = 300, 11
+    x = rng.random((n, 3)); Y = np.stack([np.sin((k + 1) * x.sum(axis=1)) for k in range(c)], axis=1)
+    nv = np.full(n, 0.02); th = np.array([1.0, 0.4, 0.5, 0.6])
+    gp = fvgp_amd.GP(x, Y, init_hyperparameters=th, noise_variances=nv, kernel_function="rbf_ard")
+    ref = orc.OracleGP(x, Y, th, nv, kernel="rbf_ard")
+    np.testing.assert_allclose(gp.log_likelihood(), ref.log_likelihood(), rtol=1e-10)
+    np.testing.assert_allclose(gp.log_likelihood(th * 0.9), ref.log_likelihood(th * 0.9), rtol=1e-10)
+    assert np.max(np.abs(gp.KVinvY - ref.KVinvY)) <= 1e-8 * np.max(np.abs(ref.KVinvY))
+    xp = rng.random((4, 3))
+    np.testing.assert_allclose(gp.posterior_mean(xp)["m(x)"], ref.posterior_mean(xp)["m(x)"], rtol=1e-8, atol=1e-10)
+    assert gp.posterior_covariance(xp)["v(x)"].shape == (4, c)
+    np.testing.assert_allclose(gp.neg_log_likelihood_gradient(th, component=7), ref.neg_log_likelihood_gradient(th, component=7), rtol=1e-8)
+
+
 def test_train_methods_improve_the_likelihood():
     """GP.train (gp.py:781) with the Dask-free methods; every objective call is a device evaluation."""
     import fvgp_amd
