@@ -219,7 +219,7 @@ def main():
                 "algorithmic_flops_per_launch": prof["flops"] / max(prof["launches"], 1.0),
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_sample_n)
         print(json.dumps(out))
     if dist is not None:
