@@ -24,7 +24,7 @@ MAX_RHS_VEC = 8
 SYMBOLS = [
     "fvgp_hip_version", "fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_create",
     "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
-    "fvgp_hip_potrf", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
+    "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize",
     "fvgp_hip_debug_tile_map", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_syrk_rowshard",
@@ -82,6 +82,7 @@ def lib():
     L.fvgp_hip_get_profile.argtypes = [c_p, P_d]
     L.fvgp_hip_kmat.argtypes = [c_p, c_i, c_p, c_l, c_p, c_l, c_i, P_d, c_i, c_p, c_p, c_l, c_i, c_i]
     L.fvgp_hip_potrf.argtypes = [c_p, c_p, c_l, c_l, P_i]
+    L.fvgp_hip_potrf_dev.argtypes = [c_p, c_p, c_l, c_l, c_l, c_p, c_p]
     L.fvgp_hip_potrs.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
     L.fvgp_hip_trsm_lower.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
     L.fvgp_hip_logdet.argtypes = [c_p, c_p, c_l, c_l, P_d]
@@ -96,8 +97,8 @@ def lib():
     L.fvgp_hip_mfma_peak.argtypes = [c_p, c_p, c_i, c_i]
     L.fvgp_hip_trsm_lower_t.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
     L.fvgp_hip_panel_trsm.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
-    L.fvgp_hip_syrk_rowshard.argtypes = [c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i]
-    L.fvgp_hip_debug_tile_map.argtypes = [c_i, c_i, c_i, P_i, P_i, c_l]
+    L.fvgp_hip_syrk_rowshard.argtypes = [c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i]
+    L.fvgp_hip_debug_tile_map.argtypes = [c_i, c_i, c_i, c_i, c_i, P_i, P_i, c_l]
     L.fvgp_hip_debug_tile_map.restype = c_l
     for s in SYMBOLS:
         if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map"):
@@ -202,9 +203,15 @@ class Handle:
         _check(lib().fvgp_hip_panel_trsm(self._h, _ptr(D), int(nd), D.stride(0), _ptr(P), int(rows), P.stride(0)),
                "fvgp_hip_panel_trsm")
 
-    def syrk_rowshard(self, M, N, K, A, B, C, scale, off):
+    def syrk_rowshard(self, M, N, K, A, B, C, scale, off, b_ranks=1, b_blocks=0, b_off=0):
         _check(lib().fvgp_hip_syrk_rowshard(self._h, int(M), int(N), int(K), _ptr(A), A.stride(0), _ptr(B), B.stride(0),
-                                            _ptr(C), C.stride(0), int(scale), int(off)), "fvgp_hip_syrk_rowshard")
+                                            _ptr(C), C.stride(0), int(scale), int(off), int(b_ranks), int(b_blocks),
+                                            int(b_off)), "fvgp_hip_syrk_rowshard")
+
+    def potrf_dev(self, A, n, n_logdet, info_dev, logdet_dev):
+        """Enqueue-only potrf: info (int32 tensor) and log-det (float64 tensor) stay on the device."""
+        _check(lib().fvgp_hip_potrf_dev(self._h, _ptr(A), int(n), A.stride(0), int(n_logdet), _ptr(info_dev),
+                                        _ptr(logdet_dev) if logdet_dev is not None else None), "fvgp_hip_potrf_dev")
 
     def logdet(self, L, n):
         out = ctypes.c_double(0.0)

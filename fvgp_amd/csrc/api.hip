@@ -205,7 +205,7 @@ static double lower_flops(int64_t M, int64_t N, int64_t K) {     // algorithmic 
 // look-ahead (option "lookahead"): the trailing update of panel J is split into the block columns of
 // panel J+1 (done first) and the rest; panel J+1 is then factored on a second, high-priority stream
 // while the rest of the update runs on the main stream.
-static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host) {
+static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host, int *info_dev = nullptr, bool enqueue_only = false) {
     const int64_t np = pad128(n), nblk = np / TILE;
     int rc = ensure_blocks(h, nblk);
     if (rc) return rc;
@@ -220,13 +220,14 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
         *e = h->ev[nev++];
         return 0;
     };
-    if (h->profile) { rc = get_event(&e_begin); if (rc) return rc; HIPCHK(hipEventRecord(e_begin, h->stream)); }
+    const bool profile = h->profile && !enqueue_only;
+    if (profile) { rc = get_event(&e_begin); if (rc) return rc; HIPCHK(hipEventRecord(e_begin, h->stream)); }
     auto timed_update = [&](int64_t J0, int64_t Jend, int64_t c0, int64_t c1) -> int {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->profile) { int r = get_event(&e0); if (r) return r; HIPCHK(hipEventRecord(e0, h->stream)); }
+        if (profile) { int r = get_event(&e0); if (r) return r; HIPCHK(hipEventRecord(e0, h->stream)); }
         int r = trailing_update(h, A, np, lda, J0, Jend, c0, c1);
         if (r) return r;
-        if (h->profile) {
+        if (profile) {
             r = get_event(&e1); if (r) return r; HIPCHK(hipEventRecord(e1, h->stream));
             h->ev_flops.push_back(lower_flops(np - c0, c1 - c0, Jend - J0));
         }
@@ -277,6 +278,11 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             // the next iteration's updates use panel J+1: wait for its factorisation
             HIPCHK(hipStreamWaitEvent(mainS, h->ev_panel, 0));
         }
+    }
+    if (enqueue_only) {          // no host round trip: info stays on the device, nothing is timed
+        if (info_dev) HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        h->linv_L = A; h->linv_n = n; h->linv_ld = lda;
+        return 0;
     }
     if (h->profile) { rc = get_event(&e_end); if (rc) return rc; HIPCHK(hipEventRecord(e_end, h->stream)); }
     int *hinfo = reinterpret_cast<int *>(h->hpin + RED_SLOTS - 2);
@@ -399,6 +405,21 @@ int fvgp_hip_potrf(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_
     rc = launch_pad_identity(h, A, n, pad128(n), lda);
     if (rc) return rc;
     return potrf_driver(h, A, n, lda, info_host);
+}
+
+int fvgp_hip_potrf_dev(fvgp_handle *h, double *A, int64_t n, int64_t lda, int64_t n_logdet, int *info_dev, double *logdet_dev) {
+    if (!h) return -1;
+    int rc = check_square(A, n, lda, 2, 3, 4);
+    if (rc) return rc;
+    if (n_logdet < 0 || n_logdet > n) return -5;
+    if (!info_dev) return -6;
+    HIPCHK(hipSetDevice(h->device));
+    rc = launch_pad_identity(h, A, n, pad128(n), lda);
+    if (rc) return rc;
+    rc = potrf_driver(h, A, n, lda, nullptr, info_dev, true);
+    if (rc) return rc;
+    if (logdet_dev && n_logdet > 0) return launch_diag_logsum(h, A, n_logdet, lda, logdet_dev);
+    return 0;
 }
 
 int fvgp_hip_potrs(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb) {
@@ -663,16 +684,22 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
 }
 
 int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
-                            const double *B, int64_t ldb, double *C, int64_t ldc, int scale, int off) {
+                            const double *B, int64_t ldb, double *C, int64_t ldc, int scale, int off,
+                            int b_ranks, int b_blocks, int b_off) {
     if (!h) return -1;
     if (!A) return -5;
     if (!B) return -7;
     if (!C) return -9;
     if (scale < 1) return -11;
-    if (off < 0) return -12;
+    if (b_ranks < 1) return -13;
+    if (b_off < 0 || (b_ranks > 1 && b_blocks < 1)) return -14;
+    if (b_blocks > 0 && N > 0 && (b_off + N / TILE - 1) / b_ranks >= b_blocks) {
+        fvgp_set_error("syrk_rowshard: the tile columns run past the gathered blocks"); return -14;
+    }
     HIPCHK(hipSetDevice(h->device));
     GemmDesc g{};
     g.a_kmajor = 0; g.b_nmajor = 0; g.lower = 2; g.lower_scale = scale; g.lower_off = off; g.role = 1;
+    g.bc_ranks = b_ranks; g.bc_blocks = b_blocks; g.bc_off = b_off;
     g.M = M; g.N = N; g.K = K; g.alpha = -1.0; g.beta = 1.0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     return launch_gemm(h, g);
@@ -739,9 +766,10 @@ int fvgp_hip_mfma_selftest(fvgp_handle *h, const double *A, const double *B, dou
     return launch_mfma_selftest(h, A, B, D);
 }
 
-int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int *out_ti, int *out_tj, int64_t cap) {
+int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int scale, int off, int *out_ti, int *out_tj, int64_t cap) {
     if (tiles_m < 1 || tiles_n < 1 || !out_ti || !out_tj) return -1;
-    return gemm_debug_tile_map(tiles_m, tiles_n, lower, out_ti, out_tj, cap);
+    if (lower < 0 || lower > 2 || (lower == 2 && scale < 1)) return -3;
+    return gemm_debug_tile_map(tiles_m, tiles_n, lower, scale, off, out_ti, out_tj, cap);
 }
 
 int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters) {

@@ -67,9 +67,12 @@ struct GemmDesc {
     double *C; int64_t ldc;
     // per-tile K range: [kb0 + kbi*ti + kbj*tj, ke0 + kei*ti + kej*tj) clamped to [0,K], in elements
     int64_t kb0 = 0, kbi = 0, kbj = 0, ke0 = -1, kei = 0, kej = 0;
+    // B (b_nmajor = 0 only) as an all-gather leaves it: `bc_ranks` chunks of `bc_blocks` 128-row blocks, chunk q
+    // holding the blocks q, q + bc_ranks, ...; output tile column tj reads block tj + bc_off of that cyclic order
+    int bc_ranks = 1, bc_blocks = 0, bc_off = 0;
 };
 int launch_gemm(fvgp_handle *h, const GemmDesc &g);
-long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int *out_ti, int *out_tj, long cap);
+long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int ls, int lo, int *out_ti, int *out_tj, long cap);
 
 struct KmatDesc {
     int kind;                 // 0 rbf, 1 matern 3/2, 2 matern 5/2

@@ -33,6 +33,7 @@ struct GemmArgs {
     double alpha, beta;
     int tiles_m, tiles_n, lower;      // lower: 0 all tiles, 1 tj <= ti, 2 tj <= ti*ls + lo (row-sharded trailing update)
     int ls, lo;
+    int bcr, bcb, bco;                // B rows in all-gather (block-cyclic) order, see GemmDesc
     long K;
     long kb0, kbi, kbj, ke0, kei, kej;
     long ntiles;
@@ -65,6 +66,30 @@ __host__ __device__ inline void tile_of(long t, int tiles_m, int tiles_n, int lo
     ti = si * S + in / SN; tj = sj * SN + in % SN;
 }
 
+// row-sharded trailing update (lower == 2, tile (ti, tj) exists iff tj <= ti*ls + lo): super-row si holds only
+// the super-tiles its widest row reaches, so the grid carries no dead half.  Linear search over the
+// super-rows (a few dozen scalar iterations per workgroup).
+__host__ __device__ inline int rs_super_count(int si, int tiles_n, int SN, int ls, int lo) {
+    long w = (long)(si * 8 + 7) * ls + lo + 1;
+    if (w <= 0) return 0;
+    if (w > tiles_n) w = tiles_n;
+    return (int)((w + SN - 1) / SN);
+}
+__host__ __device__ inline void tile_of_rs(long t, int tiles_m, int tiles_n, int ls, int lo, int &ti, int &tj) {
+    constexpr int S = 8;
+    const int SN = tiles_n < S ? tiles_n : S;
+    const long per = (long)S * SN;
+    long st = t / per; const int in = (int)(t % per);
+    const int sm = (tiles_m + S - 1) / S;
+    int si = 0;
+    for (; si < sm; ++si) {
+        const int c = rs_super_count(si, tiles_n, SN, ls, lo);
+        if (st < c) break;
+        st -= c;
+    }
+    ti = si * S + in / SN; tj = (int)st * SN + in % SN;      // si == sm (past the end) gives ti >= tiles_m: exits
+}
+
 __host__ __device__ inline long xcd_remap(long b, long nwg, int tiles_n) {
     const long per = 8L * (tiles_n < 8 ? tiles_n : 8);      // tiles per super-tile
     const long nst = nwg / per;                             // grid is a whole number of super-tiles
@@ -91,7 +116,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // round-robin over the XCDs so every XCD gets the same mix of full and diagonal (half-empty) ones.
     const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
     int ti, tj;
-    tile_of(t, g.tiles_m, g.tiles_n, g.lower == 1, ti, tj);
+    if (g.lower == 2) tile_of_rs(t, g.tiles_m, g.tiles_n, g.ls, g.lo, ti, tj);
+    else tile_of(t, g.tiles_m, g.tiles_n, g.lower == 1, ti, tj);
     if (ti >= g.tiles_m || tj >= g.tiles_n) return;
     if (g.lower == 1 && tj > ti) return;
     if (g.lower == 2 && tj > ti * g.ls + g.lo) return;
@@ -107,6 +133,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     const int nk = kend > kbeg ? (int)((kend - kbeg) / BK) : 0;
 
     const long m0 = (long)ti * 128, n0 = (long)tj * 128;
+    long nb0 = n0;                    // first row of this tile's B block
+    if (!BNM) { const int idx = tj + g.bco; nb0 = ((long)(idx % g.bcr) * g.bcb + idx / g.bcr) * 128; }
 
     // global -> register staging maps (4 x 16 B per operand per thread)
     const double *ga[4]; const double *gb[4];
@@ -129,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             sb[p] = kr * LDM + nc;
         } else {             // B stored (N, K)
             int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
-            gb[p] = g.B + (n0 + row) * g.ldb + kbeg + kc;
+            gb[p] = g.B + (nb0 + row) * g.ldb + kbeg + kc;
             sb[p] = row * LDK + kc;
         }
     }
@@ -296,13 +324,21 @@ static long gemm_grid_tiles(int tiles_m, int tiles_n, int lower) {
     return nst * S * SN;
 }
 
+static long gemm_grid_tiles_rs(int tiles_m, int tiles_n, int ls, int lo) {
+    const int S = 8, SN = tiles_n < S ? tiles_n : S;
+    long nst = 0;
+    for (int si = 0; si < (tiles_m + S - 1) / S; ++si) nst += rs_super_count(si, tiles_n, SN, ls, lo);
+    return nst * S * SN;
+}
+
 // host-side replay of the blockIdx -> tile map (XCD remap included) for the CPU tests
-long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int *out_ti, int *out_tj, long cap) {
-    const long nwg = gemm_grid_tiles(tiles_m, tiles_n, lower);
+long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int ls, int lo, int *out_ti, int *out_tj, long cap) {
+    const long nwg = lower == 2 ? gemm_grid_tiles_rs(tiles_m, tiles_n, ls, lo) : gemm_grid_tiles(tiles_m, tiles_n, lower);
     for (long b = 0; b < nwg && b < cap; ++b) {
         const long t = xcd_remap(b, nwg, tiles_n);
         int ti, tj;
-        tile_of(t, tiles_m, tiles_n, lower, ti, tj);
+        if (lower == 2) tile_of_rs(t, tiles_m, tiles_n, ls, lo, ti, tj);
+        else tile_of(t, tiles_m, tiles_n, lower, ti, tj);
         out_ti[b] = ti; out_tj[b] = tj;
     }
     return nwg;
@@ -318,8 +354,12 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.A = d.A; g.B = d.B; g.C = d.C; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
     g.alpha = d.alpha; g.beta = d.beta; g.K = d.K;
     g.tiles_m = (int)(d.M / 128); g.tiles_n = (int)(d.N / 128); g.lower = d.lower; g.ls = d.lower_scale; g.lo = d.lower_off;
+    g.bcr = d.bc_ranks; g.bcb = d.bc_blocks; g.bco = d.bc_off;
+    if (d.bc_ranks < 1) return -7;
+    if ((d.bc_ranks > 1 || d.bc_off) && d.b_nmajor) { fvgp_set_error("gemm: block-cyclic B needs the (N, K) layout"); return -7; }
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
-    g.ntiles = gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
+    g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
+    if (g.ntiles == 0) return 0;
     dim3 grid((unsigned)g.ntiles), block(256);
 #define GO(AK, BN) do { if (d.role == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 1>), grid, block, 0, h->stream, g); \
                         else hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 0>), grid, block, 0, h->stream, g); } while (0)

@@ -12,9 +12,13 @@ Here the same pattern carries a DENSE factorisation:
          <= 8 MB) and factored redundantly -- no pivot traffic inside the panel;
       2. each rank solves its own rows of the panel against it (MFMA GEMMs);
       3. the panel factor is all-gathered (the one large collective: sum ~ 4 N^2 bytes per rank);
-      4. each rank applies the trailing update to its own block rows (lower tiles only);
-  * the forward solve is pipelined over panels with one small all_reduce per panel; log|KV| and
-    (y-m)^T KV^-1 (y-m) come out replicated, so the log-likelihood needs no final reduction.
+      4. each rank applies the trailing update to its own block rows (lower tiles only), reading
+         the gathered panel in the order the all-gather left it (no re-ordering copy);
+     with one panel of look-ahead: the update is split into the next panel's columns and the rest,
+     and steps 1-3 of the next panel run on a second stream while the rest is applied;
+  * the forward solve rides along as one more block row holding (y-m)^T, replicated on every rank;
+    log|KV| and (y-m)^T KV^-1 (y-m) come out replicated, so the log-likelihood needs no final
+    reduction and one evaluation has exactly one host synchronisation.
 
 All arithmetic goes through an `ops` object; the product ops are the HIP kernels (HipOps, raises
 without a GPU).  tests/ plug in a torch-CPU stand-in to exercise the partition and collective
@@ -31,15 +35,42 @@ TILE = 128
 
 
 class HipOps:
-    """The product implementation: every operation is a libfvgp_hip.so call."""
+    """The product implementation: every operation is a libfvgp_hip.so call.  `chain` is the same set of
+    operations bound to a second, high-priority stream: the panel chain (diagonal-block factorisation, panel
+    solve, all-gather) runs there while the main stream applies the previous panel to the trailing matrix."""
 
-    def __init__(self, handle=None):
-        from .device import default_handle
-        self.H = handle or default_handle()
-        self.torch = self.H.torch
+    def __init__(self, handle=None, _stream=None, _main=None):
+        from .device import default_handle, local_device
+        torch = self.torch = __import__("torch")
+        if _stream is None:
+            self.H = handle or default_handle()
+            self._stream = torch.cuda.current_stream(self.H.device)
+            side = torch.cuda.Stream(device=self.H.device, priority=-1)
+            self.chain = HipOps(_lib.Handle(self.H.device, stream=side.cuda_stream), _stream=side, _main=self)
+        else:
+            self.H, self._stream, self.chain = handle, _stream, self
+            self._main = _main
 
-    def zeros(self, *shape):
-        return self.H.zeros(*shape)
+    def stream(self):
+        """context in which torch's own work (copies, collectives) lands on this object's stream"""
+        return self.torch.cuda.stream(self._stream)
+
+    def fork(self):
+        """the chain stream waits for everything enqueued on the main stream so far"""
+        ev = self.torch.cuda.Event()
+        ev.record(self._stream)
+        self.chain._stream.wait_event(ev)
+
+    def join(self):
+        """the main stream waits for everything enqueued on the chain stream so far"""
+        ev = self.torch.cuda.Event()
+        ev.record(self.chain._stream)
+        self._stream.wait_event(ev)
+
+    def zeros(self, *shape, dtype=None):
+        if dtype is None:
+            return self.H.zeros(*shape)
+        return self.torch.zeros(*shape, dtype=dtype, device=f"cuda:{self.H.device}")
 
     def to_device(self, a):
         return self.H.to_device(a)
@@ -48,21 +79,14 @@ class HipOps:
         """out[:len(x_rows), :len(x_all)] = k(x_rows, x_all); the rest of the padded window is zeroed."""
         self.H.kmat(kernel_id, x_rows, x_all, theta, out, pad=_lib.PAD_ZERO)
 
-    def potrf(self, D, n):
-        return self.H.potrf(D, n)
+    def potrf_dev(self, D, n, n_logdet, info_dev, logdet_dev):
+        self.H.potrf_dev(D, n, n_logdet, info_dev, logdet_dev)
 
     def panel_trsm(self, D, nd, Pm, rows):
         self.H.panel_trsm(D, nd, Pm, rows)
 
-    def syrk_rowshard(self, M, N, K, A, B, C, scale, off):
-        self.H.syrk_rowshard(M, N, K, A, B, C, scale, off)
-
-    def trsm_lower(self, D, n, B, nrhs):
-        self.H.trsm_lower(D, n, B, nrhs)
-
-    def gemm_nn_sub(self, M, N, K, A, B, C):
-        """C (M,N) -= A (M,K) @ B (K,N)."""
-        self.H.gemm(0, 1, 0, M, N, K, -1.0, A, B, 1.0, C)
+    def syrk_rowshard(self, M, N, K, A, B, C, scale, off, b_ranks, b_blocks, b_off):
+        self.H.syrk_rowshard(M, N, K, A, B, C, scale, off, b_ranks, b_blocks, b_off)
 
     def sync(self):
         self.H.sync()
@@ -72,7 +96,9 @@ class ShardedGP:
     """log marginal likelihood of one GP sharded over the process group.
 
     x (n,d), y (n,) or (n,c), noise variances (n,) are given replicated (host arrays); the N x N
-    matrix only ever exists as this rank's block rows."""
+    matrix only ever exists as this rank's block rows.  Below them every rank keeps one more 128-row
+    block holding (y-m)^T: carried through the panel solves and trailing updates like any other block
+    row it comes out as (L^-1 (y-m))^T, so the forward solve costs no extra pass and no collective."""
 
     def __init__(self, x, y, noise_variances, kernel="rbf_ard", group=None, ops=None, panel=1024,
                  rank=None, world=None):
@@ -91,10 +117,12 @@ class ShardedGP:
         y = np.asarray(y, dtype=np.float64).reshape(len(x), -1)
         self.n, self.d = x.shape
         self.ncol = y.shape[1]
+        assert self.ncol <= TILE, "at most 128 columns of y"
         self.np_ = _lib.pad128(self.n)
         self.nblk = self.np_ // TILE
         self.nb_max = -(-self.nblk // self.P)                       # block rows per rank (uniform, padded)
         self.nb_loc = len(range(self.p, self.nblk, self.P))          # block rows this rank really owns
+        self.nloc = self.nb_max + 1                                  # + the block of right-hand-side rows
         # global row index of every local row
         gb = np.arange(self.nb_max) * self.P + self.p
         self.gidx = (gb[:, None] * TILE + np.arange(TILE)[None, :]).reshape(-1)
@@ -105,16 +133,31 @@ class ShardedGP:
         self.x_loc = o.to_device(x[self.gidx[:self.nv]]) if self.nv > 0 else None
         self.v_host = np.asarray(noise_variances, dtype=np.float64)
         m = float(np.mean(y))                                        # default prior mean, gp_prior.py:449-458
-        ym = np.zeros((self.np_, self.ncol))
-        ym[:self.n] = y - m
-        self.ymean_host = ym
-        self.A = o.zeros(self.nb_max * TILE, self.np_)
-        self._diag_rows = torch.as_tensor(np.arange(self.nb_max * TILE)[self.gidx < self.np_])
-        self._diag_cols = torch.as_tensor(self.gidx[self.gidx < self.np_])
-        dv = np.ones(len(self._diag_rows))                           # identity on the padding diagonal
-        sel = self.gidx[self.gidx < self.np_]
+        zt = np.zeros((TILE, self.np_))
+        zt[:self.ncol, :self.n] = (y - m).T
+        self.zt = o.to_device(zt)
+        self.A = o.zeros(self.nloc * TILE, self.np_)
+        self.zrow = self.nb_max * TILE
+        # diagonal of the local rows: + noise on real rows, 1 on the padding rows of the last block
+        inside = self.gidx < self.np_
+        sel = self.gidx[inside]
+        dv = np.ones(len(sel))
         dv[sel < self.n] = self.v_host[sel[sel < self.n]]
-        self._diag_add = dv
+        dev = self.A.device
+        self._diag_rows = torch.as_tensor(np.nonzero(inside)[0], device=dev)
+        self._diag_cols = torch.as_tensor(sel, device=dev)
+        self._diag_add = torch.as_tensor(dv, device=dev)
+        self._diag_real = torch.as_tensor(sel < self.n, device=dev)
+        # panels
+        self.bnd = list(range(0, self.np_, self.NB)) + [self.np_]
+        self.npan = len(self.bnd) - 1
+        self.D = o.zeros(self.npan, self.NB, self.NB)                # factored diagonal blocks, replicated
+        self.info_dev = o.zeros(self.npan, dtype=torch.int32)
+        self.ld_dev = o.zeros(self.npan)
+        if self.P > 1:
+            self._send = o.zeros(self.nb_max * TILE * self.NB)
+            self._recv = [o.zeros(self.P * self.nb_max * TILE * self.NB) for _ in range(2)]
+        self._into_tensor = self.P > 1 and dist.get_backend(group) == "nccl"
 
     # -- collectives (no-ops on one rank) ---------------------------------------------------------
     def _all_reduce(self, t):
@@ -122,122 +165,103 @@ class ShardedGP:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def _all_gather(self, out, inp):
-        if self.P > 1:
-            chunks = list(out.view(self.P, -1).unbind(0))        # contiguous views: works on nccl and gloo
-            self.dist.all_gather(chunks, inp.reshape(-1), group=self.group)
+        """out (P, k) <- every rank's inp (k,)"""
+        if self._into_tensor:
+            self.dist.all_gather_into_tensor(out.view(-1), inp, group=self.group)
         else:
-            out.copy_(inp.reshape(out.shape))
+            self.dist.all_gather(list(out.unbind(0)), inp, group=self.group)      # contiguous views (gloo)
 
     # -- steps ------------------------------------------------------------------------------------
     def assemble(self, theta):
         """This rank's block rows of K+V (full width: the rows are short enough that skipping the upper
-        part is not worth a second code path), identity on the padding."""
+        part is not worth a second code path), identity on the padding, (y-m)^T in the extra block."""
         o, A = self.ops, self.A
-        A.zero_()
+        top = 0
         if self.nv > 0:
             o.kmat_rows(self.kernel_id, self.x_loc, self.x_all, np.asarray(theta, dtype=np.float64), A)
-        if self.nv < A.shape[0]:
-            A[self.nv:].zero_()
-        dev = A.device
-        rows, cols = self._diag_rows.to(dev), self._diag_cols.to(dev)
-        add = self.torch.as_tensor(self._diag_add, device=dev)
-        valid = self.torch.as_tensor(self.gidx[self.gidx < self.np_] < self.n, device=dev)
-        cur = A[rows, cols]
-        A[rows, cols] = self.torch.where(valid, cur + add, add)
+            top = _lib.pad128(self.nv)
+        if top < self.zrow:
+            A[top:self.zrow].zero_()
+        rows, cols = self._diag_rows, self._diag_cols
+        A[rows, cols] = self.torch.where(self._diag_real, A[rows, cols] + self._diag_add, self._diag_add)
+        A[self.zrow:].copy_(self.zt)
+
+    def _chain(self, J):
+        """Panel J on the chain stream: diagonal block to every rank (all_reduce of a zero-filled buffer),
+        factored redundantly; this rank's rows below it solved against it; panel factor all-gathered."""
+        o, A, P, p, NB = self.ops.chain, self.A, self.P, self.p, self.NB
+        J0, Jend = self.bnd[J], self.bnd[J + 1]
+        w = Jend - J0
+        b0, b1 = J0 // TILE, Jend // TILE
+        la = max(0, -(-(b0 - p) // P))                              # local blocks [la, lb) lie in the panel's rows
+        lb = max(0, -(-(b1 - p) // P))
+        D = self.D[J]
+        with o.stream():
+            mine = None
+            if lb > la:
+                mine = D.view(NB // TILE, TILE, NB)[la * P + p - b0::P][:lb - la][:, :, :w]
+            if P > 1:
+                D.zero_()
+            if mine is not None:
+                mine.copy_(A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)))
+            self._all_reduce(D)
+            o.potrf_dev(D, w, max(0, min(w, self.n - J0)), self.info_dev[J:J + 1], self.ld_dev[J:J + 1])
+            if mine is not None:
+                A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)).copy_(mine)
+            o.panel_trsm(D, w, A[lb * TILE:, J0:Jend], (self.nloc - lb) * TILE)
+            if Jend < self.np_ and P > 1:
+                L0 = b1 // P                                        # uniform first gathered local block
+                k = (self.nb_max - L0) * TILE
+                send = self._send[:k * w].view(k, w)
+                send.copy_(A[L0 * TILE:self.nb_max * TILE, J0:Jend])
+                self._all_gather(self._recv[J % 2][:P * k * w].view(P, k * w), send.view(-1))
+
+    def _update(self, J, c0, c1):
+        """Apply panel J to block columns [c0, c1) of this rank's rows below the panel (lower tiles only)."""
+        if c1 <= c0:
+            return
+        o, A, P, p = self.ops, self.A, self.P, self.p
+        J0, Jend = self.bnd[J], self.bnd[J + 1]
+        w = Jend - J0
+        b1 = Jend // TILE
+        l0 = max(0, -(-(b1 - p) // P))                              # first local block row below the panel
+        M = (self.nloc - l0) * TILE
+        cb = c0 // TILE
+        if P > 1:
+            L0 = b1 // P
+            k = (self.nb_max - L0) * TILE
+            B = self._recv[J % 2][:P * k * w].view(P * k, w)
+            b_blocks, b_off = self.nb_max - L0, cb - L0 * P
+        else:
+            B, b_blocks, b_off = A[c0:self.zrow, J0:Jend], 0, 0
+        o.syrk_rowshard(M, c1 - c0, w, A[l0 * TILE:, J0:Jend], B, A[l0 * TILE:, c0:], P, l0 * P + p - cb,
+                        P, b_blocks, b_off)
 
     def factor(self):
-        """Blocked right-looking Cholesky of the sharded matrix, in place.  Returns (info, logdet) and keeps
-        the factored diagonal blocks for the solves."""
-        o, A, P, p, NB, np_ = self.ops, self.A, self.P, self.p, self.NB, self.np_
-        torch = self.torch
-        self.diag_blocks = []
-        logdet = 0.0
-        for J0 in range(0, np_, NB):
-            Jend = min(J0 + NB, np_)
-            w = Jend - J0
-            b0, b1 = J0 // TILE, Jend // TILE
-            # 1. diagonal block to everyone, factored redundantly
-            D = o.zeros(w, w)
-            for gb in range(b0, b1):
-                if gb % P == p:
-                    l = gb // P
-                    D[(gb - b0) * TILE:(gb - b0 + 1) * TILE, :] = A[l * TILE:(l + 1) * TILE, J0:Jend]
-            self._all_reduce(D)
-            info = o.potrf(D, w)
-            if info != 0:
-                return J0 + info, float("nan")
-            dg = torch.diagonal(D)[:max(0, min(w, self.n - J0))]
-            logdet += 2.0 * float(torch.log(dg).sum().item())
-            for gb in range(b0, b1):
-                if gb % P == p:
-                    l = gb // P
-                    A[l * TILE:(l + 1) * TILE, J0:Jend] = D[(gb - b0) * TILE:(gb - b0 + 1) * TILE, :]
-            self.diag_blocks.append(D)
-            if Jend >= np_:
-                break
-            # 2. this rank's rows below the panel: X = A_panel * L_JJ^-T
-            l0 = max(0, -(-(b1 - p) // P))                          # first local block row with global block >= b1
-            rows = (self.nb_loc - l0) * TILE
-            if rows > 0:
-                o.panel_trsm(D, w, A[l0 * TILE:, J0:Jend], rows)
-            # 3. all-gather the panel factor, re-ordered to global block order
-            L0 = b1 // P                                            # uniform first local index on every rank
-            m = self.nb_max - L0
-            send = A[L0 * TILE:self.nb_max * TILE, J0:Jend].contiguous()
-            recv = o.zeros(P * m * TILE, w)
-            self._all_gather(recv, send)
-            G = recv.view(P, m, TILE, w).permute(1, 0, 2, 3).reshape(m * P * TILE, w)
-            Gv = G[(b1 - L0 * P) * TILE:]
-            # 4. trailing update of this rank's block rows, lower tiles only
-            N = np_ - Jend
-            if rows > 0:
-                if Gv.shape[0] < N:                                 # ranks past the end contribute nothing
-                    pad = o.zeros(N - Gv.shape[0], w)
-                    Gv = torch.cat([Gv, pad], dim=0)
-                Gc = Gv[:N].contiguous()
-                o.syrk_rowshard(rows, N, w, A[l0 * TILE:, J0:Jend], Gc, A[l0 * TILE:, Jend:], P, l0 * P + p - b1)
-        return 0, logdet
-
-    def forward_solve(self):
-        """z = L^-1 (y - m), replicated; returns sum(z^2)/ncol.  One small all_reduce per panel."""
-        o, A, P, p, NB, np_ = self.ops, self.A, self.P, self.p, self.NB, self.np_
-        torch = self.torch
-        c = self.ncol
-        # local residual: rows this rank owns, 128 padded columns (GEMM granularity)
-        r = o.zeros(self.nb_max * TILE, TILE)
-        ym = o.to_device(self.ymean_host)
-        rows_ok = self.gidx < np_
-        r[torch.as_tensor(np.nonzero(rows_ok)[0], device=r.device), :c] = ym[torch.as_tensor(self.gidx[rows_ok], device=r.device)]
-        quad = 0.0
-        self.z_panels = []
-        for Ji, J0 in enumerate(range(0, np_, NB)):
-            Jend = min(J0 + NB, np_)
-            w = Jend - J0
-            b0, b1 = J0 // TILE, Jend // TILE
-            D = self.diag_blocks[Ji]
-            bJ = o.zeros(w, TILE)
-            for gb in range(b0, b1):
-                if gb % P == p:
-                    l = gb // P
-                    bJ[(gb - b0) * TILE:(gb - b0 + 1) * TILE] = r[l * TILE:(l + 1) * TILE]
-            self._all_reduce(bJ)
-            o.trsm_lower(D, w, bJ, TILE)                            # z_J = L_JJ^-1 b_J
-            o.sync()
-            quad += float((bJ[:, :c] ** 2).sum().item())
-            self.z_panels.append(bJ)
-            if Jend >= np_:
-                break
-            l0 = max(0, -(-(b1 - p) // P))
-            rows = (self.nb_loc - l0) * TILE
-            if rows > 0:
-                o.gemm_nn_sub(rows, TILE, w, A[l0 * TILE:, J0:Jend], bJ, r[l0 * TILE:])
-        return quad / c
+        """Blocked right-looking Cholesky of the sharded matrix with one panel of look-ahead, all enqueued
+        without a host round trip; the appended rows come out as (L^-1 (y-m))^T."""
+        o, bnd = self.ops, self.bnd
+        o.fork()
+        self._chain(0)
+        for J in range(self.npan - 1):
+            o.join()                                                # panel J factored and gathered
+            self._update(J, bnd[J + 1], bnd[J + 2])                 # next panel's columns first ...
+            o.fork()
+            self._chain(J + 1)                                      # ... so its chain overlaps the rest
+            self._update(J, bnd[J + 2], self.np_)
+        o.join()
 
     def log_likelihood(self, theta):
-        """GPMarginalLikelihood.log_likelihood(theta) (gp_marginal_likelihood.py:137-179) on the sharded matrix."""
+        """GPMarginalLikelihood.log_likelihood(theta) (gp_marginal_likelihood.py:137-179) on the sharded matrix.
+        Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated on every rank."""
+        torch = self.torch
         self.assemble(theta)
-        info, logdet = self.factor()
-        if info != 0:
-            raise np.linalg.LinAlgError(f"{info}-th leading minor of the array is not positive definite")
-        quad = self.forward_solve()
+        self.factor()
+        z = self.A[self.zrow:self.zrow + self.ncol, :self.n]
+        out = torch.cat([(z * z).sum().reshape(1), self.ld_dev.sum().reshape(1), self.info_dev.to(torch.float64)]).cpu().numpy()
+        bad = np.nonzero(out[2:])[0]
+        if len(bad):
+            J = int(bad[0])
+            raise np.linalg.LinAlgError(f"{self.bnd[J] + int(out[2 + J])}-th leading minor of the array is not positive definite")
+        quad, logdet = float(out[0]) / self.ncol, float(out[1])
         return -0.5 * (quad + logdet + self.n * math.log(2.0 * math.pi)), logdet, quad

@@ -89,6 +89,10 @@ int fvgp_hip_kmat(fvgp_handle *h, int kernel_id, const double *x1, int64_t n1, c
  * A / L: padded_dim(n) rows, lda >= padded_dim(n).  B: (padded_dim(n), ldb) row-major,
  * nrhs columns used; rows >= n of B are overwritten with zeros. */
 int fvgp_hip_potrf(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host);
+/* potrf without the host round trip (the row-sharded driver factors one diagonal block per panel and must
+ * not drain the stream): info goes to `info_dev` (device int), 2*sum(log|diag|) of the first n_logdet
+ * rows to `logdet_dev` (device double, may be null).  Enqueue only. */
+int fvgp_hip_potrf_dev(fvgp_handle *h, double *A, int64_t n, int64_t lda, int64_t n_logdet, int *info_dev, double *logdet_dev);
 int fvgp_hip_potrs(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb);
 int fvgp_hip_logdet(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *out_host);
 int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *work, int64_t ldw);
@@ -104,11 +108,15 @@ int fvgp_hip_trsm_lower_t(fvgp_handle *h, const double *L, int64_t n, int64_t ld
  * panel_trsm   : P (rows, nd) <- P * L_D^-T with D the factored nd x nd diagonal block (nd % 128 == 0)
  * syrk_rowshard: C[ti][tj] -= A[ti] B[tj]^T for the 128x128 tiles with tj <= ti*scale + off, i.e. the
  *                lower-triangular part of the trailing update restricted to this rank's block rows
- *                (scale = number of ranks, off = global offset of the first local block row);
- *                A (M,K), B (N,K), C (M,N) row-major. */
+ *                (scale = number of ranks, off = global offset of the first local block row, may be < 0);
+ *                A (M,K), B (N,K), C (M,N) row-major.  B may be used as an all-gather leaves it:
+ *                b_ranks chunks of b_blocks 128-row blocks each, chunk q holding the cyclic blocks
+ *                q, q + b_ranks, ...; tile column tj reads cyclic block tj + b_off
+ *                (b_ranks = 1, b_off = 0: plain row order). */
 int fvgp_hip_panel_trsm(fvgp_handle *h, const double *D, int64_t nd, int64_t ldd, double *P, int64_t rows, int64_t ldp);
 int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
-                            const double *B, int64_t ldb, double *C, int64_t ldc, int scale, int off);
+                            const double *B, int64_t ldb, double *C, int64_t ldc, int scale, int off,
+                            int b_ranks, int b_blocks, int b_off);
 
 /* ---- fused evaluations ----------------------------------------------------------------
  * loglik: GPMarginalLikelihood.log_likelihood(theta)  gp_marginal_likelihood.py:137-179
@@ -155,7 +163,7 @@ int fvgp_hip_mfma_selftest(fvgp_handle *h, const double *A16x4, const double *B4
 /* host-only replay of the GEMM kernel's blockIdx -> (tile row, tile col) map, XCD remap included
  * (no GPU needed); returns the grid size, fills min(grid, cap) entries; out-of-range tiles are
  * the ones the kernel exits on. */
-int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int *out_ti, int *out_tj, int64_t cap);
+int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int scale, int off, int *out_ti, int *out_tj, int64_t cap);
 /* diagnostic: blocks x 256 threads each issue iters x 16 register-only fp64 MFMAs (2048 flop each per wave);
  * out needs blocks*256 doubles.  Gives the sustained fp64 MFMA ceiling of the device. */
 int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);

@@ -3,6 +3,8 @@
 Same method surface, plain torch/numpy arithmetic (kernels from the oracle), so the partition and
 collective logic of ShardedGP can run under gloo on a machine without a GPU.  Never imported by
 the package."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -14,8 +16,20 @@ NAMES = {0: "rbf_ard", 1: "matern32_ard", 2: "matern52_ard", 3: "rbf_iso", 4: "m
 class StubOps:
     torch = torch
 
-    def zeros(self, *shape):
-        return torch.zeros(*shape, dtype=torch.float64)
+    def __init__(self):
+        self.chain = self                      # no streams on the CPU: the chain runs in program order
+
+    def stream(self):
+        return contextlib.nullcontext()
+
+    def fork(self):
+        pass
+
+    def join(self):
+        pass
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=dtype or torch.float64)
 
     def to_device(self, a):
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64))
@@ -27,28 +41,27 @@ class StubOps:
         out[:r, :c] = 0.0
         out[:k.shape[0], :k.shape[1]] = torch.as_tensor(k)
 
-    def potrf(self, D, n):
-        L, info = torch.linalg.cholesky_ex(torch.tril(D[:n, :n]) + torch.tril(D[:n, :n], -1).T)
+    def potrf_dev(self, D, n, n_logdet, info_dev, logdet_dev):
+        M = torch.tril(D[:n, :n]) + torch.tril(D[:n, :n], -1).T
+        L, info = torch.linalg.cholesky_ex(M)
+        info_dev[0] = int(info)
         if int(info) != 0:
-            return int(info)
+            D[:n, :n] = float("nan")
+            return
         D[:n, :n] = torch.tril(L) + torch.triu(D[:n, :n], 1)       # strict upper left as is (unspecified)
-        return 0
+        logdet_dev[0] = 2.0 * torch.log(torch.diagonal(L)[:n_logdet]).sum()
 
     def panel_trsm(self, D, nd, Pm, rows):
         L = torch.tril(D[:nd, :nd])
         Pm[:rows, :nd] = torch.linalg.solve_triangular(L, Pm[:rows, :nd].T, upper=False).T
 
-    def syrk_rowshard(self, M, N, K, A, B, C, scale, off):
+    def syrk_rowshard(self, M, N, K, A, B, C, scale, off, b_ranks=1, b_blocks=0, b_off=0):
         for ti in range(M // 128):
             for tj in range(N // 128):
                 if tj <= ti * scale + off:
-                    C[ti * 128:(ti + 1) * 128, tj * 128:(tj + 1) * 128] -= A[ti * 128:(ti + 1) * 128, :K] @ B[tj * 128:(tj + 1) * 128, :K].T
-
-    def trsm_lower(self, D, n, B, nrhs):
-        B[:n, :nrhs] = torch.linalg.solve_triangular(torch.tril(D[:n, :n]), B[:n, :nrhs], upper=False)
-
-    def gemm_nn_sub(self, M, N, K, A, B, C):
-        C[:M, :N] -= A[:M, :K] @ B[:K, :N]
+                    idx = tj + b_off
+                    rb = (idx % b_ranks) * b_blocks + idx // b_ranks
+                    C[ti * 128:(ti + 1) * 128, tj * 128:(tj + 1) * 128] -= A[ti * 128:(ti + 1) * 128, :K] @ B[rb * 128:(rb + 1) * 128, :K].T
 
     def sync(self):
         pass

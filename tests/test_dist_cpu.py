@@ -68,7 +68,8 @@ def _run_file(world, tmp_path, **kw):
 
 
 @pytest.mark.parametrize("world,n,panel,kernel,ncol", [(2, 700, 256, "rbf_ard", 1), (3, 900, 128, "matern52_ard", 1),
-                                                       (2, 1100, 384, "matern32_ard", 2)])
+                                                       (2, 1100, 384, "matern32_ard", 2), (4, 1300, 256, "rbf_ard", 1),
+                                                       (4, 300, 128, "rbf_ard", 1)])
 def test_sharded_loglik_equals_dense(tmp_path, world, n, panel, kernel, ncol):
     d = 3
     theta = [1.0, 0.3, 0.35, 0.4]
@@ -95,3 +96,16 @@ def test_single_rank_stub_path():
     np.testing.assert_allclose(ll, ref.log_likelihood(), rtol=1e-11)
     # block ownership bookkeeping
     assert gp.nblk == 4 and gp.nb_loc == 4 and gp.nv == n
+
+
+def test_sharded_non_positive_definite_raises():
+    """info travels on the device until the single read-back; the failing minor is reported in global rows."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_stub_ops import StubOps
+    from fvgp_amd.dist import ShardedGP
+    n = 600
+    x, y = synth(n, 2)
+    nv = np.full(n, 0.02); nv[300:] = -3.0
+    gp = ShardedGP(x, y, nv, kernel="rbf_ard", ops=StubOps(), panel=256, rank=0, world=1)
+    with pytest.raises(np.linalg.LinAlgError, match="leading minor"):
+        gp.log_likelihood(np.array([1.0, 0.3, 0.5]))

@@ -303,3 +303,74 @@ def test_loglik_matches_oracle_medium(H):
     ll, logdet, quad, info = H.loglik(0, H.to_device(x), theta, H.to_device(nv), H.to_device(ym), KV, alpha)
     assert info == 0
     np.testing.assert_allclose(ll, ref, rtol=1e-10)
+
+
+# ---- row-sharded building blocks (fvgp_amd/dist.py) ------------------------------------------------
+
+@pytest.mark.parametrize("ranks,off,b_off", [(1, 0, 0), (3, 2, 4), (2, -3, 1)])
+def test_syrk_rowshard_predicate_and_gathered_operand(H, ranks, off, b_off):
+    """C[ti][tj] -= A[ti] B[blk(tj)]^T exactly on the tiles tj <= ti*ranks + off, with B read in the order an
+    all-gather leaves it (chunk q = cyclic blocks q, q+ranks, ..)."""
+    rng = np.random.default_rng(5)
+    tm, tn, K = 3, 7, 256
+    b_blocks = -(-(b_off + tn) // ranks)
+    A = rng.standard_normal((tm * 128, K))
+    Bc = rng.standard_normal(((b_off + tn + ranks) * 128, K))          # blocks in cyclic (global) order
+    Bg = np.zeros((ranks * b_blocks * 128, K))                            # as gathered
+    for idx in range(ranks * b_blocks):
+        if (idx + 1) * 128 <= Bc.shape[0]:
+            q, j = idx % ranks, idx // ranks
+            Bg[(q * b_blocks + j) * 128:(q * b_blocks + j + 1) * 128] = Bc[idx * 128:(idx + 1) * 128]
+    C0 = rng.standard_normal((tm * 128, tn * 128))
+    Cd = H.to_device(C0)
+    H.syrk_rowshard(tm * 128, tn * 128, K, H.to_device(A), H.to_device(Bg), Cd, ranks, off, ranks, b_blocks if ranks > 1 else 0, b_off)
+    H.sync()
+    want = C0.copy()
+    for ti in range(tm):
+        for tj in range(tn):
+            if tj <= ti * ranks + off:
+                blk = Bc[(tj + b_off) * 128:(tj + b_off + 1) * 128]
+                want[ti * 128:(ti + 1) * 128, tj * 128:(tj + 1) * 128] -= A[ti * 128:(ti + 1) * 128] @ blk.T
+    got = Cd.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)
+    untouched = np.ones_like(C0, dtype=bool)
+    for ti in range(tm):
+        for tj in range(tn):
+            if tj <= ti * ranks + off:
+                untouched[ti * 128:(ti + 1) * 128, tj * 128:(tj + 1) * 128] = False
+    assert np.array_equal(got[untouched], C0[untouched])                  # tiles outside the predicate: bit-identical
+
+
+def test_syrk_rowshard_rejects_columns_past_the_gather(H):
+    from fvgp_amd._lib import HipExtensionError
+    Z = H.zeros(128, 512)
+    with pytest.raises(HipExtensionError):
+        H.syrk_rowshard(128, 512, 128, H.zeros(128, 128), H.zeros(2 * 128, 128), Z, 2, 0, 2, 1, 0)   # 4 tile cols, 2 blocks
+
+
+def test_potrf_dev_and_panel_trsm(H):
+    """enqueue-only potrf (info / log-det stay on the device) and the panel solve X = P L^-T."""
+    import torch
+    rng = np.random.default_rng(9)
+    n = 384
+    G = rng.standard_normal((n, n))
+    S = G @ G.T + n * np.eye(n)
+    Dd = H.to_device(S)
+    info = torch.full((1,), 7, dtype=torch.int32, device="cuda:0")
+    ld = H.zeros(1)
+    H.potrf_dev(Dd, n, n - 5, info, ld)
+    Pm = rng.standard_normal((256, n))
+    Pd = H.to_device(Pm)
+    H.panel_trsm(Dd, n, Pd, 256)
+    H.sync()
+    L = np.linalg.cholesky(S)
+    assert int(info.item()) == 0
+    np.testing.assert_allclose(np.tril(Dd.cpu().numpy()), L, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(float(ld.item()), 2 * np.log(np.diag(L)[:n - 5]).sum(), rtol=1e-12)
+    np.testing.assert_allclose(Pd.cpu().numpy(), sla.solve_triangular(L, Pm.T, lower=True).T, rtol=1e-10, atol=1e-12)
+    # not positive definite: info = order of the failing minor, on the device
+    S2 = S.copy(); S2[200, 200] = -1.0
+    D2 = H.to_device(S2)
+    H.potrf_dev(D2, n, n, info, ld)
+    H.sync()
+    assert int(info.item()) == 201

@@ -57,25 +57,32 @@ def test_cpu_device_is_refused():
                     noise_function=lambda x, h: np.ones(len(x)))
 
 
-@pytest.mark.parametrize("tm,tn,lower", [(1, 1, 0), (3, 1, 0), (391, 1, 0), (5, 3, 1), (12, 3, 1), (8, 8, 1), (9, 9, 1),
-                                         (23, 23, 1), (40, 16, 1), (17, 5, 0), (16, 24, 0), (391, 391, 1), (100, 7, 1)])
-def test_gemm_tile_map_covers_each_tile_once(L, tm, tn, lower):
+@pytest.mark.parametrize("case", [(1, 1, 0), (3, 1, 0), (391, 1, 0), (5, 3, 1), (12, 3, 1), (8, 8, 1), (9, 9, 1),
+                                         (23, 23, 1), (40, 16, 1), (17, 5, 0), (16, 24, 0), (391, 391, 1), (100, 7, 1),
+                                         # row-sharded predicate tj <= ti*scale + off (lower = 2)
+                                         (49, 383, 2, 8, 3), (50, 391, 2, 8, -5), (391, 383, 2, 1, 0), (13, 8, 2, 2, -9),
+                                         (3, 5, 2, 4, 0), (20, 100, 2, 3, -70)])
+def test_gemm_tile_map_covers_each_tile_once(L, case):
     """The blockIdx -> tile map (8xSN super-tiles + XCD remap) must hit every wanted tile exactly once."""
+    tm, tn, lower, scale, off = (tuple(case) + (1, 0))[:5]
     cap = 400000
     ti = (ctypes.c_int * cap)(); tj = (ctypes.c_int * cap)()
-    nwg = L.fvgp_hip_debug_tile_map(tm, tn, lower, ti, tj, cap)
-    assert 0 < nwg <= cap
+    nwg = L.fvgp_hip_debug_tile_map(tm, tn, lower, scale, off, ti, tj, cap)
+    assert 0 <= nwg <= cap
+    keep = (lambda i, j: True) if lower == 0 else (lambda i, j: j <= i) if lower == 1 else (lambda i, j: j <= i * scale + off)
     got = {}
     for b in range(nwg):
         i, j = ti[b], tj[b]
-        if i >= tm or j >= tn or (lower and j > i):
+        if i >= tm or j >= tn or not keep(i, j):
             continue
         assert (i, j) not in got, f"tile {(i, j)} mapped twice"
         got[(i, j)] = b
-    want = {(i, j) for i in range(tm) for j in range(tn) if not lower or j <= i}
+    want = {(i, j) for i in range(tm) for j in range(tn) if keep(i, j)}
     assert set(got) == want
+    if lower == 2 and want:
+        assert nwg <= 2 * len(want) + 64 * ((tm + 7) // 8)       # the grid carries no dead half
     # blocks b and b+8 share an XCD: their tiles should be neighbours in the enumeration
-    if nwg >= 64 and tn >= 8:
+    if nwg >= 64 and tn >= 8 and lower != 2:
         i0, j0, i1, j1 = ti[0], tj[0], ti[8], tj[8]
         assert abs(i0 - i1) <= 8 and abs(j0 - j1) <= 8
 
