@@ -9,7 +9,9 @@ covariance assembly (+noise) -> blocked Cholesky -> two triangular solves -> log
 
 N > 1: every rank evaluates its own theta sequence on its own GPU (independent replicas of the
 population of hyperparameter proposals a trainer evaluates -- SURVEY 8e "replicas-only"); no
-data-path collective, "scaling": "weak".  Rank 0 prints ONE JSON line.
+data-path collective, "scaling": "weak".  After the timed region the same workload is also run as ONE
+evaluation row-sharded over the ranks (block-cyclic rows, RCCL all-gather of panel factors) and reported
+under "sharded"; `--mode sharded` makes that the headline instead.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -61,8 +63,9 @@ def cpu_baseline(n_full, d, sample_n):
     }
 
 
-def sharded_main(args, x, y, world, rank, local, dist):
-    """One evaluation at a time, K+V row-sharded over the ranks (fvgp_amd/dist.py)."""
+def sharded_measure(args, x, y, world, rank, local, dist, steps, warmup, check_theta=None, check_value=None):
+    """One evaluation at a time, K+V row-sharded over the ranks (fvgp_amd/dist.py).  Returns (on every rank)
+    the timing of `steps` evaluations after `warmup`, max over ranks."""
     import torch
     from fvgp_amd.dist import ShardedGP
     n, d = args.n, args.d
@@ -76,30 +79,51 @@ def sharded_main(args, x, y, world, rank, local, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for t in range(args.warmup):
+    for t in range(warmup):
         gp.log_likelihood(theta0 * (1.0 + 0.02 * t))
     sync_all()
     t0 = time.perf_counter()
-    for t in range(args.steps):
-        ll, logdet, quad = gp.log_likelihood(theta0 * (1.0 + 0.02 * (args.warmup + t)))
+    for t in range(steps):
+        ll, logdet, quad = gp.log_likelihood(theta0 * (1.0 + 0.02 * (warmup + t)))
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    gathered = 0.0                                                   # bytes every rank receives per evaluation
+    if world > 1:
+        for J in range(gp.npan - 1):
+            k = (gp.nb_max - gp.bnd[J + 1] // 128 // world) * 128
+            gathered += 8.0 * (world - 1) * k * (gp.bnd[J + 1] - gp.bnd[J])
+    extra = {}
+    if check_theta is not None:                                      # same theta as a single-GPU evaluation of this run
+        ll_c, _, _ = gp.log_likelihood(check_theta)
+        if check_value is not None:
+            extra = {"loglik_at_check_theta": ll_c, "single_gpu_loglik_at_check_theta": check_value,
+                     "rel_diff_vs_single_gpu": abs(ll_c - check_value) / abs(check_value)}
+    return {**extra, "evals_per_s": steps / elapsed, "ms_per_eval": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
+            "tflops_per_gpu": steps * (n ** 3) / 3.0 / elapsed / 1e12 / world, "loglik_last": ll,
+            "panel": gp.NB, "all_gather_bytes_per_rank_per_eval": gathered,
+            "parallelism": f"block-cyclic 128-row blocks over {world} GPU(s), per panel: all-reduce of the diagonal "
+                           f"block, RCCL all-gather of the panel factor, one panel of look-ahead"}
+
+
+def sharded_main(args, x, y, world, rank, local, dist):
+    n, d = args.n, args.d
+    r = sharded_measure(args, x, y, world, rank, local, dist, args.steps, args.warmup)
     if rank == 0:
-        potrf_tflops = args.steps * (n ** 3) / 3.0 / elapsed / 1e12
         out = {
-            "metric": "log_marginal_likelihood_evals_per_sec", "value": args.steps / elapsed, "unit": "evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "metric": "log_marginal_likelihood_evals_per_sec", "value": r["evals_per_s"], "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_eval"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N={n} d={d} RBF(ARD) log_likelihood(theta), one evaluation row-sharded over the GPUs",
-                       "n": n, "d": d, "kernel": "rbf_ard", "parallelism": f"block-cyclic rows over {world} GPU(s), panel all-gather"},
-            "whole_eval_tflops_equiv": potrf_tflops, "loglik_last": ll,
+                       "n": n, "d": d, "kernel": "rbf_ard", "parallelism": r["parallelism"]},
+            "whole_eval_tflops_equiv": r["tflops_per_gpu"] * world, "loglik_last": r["loglik_last"],
+            "all_gather_bytes_per_rank_per_eval": r["all_gather_bytes_per_rank_per_eval"],
             "roofline": {"kernel": "gemm_f64_kernel<0, 0, 1> (row-sharded trailing update)", "bound": "mfma",
-                         "achieved": potrf_tflops / world, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": potrf_tflops / world / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "achieved": r["tflops_per_gpu"], "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": r["tflops_per_gpu"] / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                          "note": "whole-evaluation N^3/3 flops per GPU-second (collectives and solves included)"},
         }
         print(json.dumps(out))
@@ -113,13 +137,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=50000)
+    ap.add_argument("--n", "--npoints", dest="n", type=int, default=50000, help="data points (use --npoints under torchrun: its parser claims --n)")
     ap.add_argument("--d", type=int, default=3)
     ap.add_argument("--outer-block", type=int, default=0, help="K of the trailing SYRK (0 = library default)")
     ap.add_argument("--lookahead", type=int, default=-1, help="1/0: factor the next panel on a side stream (-1 = library default)")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="N>1: independent replicas (one theta stream per GPU, default) or ONE evaluation row-sharded "
                          "over the GPUs (block-cyclic rows, RCCL all-gather of panel factors; strong scaling)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for tests that "
+                                                      "put several ranks on one GPU)")
+    ap.add_argument("--no-sharded", action="store_true",
+                    help="N>1, replicas mode: skip the extra row-sharded measurement reported under \"sharded\"")
+    ap.add_argument("--sharded-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-sample-n", type=int, default=18000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -129,7 +158,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("FVGP_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # FVGP_DEVICE: ranks sharing a GPU (tests)
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -139,7 +168,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     n, d = args.n, args.d
     x, y = synth(n, d)
@@ -221,7 +253,46 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_sample_n)
-        print(json.dumps(out))
+    else:
+        out = None
+
+    # N > 1: the same workload once more as ONE evaluation row-sharded over the ranks (the partitioning the
+    # north star names), outside the timed region above, reported under "sharded".  A watchdog prints the line
+    # without it if the collectives do not come back, so the headline number can never be lost to this leg.
+    if world > 1 and not args.no_sharded:
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(args.sharded_timeout):
+                if rank == 0 and out is not None:
+                    out["sharded"] = {"error": f"no result within {args.sharded_timeout:.0f} s"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            del KV, alpha
+            torch.cuda.empty_cache()
+            sh = sharded_measure(args, x, y, world, rank, local, dist, steps=3, warmup=1,
+                                 check_theta=theta0 * (1.0 + 0.02 * ((args.warmup + args.steps - 1) * world)),
+                                 check_value=ll if rank == 0 else None)
+        except Exception as e:                                  # noqa: BLE001 -- reported, not swallowed
+            sh = {"error": repr(e)[:300]}
+        if rank == 0:
+            out["sharded"] = sh
+            print(json.dumps(out), flush=True)
+            out = None
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        done.set()
+        H.close()
+        return
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

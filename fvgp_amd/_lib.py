@@ -23,7 +23,7 @@ MAX_RHS_VEC = 8
 # every symbol include/fvgp_hip.h declares (tests check the library exports each of them)
 SYMBOLS = [
     "fvgp_hip_version", "fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_create",
-    "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
+    "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_stream_create", "fvgp_hip_stream_destroy", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize",
@@ -78,6 +78,8 @@ def lib():
     L.fvgp_hip_create.argtypes = [ctypes.POINTER(c_p), c_i, c_p]
     L.fvgp_hip_destroy.argtypes = [c_p]
     L.fvgp_hip_sync.argtypes = [c_p]
+    L.fvgp_hip_stream_create.argtypes = [ctypes.POINTER(c_p), c_i, c_i, ctypes.POINTER(ctypes.c_uint32), c_i]
+    L.fvgp_hip_stream_destroy.argtypes = [c_p]
     L.fvgp_hip_set_option.argtypes = [c_p, ctypes.c_char_p, c_l]
     L.fvgp_hip_get_profile.argtypes = [c_p, P_d]
     L.fvgp_hip_kmat.argtypes = [c_p, c_i, c_p, c_l, c_p, c_l, c_i, P_d, c_i, c_p, c_p, c_l, c_i, c_i]
@@ -121,6 +123,25 @@ def _theta(theta):
 def _ptr(t):
     """device pointer of a torch tensor (or None)."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def create_stream(device, cu_mask=None, high_priority=False):
+    """hipStream_t (as int) from fvgp_hip_stream_create: restricted to the CUs in `cu_mask` (iterable of CU
+    indices) or an ordinary non-blocking stream."""
+    out = ctypes.c_void_p()
+    if cu_mask is None:
+        _check(lib().fvgp_hip_stream_create(ctypes.byref(out), int(device), int(high_priority), None, 0), "fvgp_hip_stream_create")
+    else:
+        words = [0] * 8
+        for cu in cu_mask:
+            words[cu // 32] |= 1 << (cu % 32)
+        arr = (ctypes.c_uint32 * 8)(*words)
+        _check(lib().fvgp_hip_stream_create(ctypes.byref(out), int(device), 0, arr, 8), "fvgp_hip_stream_create")
+    return out.value
+
+
+def destroy_stream(stream):
+    _check(lib().fvgp_hip_stream_destroy(ctypes.c_void_p(stream)), "fvgp_hip_stream_destroy")
 
 
 class Handle:

@@ -53,6 +53,28 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     return 0;
 }
 
+int fvgp_hip_stream_create(void **out_stream, int device, int high_priority, const uint32_t *cu_mask, int mask_words) {
+    if (!out_stream) return -1;
+    if (cu_mask && mask_words < 1) return -5;
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    if (cu_mask) {
+        HIPCHK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask));
+    } else {
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? hi : lo));
+    }
+    *out_stream = s;
+    return 0;
+}
+
+int fvgp_hip_stream_destroy(void *stream) {
+    if (!stream) return -1;
+    HIPCHK(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int fvgp_hip_sync(fvgp_handle *h) {
     if (!h) return -1;
     HIPCHK(hipStreamSynchronize(h->stream));

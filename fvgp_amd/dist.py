@@ -39,17 +39,40 @@ class HipOps:
     operations bound to a second, high-priority stream: the panel chain (diagonal-block factorisation, panel
     solve, all-gather) runs there while the main stream applies the previous panel to the trailing matrix."""
 
-    def __init__(self, handle=None, _stream=None, _main=None):
+    def __init__(self, handle=None, reserve_cus=0, n_cus=256, _stream=None):
+        """reserve_cus > 0 (a multiple of 8): the chain gets that many compute units of its own and the main
+        stream the rest, through CU-masked streams -- worth it once the panel chain, not the trailing update,
+        is the critical path (many ranks, small local matrices).  Mask bit i is CU i/8 of XCD i%8 on this part
+        (tools/cu_mask_probe.hip), so the last reserve_cus bits take reserve_cus/8 CUs from every XCD and
+        both streams keep all eight L2s."""
         from .device import default_handle, local_device
         torch = self.torch = __import__("torch")
-        if _stream is None:
+        if _stream is not None:                                    # the chain-side twin
+            self.H, self._stream, self.chain = handle, _stream, self
+            return
+        self._owned = []
+        if reserve_cus > 0:
+            dev = handle.device if handle is not None else local_device()
+            assert reserve_cus % 8 == 0 and 0 < reserve_cus < n_cus
+            side_cus = list(range(n_cus - reserve_cus, n_cus))
+            main_cus = sorted(set(range(n_cus)) - set(side_cus))
+            sm = _lib.create_stream(dev, cu_mask=main_cus)
+            ss = _lib.create_stream(dev, cu_mask=side_cus)
+            self._owned = [sm, ss]
+            self._stream = torch.cuda.ExternalStream(sm, device=dev)
+            side = torch.cuda.ExternalStream(ss, device=dev)
+            self.H = _lib.Handle(dev, stream=sm)
+        else:
             self.H = handle or default_handle()
             self._stream = torch.cuda.current_stream(self.H.device)
             side = torch.cuda.Stream(device=self.H.device, priority=-1)
-            self.chain = HipOps(_lib.Handle(self.H.device, stream=side.cuda_stream), _stream=side, _main=self)
-        else:
-            self.H, self._stream, self.chain = handle, _stream, self
-            self._main = _main
+        self.chain = HipOps(_lib.Handle(self.H.device, stream=side.cuda_stream), _stream=side)
+
+    def close(self):
+        self.torch.cuda.synchronize(self.H.device)
+        for st in getattr(self, "_owned", []):
+            _lib.destroy_stream(st)
+        self._owned = []
 
     def stream(self):
         """context in which torch's own work (copies, collectives) lands on this object's stream"""
@@ -157,7 +180,7 @@ class ShardedGP:
         if self.P > 1:
             self._send = o.zeros(self.nb_max * TILE * self.NB)
             self._recv = [o.zeros(self.P * self.nb_max * TILE * self.NB) for _ in range(2)]
-        self._into_tensor = self.P > 1 and dist.get_backend(group) == "nccl"
+        self._into_tensor = self.P > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl"
 
     # -- collectives (no-ops on one rank) ---------------------------------------------------------
     def _all_reduce(self, t):
@@ -255,10 +278,11 @@ class ShardedGP:
         """GPMarginalLikelihood.log_likelihood(theta) (gp_marginal_likelihood.py:137-179) on the sharded matrix.
         Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated on every rank."""
         torch = self.torch
-        self.assemble(theta)
-        self.factor()
-        z = self.A[self.zrow:self.zrow + self.ncol, :self.n]
-        out = torch.cat([(z * z).sum().reshape(1), self.ld_dev.sum().reshape(1), self.info_dev.to(torch.float64)]).cpu().numpy()
+        with self.ops.stream():
+            self.assemble(theta)
+            self.factor()
+            z = self.A[self.zrow:self.zrow + self.ncol, :self.n]
+            out = torch.cat([(z * z).sum().reshape(1), self.ld_dev.sum().reshape(1), self.info_dev.to(torch.float64)]).cpu().numpy()
         bad = np.nonzero(out[2:])[0]
         if len(bad):
             J = int(bad[0])

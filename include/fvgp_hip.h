@@ -61,6 +61,11 @@ int64_t fvgp_hip_padded_dim(int64_t n);
 int fvgp_hip_create(fvgp_handle **out, int device, void *stream);
 int fvgp_hip_destroy(fvgp_handle *h);
 int fvgp_hip_sync(fvgp_handle *h);
+/* a stream restricted to the compute units whose bits are set in cu_mask (mask_words x 32 bits), or an
+ * ordinary non-blocking stream (high_priority 0/1) when cu_mask is NULL.  The row-sharded driver gives
+ * the panel chain a few CUs of its own so its small kernels never queue behind the trailing update. */
+int fvgp_hip_stream_create(void **out_stream, int device, int high_priority, const uint32_t *cu_mask, int mask_words);
+int fvgp_hip_stream_destroy(void *stream);
 /* keys: "outer_block" (panel width = K of the trailing update, multiple of 128; default 1024),
  *       "outer_block_big" / "big_threshold" (optional wider panels while more rows than the threshold remain),
  *       "lookahead" (0/1: factor the next panel on a high-priority side stream under the trailing update),

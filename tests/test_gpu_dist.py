@@ -68,3 +68,40 @@ def test_ranks_sharing_one_gpu_over_gloo(tmp_path, world, n, panel):
     for t, (ll, logdet, quad) in enumerate(out):
         ref, _ = orc.log_likelihood_once(x, y, np.full(n, 0.01), np.array([1.0, 0.3, 0.3, 0.3]) * (1 + 0.02 * t), "rbf_ard")
         np.testing.assert_allclose(ll, ref, rtol=1e-10)
+
+
+def test_reserved_compute_units_give_the_same_numbers():
+    """The chain on its own CU-masked stream (HipOps(reserve_cus=32)) is a scheduling choice only."""
+    from fvgp_amd.dist import ShardedGP, HipOps
+    n = 2500
+    x, y = synth(n, 3)
+    nv = np.full(n, 0.01)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    ops = HipOps(reserve_cus=32)
+    gp = ShardedGP(x, y, nv, kernel="rbf_ard", panel=512, rank=0, world=1, ops=ops)
+    got = [gp.log_likelihood(theta * (1 + 0.05 * t))[0] for t in range(3)]
+    for t, ll in enumerate(got):
+        ref, _ = orc.log_likelihood_once(x, y, nv, theta * (1 + 0.05 * t), "rbf_ard")
+        np.testing.assert_allclose(ll, ref, rtol=1e-10)
+    ops.close()
+
+
+def test_bench_multi_rank_line_carries_the_sharded_leg(tmp_path):
+    """bench.py with 2 ranks (sharing the one GPU over gloo): ONE JSON line, replicas headline + "sharded"
+    whose log-likelihood agrees with the single-GPU evaluation of the same theta."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, FVGP_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--npoints", "5000", "--backend", "gloo"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "cpu_baseline" not in out
+    sh = out["sharded"]
+    assert "error" not in sh, sh
+    assert sh["rel_diff_vs_single_gpu"] < 1e-10
+    assert sh["all_gather_bytes_per_rank_per_eval"] > 0
