@@ -580,6 +580,145 @@ class GP:
         return {"x": x_orig, "x_pred": x_pred, "v(x)": v_re, "S": S_re, "S_flat": S, "v_flat": v}
 
     # ------------------------------------------------------------------------------------------
+    # derivatives built on the path -- finite differences of the same device evaluations, with the
+    # reference's steps (so they agree with it to its own noise level, not beyond)
+    # ------------------------------------------------------------------------------------------
+    def neg_log_likelihood_hessian(self, hyperparameters=None):
+        """fvgp/gp.py, gp_marginal_likelihood.py:312-336: forward difference (1e-6) of the exact gradient."""
+        hps = self._hps if hyperparameters is None else np.asarray(hyperparameters, dtype=np.float64)
+        nh = len(hps)
+        d2 = np.zeros((nh, nh))
+        epsilon = 1e-6
+        g0 = self.neg_log_likelihood_gradient(hyperparameters=hps)
+        for i in range(nh):
+            t = np.array(hps)
+            t[i] = t[i] + epsilon
+            d2[i, i:] = ((self.neg_log_likelihood_gradient(hyperparameters=t) - g0) / epsilon)[i:]
+        return d2 + d2.T - np.diag(np.diag(d2))
+
+    def test_log_likelihood_gradient(self, hyperparameters, epsilon=1e-6):
+        """gp_marginal_likelihood.py:338-364: (forward-difference gradient, analytical gradient) of the log-likelihood."""
+        thps = np.array(hyperparameters, dtype=np.float64)
+        grad = np.empty(len(thps))
+        base = self.log_likelihood(hyperparameters=thps)
+        for i in range(len(thps)):
+            aux = np.array(thps)
+            aux[i] = aux[i] + epsilon
+            grad[i] = (self.log_likelihood(hyperparameters=aux) - base) / epsilon
+        return grad, -self.neg_log_likelihood_gradient(hyperparameters=thps)
+
+    def _cross_dev(self, x_b, hps):
+        """k(x_data, x_b) on the device, (padded N) x (padded P), zero padding."""
+        H, n = self._H, self.point_number
+        P = len(x_b)
+        kx = H.empty(self._np, _lib.pad128(P))
+        if self._native is not None:
+            H.kmat(self._native.kernel_id, self._x_dev, H.to_device(x_b), hps, kx, pad=_lib.PAD_ZERO)
+        else:
+            kx.zero_()
+            kx[:n, :P] = H.to_device(self._host_kernel(self.x_data, x_b, hps))
+        return kx
+
+    def _kk_host(self, x_b, hps):
+        """k(x_b, x_b) as a host array (P x P)."""
+        if self._native is None:
+            return self._host_kernel(x_b, x_b, hps)
+        H = self._H
+        P = len(x_b)
+        xb = H.to_device(x_b)
+        buf = H.empty(P, P + (P & 1))
+        H.kmat(self._native.kernel_id, xb, xb, hps, buf)
+        H.sync()
+        return buf[:, :P].cpu().numpy()
+
+    def posterior_mean_grad(self, x_pred, hyperparameters=None, x_out=None, direction=None, component=0):
+        """fvgp/gp.py, gp_posterior.py:184-226: dm/dx = d(prior mean)/dx (step 1e-6) + dk/dx^T KVinvY with the
+        kernel derivative taken by a forward difference of step 1e-8 (gp_prior.py:402-409).  By linearity
+        dk/dx^T KVinvY is the same difference of two device evaluations of k^T KVinvY."""
+        L, alpha, hps = self._L, self._alpha, self._hps
+        if hyperparameters is not None:
+            hps = np.asarray(hyperparameters, dtype=np.float64)
+            L, alpha = self._scratch()
+            self._evaluate(hps, L, alpha)
+        if x_out is None:
+            x_out = self.x_out
+        self._perform_input_checks(x_pred, x_out)
+        x_orig = x_pred.copy()
+        if isinstance(x_out, np.ndarray):
+            x_pred = self.cartesian_product(x_pred, x_out)
+        f = self._mean(x_pred, hps)
+        eps = 1e-6
+        A0 = self._posterior_device(x_pred, hps, L, alpha, want_cov=False)[0][:, component]
+
+        def one(dd):
+            x1 = np.array(x_pred)
+            x1[:, dd] = x1[:, dd] + eps
+            mean_der = (self._mean(x1, hps) - f) / eps
+            xk = np.array(x_pred)
+            xk[:, dd] += 1e-8
+            A1 = self._posterior_device(xk, hps, L, alpha, want_cov=False)[0][:, component]
+            return mean_der + (A1 - A0) / 1e-8
+
+        if direction is not None:
+            g = one(direction)
+            if isinstance(x_out, np.ndarray):
+                g = g.reshape(len(x_orig), len(x_out), order='F')
+        else:
+            g = np.zeros((len(x_pred), x_orig.shape[1]))
+            for dd in range(len(x_orig[0])):
+                g[:, dd] = one(dd)
+            direction = "ALL"
+            if isinstance(x_out, np.ndarray):
+                g = g.reshape(len(x_orig), len(x_orig[0]), len(x_out), order='F')
+        return {"x": x_orig, "direction": direction, "dm/dx": g}
+
+    def posterior_covariance_grad(self, x_pred, x_out=None, direction=None):
+        """fvgp/gp.py, gp_posterior.py:290-331: dS/dx = dkk/dx (step 1e-6) - 2 dk/dx^T KV^-1 k (kernel step 1e-8).
+        KV^-1 k is one device solve; the two cross products run on the MFMA GEMM."""
+        H, n = self._H, self.point_number
+        if x_out is None:
+            x_out = self.x_out
+        self._perform_input_checks(x_pred, x_out)
+        x_orig = x_pred.copy()
+        if isinstance(x_out, np.ndarray):
+            x_pred = self.cartesian_product(x_pred, x_out)
+        hps = self._hps
+        P = len(x_pred)
+        Pp = _lib.pad128(P)
+        k0 = self._cross_dev(x_pred, hps)
+        W = k0.clone()
+        H.potrs(self._L, n, W, Pp)                                   # KV^-1 k
+        kk0 = self._kk_host(x_pred, hps)
+        C = H.empty(Pp, Pp)
+        eps = 1e-6
+
+        def dS(dd):
+            xk = np.array(x_pred)
+            xk[:, dd] += 1e-8
+            k1 = self._cross_dev(xk, hps)
+            H.gemm(1, 1, 0, Pp, Pp, self._np, 1.0 / 1e-8, k1, W, 0.0, C)          # (k1 - k0)^T W / 1e-8
+            H.gemm(1, 1, 0, Pp, Pp, self._np, -1.0 / 1e-8, k0, W, 1.0, C)
+            H.sync()
+            x1 = np.array(x_pred)
+            x1[:, dd] = x1[:, dd] + eps
+            kk_g = (self._kk_host(x1, hps) - kk0) / eps
+            return kk_g - 2.0 * C[:P, :P].cpu().numpy()
+
+        if direction is not None:
+            dSdx = dS(direction)
+            a = np.diag(dSdx)
+            if isinstance(x_out, np.ndarray):
+                a = a.reshape(len(x_orig), len(x_out), order='F')
+                dSdx = dSdx.reshape(len(x_orig), len(x_orig), len(x_out), len(x_out), order='F')
+            return {"x": x_orig, "dv/dx": a, "dS/dx": dSdx}
+        grad_v = np.zeros((len(x_pred), len(x_orig[0])))
+        for dd in range(len(x_orig[0])):
+            grad_v[:, dd] = np.diag(dS(dd))
+        if isinstance(x_out, np.ndarray):
+            grad_v = grad_v.reshape(len(x_orig), len(x_orig[0]), len(x_out), order='F')
+        return {"x": x_orig, "dv/dx": grad_v}
+
+    # ------------------------------------------------------------------------------------------
     # training: the callers of the path (SURVEY 8f1) -- device-resident objective, host optimiser
     # ------------------------------------------------------------------------------------------
     def train(self, hyperparameter_bounds=None, init_hyperparameters=None, method="mcmc", pop_size=20,

@@ -409,6 +409,108 @@ class OracleGP:
         return {"x": x_orig, "x_pred": x_pred, "v(x)": v_re, "S": S_re, "S_flat": S, "v_flat": v}
 
 
+    # -- derivatives built on the path (all finite-difference based in the reference) -------------------
+    def _d_kernel_dx(self, x1, x2, direction, hps):
+        """fvgp/gp_prior.py:402-409: forward difference, step 1e-8, in coordinate `direction` of x1."""
+        new_points = np.array(x1)
+        epsilon = 1e-8
+        new_points[:, direction] += epsilon
+        return (self.kernel(new_points, x2, hps) - self.kernel(x1, x2, hps)) / epsilon
+
+    def posterior_mean_grad(self, x_pred, hyperparameters=None, x_out=None, direction=None, component=0):
+        """fvgp/gp_posterior.py:184-226."""
+        KVinvY = self.KVinvY[:, component]
+        if hyperparameters is not None:
+            KVinvY = self._new_KVlogdet_KVinvY(np.asarray(hyperparameters))[0][:, component]
+        else:
+            hyperparameters = self.hyperparameters
+        if x_out is None:
+            x_out = self.x_out
+        x_orig = x_pred.copy()
+        if isinstance(x_out, np.ndarray):
+            x_pred = cartesian_product(x_pred, x_out)
+        f = self._mean_at(x_pred, hyperparameters)
+        eps = 1e-6
+
+        def one(direction):
+            x1 = np.array(x_pred)
+            x1[:, direction] = x1[:, direction] + eps
+            mean_der = (self._mean_at(x1, hyperparameters) - f) / eps
+            k_g = self._d_kernel_dx(x_pred, self.x_data, direction, hyperparameters)
+            return mean_der + (k_g @ KVinvY)
+
+        if direction is not None:
+            g = one(direction)
+            if isinstance(x_out, np.ndarray):
+                g = g.reshape(len(x_orig), len(x_out), order='F')
+        else:
+            g = np.zeros((len(x_pred), x_orig.shape[1]))
+            for dd in range(len(x_orig[0])):
+                g[:, dd] = one(dd)
+            direction = "ALL"
+            if isinstance(x_out, np.ndarray):
+                g = g.reshape(len(x_orig), len(x_orig[0]), len(x_out), order='F')
+        return {"x": x_orig, "direction": direction, "dm/dx": g}
+
+    def _mean_at(self, x, hps):
+        return self.mean(x)            # default prior mean (gp_prior.py:449-458): independent of hps and of x
+
+    def posterior_covariance_grad(self, x_pred, x_out=None, direction=None):
+        """fvgp/gp_posterior.py:290-331."""
+        if x_out is None:
+            x_out = self.x_out
+        x_orig = x_pred.copy()
+        if isinstance(x_out, np.ndarray):
+            x_pred = cartesian_product(x_pred, x_out)
+        hps = self.hyperparameters
+        k = self.kernel(self.x_data, x_pred, hps)
+        k_covariance_prod = calculate_Chol_solve(self.Chol_factor, k)
+        eps = 1e-6
+
+        def dS(direction):
+            k_g = self._d_kernel_dx(x_pred, self.x_data, direction, hps).T
+            x1 = np.array(x_pred)
+            x1[:, direction] = x1[:, direction] + eps
+            kk_g = (self.kernel(x1, x1, hps) - self.kernel(x_pred, x_pred, hps)) / eps
+            return kk_g - (2.0 * k_g.T @ k_covariance_prod)
+
+        if direction is not None:
+            dSdx = dS(direction)
+            a = np.diag(dSdx)
+            if isinstance(x_out, np.ndarray):
+                a = a.reshape(len(x_orig), len(x_out), order='F')
+                dSdx = dSdx.reshape(len(x_orig), len(x_orig), len(x_out), len(x_out), order='F')
+            return {"x": x_orig, "dv/dx": a, "dS/dx": dSdx}
+        grad_v = np.zeros((len(x_pred), len(x_orig[0])))
+        for dd in range(len(x_orig[0])):
+            grad_v[:, dd] = np.diag(dS(dd))
+        if isinstance(x_out, np.ndarray):
+            grad_v = grad_v.reshape(len(x_orig), len(x_orig[0]), len(x_out), order='F')
+        return {"x": x_orig, "dv/dx": grad_v}
+
+    def neg_log_likelihood_hessian(self, hyperparameters):
+        """fvgp/gp_marginal_likelihood.py:312-336: forward difference (1e-6) of the exact gradient, symmetrised."""
+        nh = len(hyperparameters)
+        d2 = np.zeros((nh, nh))
+        epsilon = 1e-6
+        g0 = self.neg_log_likelihood_gradient(hyperparameters=hyperparameters)
+        for i in range(nh):
+            t = np.array(hyperparameters)
+            t[i] = t[i] + epsilon
+            d2[i, i:] = ((self.neg_log_likelihood_gradient(hyperparameters=t) - g0) / epsilon)[i:]
+        return d2 + d2.T - np.diag(np.diag(d2))
+
+    def test_log_likelihood_gradient(self, hyperparameters, epsilon=1e-6):
+        """fvgp/gp_marginal_likelihood.py:338-364: (forward-difference gradient, analytical gradient)."""
+        thps = np.array(hyperparameters)
+        grad = np.empty(len(thps))
+        for i in range(len(thps)):
+            aux = np.array(thps)
+            aux[i] = aux[i] + epsilon
+            grad[i] = (self.log_likelihood(hyperparameters=aux) - self.log_likelihood(hyperparameters=thps)) / epsilon
+        return grad, -self.neg_log_likelihood_gradient(hyperparameters=thps)
+
+
 def log_likelihood_once(x, y, noise_variances, hps, kernel="rbf_ard"):
     """One metric unit on the CPU: K-assembly + addKV + potrf + potrs + logdet + scalar.
     Used as bench.py's cpu_baseline ("port").  Returns (value, dict of stage seconds)."""

@@ -286,6 +286,56 @@ def main():
     assert rel(orc.rbf_ard_grad(x1, x2, th3), fd) < 1e-6
     np.savez_compressed(os.path.join(OUT, "G8_iso_and_units.npz"), **fx8)
 
+    # ---- G9: the finite-difference derivatives built on the path --------------------------------------
+    # posterior_mean_grad / posterior_covariance_grad (gp_posterior.py:184-226,290-331),
+    # neg_log_likelihood_hessian / test_log_likelihood_gradient (gp_marginal_likelihood.py:312-364)
+    x, y = synth(256, 2)
+    nv = np.full(256, 0.01)
+    th = np.array([1.1, 0.35, 0.45])
+    gp = fvgp.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function=ref_rbf,
+                 kernel_function_grad=orc.rbf_ard_grad)
+    o = orc.OracleGP(x, y, th, nv, kernel="rbf_ard")
+    xp = np.random.default_rng(99).random((10, 2))
+    th2 = th * 1.03
+    fx9 = {"x": x, "y": y, "noise_variances": nv, "theta": th, "theta2": th2, "x_pred": xp}
+    for tag, a, b in (("dm_all", gp.posterior_mean_grad(xp)["dm/dx"], o.posterior_mean_grad(xp)["dm/dx"]),
+                      ("dm_dir1", gp.posterior_mean_grad(xp, direction=1)["dm/dx"], o.posterior_mean_grad(xp, direction=1)["dm/dx"]),
+                      ("dm_theta2", gp.posterior_mean_grad(xp, hyperparameters=th2)["dm/dx"],
+                       o.posterior_mean_grad(xp, hyperparameters=th2)["dm/dx"]),
+                      ("dv_all", gp.posterior_covariance_grad(xp)["dv/dx"], o.posterior_covariance_grad(xp)["dv/dx"]),
+                      ("dv_dir0", gp.posterior_covariance_grad(xp, direction=0)["dv/dx"],
+                       o.posterior_covariance_grad(xp, direction=0)["dv/dx"]),
+                      ("dS_dir0", gp.posterior_covariance_grad(xp, direction=0)["dS/dx"],
+                       o.posterior_covariance_grad(xp, direction=0)["dS/dx"])):
+        fx9[tag] = np.asarray(a)
+        check("G9." + tag, b, a, 1e-9)
+    fx9["hessian"] = gp.marginal_likelihood.neg_log_likelihood_hessian(hyperparameters=th)
+    check("G9.hessian", o.neg_log_likelihood_hessian(th), fx9["hessian"], 1e-9)
+    fd_g, an_g = gp.test_log_likelihood_gradient(th)
+    fx9["fd_grad"], fx9["an_grad"] = fd_g, an_g
+    ofd, oan = o.test_log_likelihood_gradient(th)
+    check("G9.fd_grad", ofd, fd_g, 1e-9)
+    check("G9.an_grad", oan, an_g, 1e-9)
+    np.savez_compressed(os.path.join(OUT, "G9_derivatives_rbf_n256_d2.npz"), kernel="rbf_ard", **fx9)
+    # multi-task shapes of the same derivatives (x_out reshapes, order='F')
+    gp = fvgp.fvGP(xm, ym, init_hyperparameters=th5, noise_variances=nvm)
+    xt, yt, vt = orc.transform_index_set(xm, ym, nvm)
+    o = orc.OracleGP(xt, yt, th5, vt, kernel="matern32_ard", x_out=x_out)
+    xp5 = np.random.default_rng(98).random((6, 2))
+    fx9m = {"fvgp_x": xm, "fvgp_y": ym, "fvgp_noise": nvm, "theta": th5, "x_pred": xp5, "x_out": x_out}
+    for tag, a, b in (("dm_all", gp.posterior_mean_grad(xp5, x_out=x_out)["dm/dx"], o.posterior_mean_grad(xp5, x_out=x_out)["dm/dx"]),
+                      ("dm_dir0", gp.posterior_mean_grad(xp5, x_out=x_out, direction=0)["dm/dx"],
+                       o.posterior_mean_grad(xp5, x_out=x_out, direction=0)["dm/dx"]),
+                      ("dv_all", gp.posterior_covariance_grad(xp5, x_out=x_out)["dv/dx"],
+                       o.posterior_covariance_grad(xp5, x_out=x_out)["dv/dx"]),
+                      ("dv_dir1", gp.posterior_covariance_grad(xp5, x_out=x_out, direction=1)["dv/dx"],
+                       o.posterior_covariance_grad(xp5, x_out=x_out, direction=1)["dv/dx"]),
+                      ("dS_dir1", gp.posterior_covariance_grad(xp5, x_out=x_out, direction=1)["dS/dx"],
+                       o.posterior_covariance_grad(xp5, x_out=x_out, direction=1)["dS/dx"])):
+        fx9m[tag] = np.asarray(a)
+        check("G9m." + tag, b, a, 1e-9)
+    np.savez_compressed(os.path.join(OUT, "G9m_derivatives_fvgp_4x64.npz"), kernel="matern32_ard", **fx9m)
+
     print(f"{'check':32s} {'rel.diff':>10s} {'tol':>8s}")
     for tag, r, tol in report:
         print(f"{tag:32s} {r:10.2e} {tol:8.0e}")

@@ -121,3 +121,30 @@ def test_multitask_transform():
     assert len(xt) == 4 * 64 - 2
     cp = orc.cartesian_product(fx["x_pred"], fx["x_out"])
     assert np.array_equal(cp, fx["pm_xpred"])
+
+
+def test_finite_difference_derivatives_match_the_reference():
+    """posterior_mean_grad / posterior_covariance_grad / Hessian / gradient self-test (gp_posterior.py:184-226,
+    290-331; gp_marginal_likelihood.py:312-364) -- the oracle repeats the reference's arithmetic exactly."""
+    fx = load_golden("G9_derivatives_rbf_n256_d2.npz")
+    o = orc.OracleGP(fx["x"], fx["y"], fx["theta"], fx["noise_variances"], kernel="rbf_ard")
+    xp = fx["x_pred"]
+    np.testing.assert_allclose(o.posterior_mean_grad(xp)["dm/dx"], fx["dm_all"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(o.posterior_mean_grad(xp, direction=1)["dm/dx"], fx["dm_dir1"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(o.posterior_mean_grad(xp, hyperparameters=fx["theta2"])["dm/dx"], fx["dm_theta2"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(o.posterior_covariance_grad(xp)["dv/dx"], fx["dv_all"], rtol=0, atol=1e-9)
+    r = o.posterior_covariance_grad(xp, direction=0)
+    np.testing.assert_allclose(r["dv/dx"], fx["dv_dir0"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(r["dS/dx"], fx["dS_dir0"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(o.neg_log_likelihood_hessian(fx["theta"]), fx["hessian"], rtol=1e-9, atol=1e-6)
+    fd, an = o.test_log_likelihood_gradient(fx["theta"])
+    np.testing.assert_allclose(fd, fx["fd_grad"], rtol=1e-9)
+    np.testing.assert_allclose(an, fx["an_grad"], rtol=1e-9)
+    # multi-task shapes
+    fm = load_golden("G9m_derivatives_fvgp_4x64.npz")
+    xt, yt, vt = orc.transform_index_set(fm["fvgp_x"], fm["fvgp_y"], fm["fvgp_noise"])
+    om = orc.OracleGP(xt, yt, fm["theta"], vt, kernel="matern32_ard", x_out=fm["x_out"])
+    xp5, xo = fm["x_pred"], fm["x_out"]
+    assert om.posterior_mean_grad(xp5, x_out=xo)["dm/dx"].shape == fm["dm_all"].shape == (6, 2, 4)
+    np.testing.assert_allclose(om.posterior_mean_grad(xp5, x_out=xo)["dm/dx"], fm["dm_all"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(om.posterior_covariance_grad(xp5, x_out=xo, direction=1)["dS/dx"], fm["dS_dir1"], rtol=0, atol=1e-9)
