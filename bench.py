@@ -97,11 +97,18 @@ def sharded_measure(args, x, y, world, rank, local, dist, steps, warmup, check_t
             k = (gp.nb_max - gp.bnd[J + 1] // 128 // world) * 128
             gathered += 8.0 * (world - 1) * k * (gp.bnd[J + 1] - gp.bnd[J])
     extra = {}
+    if world > 1:                                                    # one more (untimed) evaluation with events around the collectives
+        gp.collective_events = []
+        gp.log_likelihood(theta0)
+        for kind, (calls, nbytes, ms) in gp.collective_summary().items():
+            extra[kind] = {"calls": calls, "bytes_received_per_rank": nbytes, "ms_on_chain_stream": ms,
+                           "GBps_per_rank": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None}
+        gp.collective_events = None
     if check_theta is not None:                                      # same theta as a single-GPU evaluation of this run
         ll_c, _, _ = gp.log_likelihood(check_theta)
         if check_value is not None:
-            extra = {"loglik_at_check_theta": ll_c, "single_gpu_loglik_at_check_theta": check_value,
-                     "rel_diff_vs_single_gpu": abs(ll_c - check_value) / abs(check_value)}
+            extra.update({"loglik_at_check_theta": ll_c, "single_gpu_loglik_at_check_theta": check_value,
+                          "rel_diff_vs_single_gpu": abs(ll_c - check_value) / abs(check_value)})
     return {**extra, "evals_per_s": steps / elapsed, "ms_per_eval": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
             "tflops_per_gpu": steps * (n ** 3) / 3.0 / elapsed / 1e12 / world, "loglik_last": ll,
             "panel": gp.NB, "all_gather_bytes_per_rank_per_eval": gathered,

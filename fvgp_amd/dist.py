@@ -90,6 +90,12 @@ class HipOps:
         ev.record(self.chain._stream)
         self._stream.wait_event(ev)
 
+    def timestamp(self):
+        """a timing event recorded on this object's stream (for the collective timings bench.py reports)"""
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(self._stream)
+        return ev
+
     def zeros(self, *shape, dtype=None):
         if dtype is None:
             return self.H.zeros(*shape)
@@ -181,6 +187,7 @@ class ShardedGP:
             self._send = o.zeros(self.nb_max * TILE * self.NB)
             self._recv = [o.zeros(self.P * self.nb_max * TILE * self.NB) for _ in range(2)]
         self._into_tensor = self.P > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.collective_events = None      # set to [] to collect (kind, bytes, start, end) per collective
 
     # -- collectives (no-ops on one rank) ---------------------------------------------------------
     def _all_reduce(self, t):
@@ -193,6 +200,24 @@ class ShardedGP:
             self.dist.all_gather_into_tensor(out.view(-1), inp, group=self.group)
         else:
             self.dist.all_gather(list(out.unbind(0)), inp, group=self.group)      # contiguous views (gloo)
+
+    def _timed(self, kind, nbytes, fn, *a):
+        rec = self.collective_events
+        if rec is None or not hasattr(self.ops.chain, "timestamp"):
+            return fn(*a)
+        t0 = self.ops.chain.timestamp()
+        fn(*a)
+        rec.append((kind, nbytes, t0, self.ops.chain.timestamp()))
+
+    def collective_summary(self):
+        """{kind: (calls, bytes received per rank, milliseconds on the chain stream)} of the events collected so far."""
+        self.ops.sync()
+        self.ops.chain.sync()
+        out = {}
+        for kind, nbytes, t0, t1 in self.collective_events or []:
+            c, b, ms = out.get(kind, (0, 0.0, 0.0))
+            out[kind] = (c + 1, b + nbytes, ms + t0.elapsed_time(t1))
+        return out
 
     # -- steps ------------------------------------------------------------------------------------
     def assemble(self, theta):
@@ -227,7 +252,7 @@ class ShardedGP:
                 D.zero_()
             if mine is not None:
                 mine.copy_(A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)))
-            self._all_reduce(D)
+            self._timed("all_reduce", 8.0 * NB * NB, self._all_reduce, D)
             o.potrf_dev(D, w, max(0, min(w, self.n - J0)), self.info_dev[J:J + 1], self.ld_dev[J:J + 1])
             if mine is not None:
                 A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)).copy_(mine)
@@ -237,7 +262,8 @@ class ShardedGP:
                 k = (self.nb_max - L0) * TILE
                 send = self._send[:k * w].view(k, w)
                 send.copy_(A[L0 * TILE:self.nb_max * TILE, J0:Jend])
-                self._all_gather(self._recv[J % 2][:P * k * w].view(P, k * w), send.view(-1))
+                self._timed("all_gather", 8.0 * (P - 1) * k * w, self._all_gather,
+                            self._recv[J % 2][:P * k * w].view(P, k * w), send.view(-1))
 
     def _update(self, J, c0, c1):
         """Apply panel J to block columns [c0, c1) of this rank's rows below the panel (lower tiles only)."""
