@@ -27,7 +27,7 @@ SYMBOLS = [
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize",
-    "fvgp_hip_debug_tile_map", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_syrk_rowshard",
+    "fvgp_hip_debug_tile_map", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
 ]
 
 
@@ -99,6 +99,7 @@ def lib():
     L.fvgp_hip_mfma_peak.argtypes = [c_p, c_p, c_i, c_i]
     L.fvgp_hip_trsm_lower_t.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
     L.fvgp_hip_panel_trsm.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
+    L.fvgp_hip_panel_potrf_dev.argtypes = [c_p, c_p, c_l, c_l, c_l, c_l, c_p, c_p]
     L.fvgp_hip_syrk_rowshard.argtypes = [c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i]
     L.fvgp_hip_debug_tile_map.argtypes = [c_i, c_i, c_i, c_i, c_i, P_i, P_i, c_l]
     L.fvgp_hip_debug_tile_map.restype = c_l
@@ -228,6 +229,11 @@ class Handle:
         _check(lib().fvgp_hip_syrk_rowshard(self._h, int(M), int(N), int(K), _ptr(A), A.stride(0), _ptr(B), B.stride(0),
                                             _ptr(C), C.stride(0), int(scale), int(off), int(b_ranks), int(b_blocks),
                                             int(b_off)), "fvgp_hip_syrk_rowshard")
+
+    def panel_potrf_dev(self, T, w, rows, n_valid, info_dev, logdet_dev):
+        """Enqueue-only factorisation of a tall panel (diagonal block on top, this rank's rows below)."""
+        _check(lib().fvgp_hip_panel_potrf_dev(self._h, _ptr(T), int(w), int(rows), T.stride(0), int(n_valid), _ptr(info_dev),
+                                              _ptr(logdet_dev) if logdet_dev is not None else None), "fvgp_hip_panel_potrf_dev")
 
     def potrf_dev(self, A, n, n_logdet, info_dev, logdet_dev):
         """Enqueue-only potrf: info (int32 tensor) and log-det (float64 tensor) stay on the device."""

@@ -444,6 +444,27 @@ int fvgp_hip_potrf_dev(fvgp_handle *h, double *A, int64_t n, int64_t lda, int64_
     return 0;
 }
 
+int fvgp_hip_panel_potrf_dev(fvgp_handle *h, double *T, int64_t w, int64_t rows, int64_t ldt, int64_t n_valid,
+                             int *info_dev, double *logdet_dev) {
+    if (!h) return -1;
+    if (!T) return -2;
+    if (w <= 0 || w % TILE) { fvgp_set_error("panel_potrf_dev: the panel width must be a positive multiple of 128"); return -3; }
+    if (rows < w || rows % TILE) return -4;
+    if (ldt < w || (ldt & 1) || ((uintptr_t)T & 15)) return -5;
+    if (n_valid < 0 || n_valid > w) return -6;
+    if (!info_dev) return -7;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_blocks(h, w / TILE);
+    if (rc) return rc;
+    h->linv_L = nullptr;
+    HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
+    rc = panel_factor(h, T, n_valid, rows, ldt, 0, w);       // leaf / TRSM of every row below / in-panel update, per 128 columns
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    if (logdet_dev && n_valid > 0) return launch_diag_logsum(h, T, n_valid, ldt, logdet_dev);
+    return 0;
+}
+
 int fvgp_hip_potrs(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb) {
     if (!h) return -1;
     int rc = check_square(L, n, ldl, 2, 3, 4);

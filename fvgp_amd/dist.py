@@ -9,8 +9,10 @@ Here the same pattern carries a DENSE factorisation:
     strips as gp2Scale's `ranges()` would leave the last rank 33 % of the flops);
   * right-looking blocked Cholesky with panel width NB:
       1. the NB x NB diagonal block is summed to every rank (all_reduce of a zero-filled buffer,
-         <= 8 MB) and factored redundantly -- no pivot traffic inside the panel;
-      2. each rank solves its own rows of the panel against it (MFMA GEMMs);
+         <= 8 MB) and stacked on top of the rank's own rows of the panel;
+      2. that tall panel is factored like a panel of the single-GPU driver, 128 columns at a time
+         (leaf, TRSM of every row below, in-panel update): the top block redundantly on every rank
+         -- no pivot traffic inside the panel -- the rank's rows solved along the way;
       3. the panel factor is all-gathered (the one large collective: sum ~ 4 N^2 bytes per rank);
       4. each rank applies the trailing update to its own block rows (lower tiles only), reading
          the gathered panel in the order the all-gather left it (no re-ordering copy);
@@ -108,11 +110,8 @@ class HipOps:
         """out[:len(x_rows), :len(x_all)] = k(x_rows, x_all); the rest of the padded window is zeroed."""
         self.H.kmat(kernel_id, x_rows, x_all, theta, out, pad=_lib.PAD_ZERO)
 
-    def potrf_dev(self, D, n, n_logdet, info_dev, logdet_dev):
-        self.H.potrf_dev(D, n, n_logdet, info_dev, logdet_dev)
-
-    def panel_trsm(self, D, nd, Pm, rows):
-        self.H.panel_trsm(D, nd, Pm, rows)
+    def panel_potrf_dev(self, T, w, rows, n_valid, info_dev, logdet_dev):
+        self.H.panel_potrf_dev(T, w, rows, n_valid, info_dev, logdet_dev)
 
     def syrk_rowshard(self, M, N, K, A, B, C, scale, off, b_ranks, b_blocks, b_off):
         self.H.syrk_rowshard(M, N, K, A, B, C, scale, off, b_ranks, b_blocks, b_off)
@@ -180,11 +179,10 @@ class ShardedGP:
         # panels
         self.bnd = list(range(0, self.np_, self.NB)) + [self.np_]
         self.npan = len(self.bnd) - 1
-        self.D = o.zeros(self.npan, self.NB, self.NB)                # factored diagonal blocks, replicated
         self.info_dev = o.zeros(self.npan, dtype=torch.int32)
         self.ld_dev = o.zeros(self.npan)
         if self.P > 1:
-            self._send = o.zeros(self.nb_max * TILE * self.NB)
+            self._T = o.zeros((self.NB + self.nloc * TILE) * self.NB)   # tall panel: diagonal block + local rows
             self._recv = [o.zeros(self.P * self.nb_max * TILE * self.NB) for _ in range(2)]
         self._into_tensor = self.P > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.collective_events = None      # set to [] to collect (kind, bytes, start, end) per collective
@@ -235,35 +233,41 @@ class ShardedGP:
         A[self.zrow:].copy_(self.zt)
 
     def _chain(self, J):
-        """Panel J on the chain stream: diagonal block to every rank (all_reduce of a zero-filled buffer),
-        factored redundantly; this rank's rows below it solved against it; panel factor all-gathered."""
-        o, A, P, p, NB = self.ops.chain, self.A, self.P, self.p, self.NB
+        """Panel J on the chain stream.  The diagonal block goes to every rank (all_reduce of a zero-filled
+        buffer) and is stacked on top of this rank's rows of the panel; the tall panel is factored like a panel
+        of the single-GPU driver (the top block redundantly on every rank -- no pivot traffic inside the panel);
+        the solved rows are all-gathered."""
+        o, A, P, p = self.ops.chain, self.A, self.P, self.p
         J0, Jend = self.bnd[J], self.bnd[J + 1]
         w = Jend - J0
         b0, b1 = J0 // TILE, Jend // TILE
-        la = max(0, -(-(b0 - p) // P))                              # local blocks [la, lb) lie in the panel's rows
-        lb = max(0, -(-(b1 - p) // P))
-        D = self.D[J]
+        n_valid = max(0, min(w, self.n - J0))
+        info, ld = self.info_dev[J:J + 1], self.ld_dev[J:J + 1]
         with o.stream():
+            if P == 1:                                               # the panel is contiguous in A: in place
+                o.panel_potrf_dev(A[J0:, J0:Jend], w, self.nloc * TILE - J0, n_valid, info, ld)
+                return
+            la = max(0, -(-(b0 - p) // P))                          # local blocks [la, lb) lie in the panel's rows
+            lb = max(0, -(-(b1 - p) // P))
+            L0 = b1 // P                                            # uniform first gathered local block (L0 <= lb)
+            kt = (self.nloc - L0) * TILE                            # rows below: local blocks L0.. and the (y-m)^T block
+            T = self._T[:(w + kt) * w].view(w + kt, w)
+            D, low = T[:w], T[w:]
+            D.zero_()
             mine = None
             if lb > la:
-                mine = D.view(NB // TILE, TILE, NB)[la * P + p - b0::P][:lb - la][:, :, :w]
-            if P > 1:
-                D.zero_()
-            if mine is not None:
+                mine = D.view(w // TILE, TILE, w)[la * P + p - b0::P][:lb - la]
                 mine.copy_(A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)))
-            self._timed("all_reduce", 8.0 * NB * NB, self._all_reduce, D)
-            o.potrf_dev(D, w, max(0, min(w, self.n - J0)), self.info_dev[J:J + 1], self.ld_dev[J:J + 1])
+            self._timed("all_reduce", 8.0 * w * w, self._all_reduce, D)
+            low.copy_(A[L0 * TILE:, J0:Jend])
+            o.panel_potrf_dev(T, w, w + kt, n_valid, info, ld)
             if mine is not None:
                 A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)).copy_(mine)
-            o.panel_trsm(D, w, A[lb * TILE:, J0:Jend], (self.nloc - lb) * TILE)
-            if Jend < self.np_ and P > 1:
-                L0 = b1 // P                                        # uniform first gathered local block
+            A[lb * TILE:, J0:Jend].copy_(low[(lb - L0) * TILE:])
+            if Jend < self.np_:
                 k = (self.nb_max - L0) * TILE
-                send = self._send[:k * w].view(k, w)
-                send.copy_(A[L0 * TILE:self.nb_max * TILE, J0:Jend])
                 self._timed("all_gather", 8.0 * (P - 1) * k * w, self._all_gather,
-                            self._recv[J % 2][:P * k * w].view(P, k * w), send.view(-1))
+                            self._recv[J % 2][:P * k * w].view(P, k * w), low[:k].reshape(-1))
 
     def _update(self, J, c0, c1):
         """Apply panel J to block columns [c0, c1) of this rank's rows below the panel (lower tiles only)."""

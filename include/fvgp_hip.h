@@ -119,6 +119,13 @@ int fvgp_hip_trsm_lower_t(fvgp_handle *h, const double *L, int64_t n, int64_t ld
  *                q, q + b_ranks, ...; tile column tj reads cyclic block tj + b_off
  *                (b_ranks = 1, b_off = 0: plain row order). */
 int fvgp_hip_panel_trsm(fvgp_handle *h, const double *D, int64_t nd, int64_t ldd, double *P, int64_t rows, int64_t ldp);
+/* one tall panel T (rows x w, row-major, ldt): the w x w diagonal block on top (lower triangle; the first
+ * n_valid rows are data, the rest identity padding), this rank's rows of the panel below it.  Factors the top
+ * block and solves the rows below against it, 128 columns at a time (leaf, TRSM by the inverted diagonal tile,
+ * in-panel update), exactly as the single-GPU driver treats a panel.  Enqueue only: info -> info_dev,
+ * 2*sum(log diag) of the first n_valid rows -> logdet_dev (may be null). */
+int fvgp_hip_panel_potrf_dev(fvgp_handle *h, double *T, int64_t w, int64_t rows, int64_t ldt, int64_t n_valid,
+                             int *info_dev, double *logdet_dev);
 int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
                             const double *B, int64_t ldb, double *C, int64_t ldc, int scale, int off,
                             int b_ranks, int b_blocks, int b_off);

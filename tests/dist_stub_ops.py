@@ -41,19 +41,18 @@ class StubOps:
         out[:r, :c] = 0.0
         out[:k.shape[0], :k.shape[1]] = torch.as_tensor(k)
 
-    def potrf_dev(self, D, n, n_logdet, info_dev, logdet_dev):
-        M = torch.tril(D[:n, :n]) + torch.tril(D[:n, :n], -1).T
+    def panel_potrf_dev(self, T, w, rows, n_valid, info_dev, logdet_dev):
+        D = T[:w, :w]
+        M = torch.tril(D) + torch.tril(D, -1).T
         L, info = torch.linalg.cholesky_ex(M)
         info_dev[0] = int(info)
         if int(info) != 0:
-            D[:n, :n] = float("nan")
+            T[:rows, :w] = float("nan")
             return
-        D[:n, :n] = torch.tril(L) + torch.triu(D[:n, :n], 1)       # strict upper left as is (unspecified)
-        logdet_dev[0] = 2.0 * torch.log(torch.diagonal(L)[:n_logdet]).sum()
-
-    def panel_trsm(self, D, nd, Pm, rows):
-        L = torch.tril(D[:nd, :nd])
-        Pm[:rows, :nd] = torch.linalg.solve_triangular(L, Pm[:rows, :nd].T, upper=False).T
+        T[:w, :w] = torch.tril(L) + torch.triu(D, 1)               # strict upper left as is (unspecified)
+        logdet_dev[0] = 2.0 * torch.log(torch.diagonal(L)[:n_valid]).sum()
+        if rows > w:
+            T[w:rows, :w] = torch.linalg.solve_triangular(torch.tril(L), T[w:rows, :w].T, upper=False).T
 
     def syrk_rowshard(self, M, N, K, A, B, C, scale, off, b_ranks=1, b_blocks=0, b_off=0):
         for ti in range(M // 128):

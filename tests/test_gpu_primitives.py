@@ -374,3 +374,27 @@ def test_potrf_dev_and_panel_trsm(H):
     H.potrf_dev(D2, n, n, info, ld)
     H.sync()
     assert int(info.item()) == 201
+
+
+@pytest.mark.parametrize("w,extra,n_valid", [(384, 256, 384), (128, 0, 100), (1024, 640, 1024)])
+def test_panel_potrf_dev_tall_panel(H, w, extra, n_valid):
+    """diagonal block on top, rows below solved against it; info and log-det stay on the device."""
+    import torch
+    rng = np.random.default_rng(11)
+    G = rng.standard_normal((w, w))
+    S = G @ G.T + w * np.eye(w)
+    S[n_valid:, :] = 0.0; S[:, n_valid:] = 0.0
+    S[np.arange(n_valid, w), np.arange(n_valid, w)] = 1.0            # identity padding below n_valid
+    Pm = rng.standard_normal((extra, w))
+    T = H.to_device(np.vstack([S, Pm]))
+    info = torch.full((1,), 9, dtype=torch.int32, device="cuda:0")
+    ld = H.zeros(1)
+    H.panel_potrf_dev(T, w, w + extra, n_valid, info, ld)
+    H.sync()
+    L = np.linalg.cholesky(S)
+    got = T.cpu().numpy()
+    assert int(info.item()) == 0
+    np.testing.assert_allclose(np.tril(got[:w]), L, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(float(ld.item()), 2 * np.log(np.diag(L)[:n_valid]).sum(), rtol=1e-12)
+    if extra:
+        np.testing.assert_allclose(got[w:], sla.solve_triangular(L, Pm.T, lower=True).T, rtol=1e-9, atol=1e-11)
