@@ -553,6 +553,7 @@ int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *wo
             u.a_kmajor = 0; u.b_nmajor = 1; u.lower = 0; u.M = R; u.N = w; u.K = R; u.alpha = -1.0; u.beta = 0.0;
             u.A = L + Jend * ldl + Jend; u.lda = ldl; u.B = work + Jend * ldw + J0; u.ldb = ldw; u.C = L + Jend * ldl + J0; u.ldc = ldl;
             u.kb0 = 0; u.ke0 = TILE; u.kei = TILE; u.kej = 0;
+            u.rev_m = 1;    // K grows with the row tile: start the long rows first so the launch has no long tail
             rc = launch_gemm(h, u); if (rc) return rc;
         }
         // W_JJ over L_JJ (its 128-tiles above the block diagonal are never read)

@@ -70,6 +70,7 @@ struct GemmDesc {
     // B (b_nmajor = 0 only) as an all-gather leaves it: `bc_ranks` chunks of `bc_blocks` 128-row blocks, chunk q
     // holding the blocks q, q + bc_ranks, ...; output tile column tj reads block tj + bc_off of that cyclic order
     int bc_ranks = 1, bc_blocks = 0, bc_off = 0;
+    int rev_m = 0;                    // walk the tile rows from the last to the first (per-tile K grows with ti: longest first)
 };
 int launch_gemm(fvgp_handle *h, const GemmDesc &g);
 long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int ls, int lo, int *out_ti, int *out_tj, long cap);

@@ -34,6 +34,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, lower;      // lower: 0 all tiles, 1 tj <= ti, 2 tj <= ti*ls + lo (row-sharded trailing update)
     int ls, lo;
     int bcr, bcb, bco;                // B rows in all-gather (block-cyclic) order, see GemmDesc
+    int rev;                          // tile rows enumerated last to first
     long K;
     long kb0, kbi, kbj, ke0, kei, kej;
     long ntiles;
@@ -95,7 +96,11 @@ __host__ __device__ inline long xcd_remap(long b, long nwg, int tiles_n) {
     const long nst = nwg / per;                             // grid is a whole number of super-tiles
     const long xcd = b % 8, idx = b / 8;                    // idx-th block of this XCD
     const long full = nst / 8 * 8;                          // super-tiles dealt round-robin
-    const long st = (idx / per) * 8 + xcd;
+    // round r of eight super-tiles goes to the XCDs in alternating direction (0..7, 7..0, ..): when the work per
+    // super-tile falls monotonically along the enumeration (per-tile K ranges of the triangular inverse) every XCD
+    // still gets the same total
+    const long round = idx / per;
+    const long st = round * 8 + ((round & 1) ? 7 - xcd : xcd);
     if (st < full) return st * per + idx % per;
     // leftover super-tiles (< 8): spread their tiles over all XCDs in plain order
     const long rem_blocks = nwg - full * per;
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     if (ti >= g.tiles_m || tj >= g.tiles_n) return;
     if (g.lower == 1 && tj > ti) return;
     if (g.lower == 2 && tj > ti * g.ls + g.lo) return;
+    if (g.rev) ti = g.tiles_m - 1 - ti;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -354,7 +360,8 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.A = d.A; g.B = d.B; g.C = d.C; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
     g.alpha = d.alpha; g.beta = d.beta; g.K = d.K;
     g.tiles_m = (int)(d.M / 128); g.tiles_n = (int)(d.N / 128); g.lower = d.lower; g.ls = d.lower_scale; g.lo = d.lower_off;
-    g.bcr = d.bc_ranks; g.bcb = d.bc_blocks; g.bco = d.bc_off;
+    g.bcr = d.bc_ranks; g.bcb = d.bc_blocks; g.bco = d.bc_off; g.rev = d.rev_m;
+    if (d.rev_m && d.lower) { fvgp_set_error("gemm: rev_m is for full (non-triangular) tile grids"); return -3; }
     if (d.bc_ranks < 1) return -7;
     if ((d.bc_ranks > 1 || d.bc_off) && d.b_nmajor) { fvgp_set_error("gemm: block-cyclic B needs the (N, K) layout"); return -7; }
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
