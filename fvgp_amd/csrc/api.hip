@@ -352,40 +352,63 @@ static int potrs_vec(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, do
     return 0;
 }
 
-// B (np x ldb), nrhs (multiple of 128) columns: forward block substitution on MFMA GEMMs
+// B (np x ldb), nrhs (multiple of 128) columns: forward block substitution on MFMA GEMMs, two block sizes like
+// the factorisation: 128-row steps inside an outer block of `outer_block` rows (updates confined to that block,
+// K = 128), then ONE update of everything below with K = outer_block -- the read-modify-write passes over B
+// drop by outer_block/128.
 static int trsm_fwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t ncols, int64_t ldb) {
-    const int64_t np = pad128(n);
+    const int64_t np = pad128(n), NB = h->outer_block;
     int rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
-    for (int64_t k0 = 0; k0 < np; k0 += TILE) {
-        GemmDesc d{};
-        d.a_kmajor = 0; d.b_nmajor = 1; d.lower = 0; d.M = TILE; d.N = ncols; d.K = TILE; d.alpha = 1.0; d.beta = 0.0;
-        d.A = h->linv + (k0 / TILE) * LEAF_DOUBLES; d.lda = TILE;
-        d.B = B + k0 * ldb; d.ldb = ldb; d.C = B + k0 * ldb; d.ldc = ldb;
-        rc = launch_gemm(h, d); if (rc) return rc;
-        const int64_t r0 = k0 + TILE, R = np - r0;
-        if (R <= 0) continue;
-        GemmDesc u{};
-        u.a_kmajor = 0; u.b_nmajor = 1; u.lower = 0; u.M = R; u.N = ncols; u.K = TILE; u.alpha = -1.0; u.beta = 1.0;
-        u.A = L + r0 * ldl + k0; u.lda = ldl; u.B = B + k0 * ldb; u.ldb = ldb; u.C = B + r0 * ldb; u.ldc = ldb;
-        rc = launch_gemm(h, u); if (rc) return rc;
+    for (int64_t J0 = 0; J0 < np; J0 += NB) {
+        const int64_t Jend = (J0 + NB < np) ? J0 + NB : np;
+        for (int64_t k0 = J0; k0 < Jend; k0 += TILE) {
+            GemmDesc d{};   // X_k = inv(L_kk) B_k
+            d.a_kmajor = 0; d.b_nmajor = 1; d.lower = 0; d.M = TILE; d.N = ncols; d.K = TILE; d.alpha = 1.0; d.beta = 0.0;
+            d.A = h->linv + (k0 / TILE) * LEAF_DOUBLES; d.lda = TILE;
+            d.B = B + k0 * ldb; d.ldb = ldb; d.C = B + k0 * ldb; d.ldc = ldb;
+            rc = launch_gemm(h, d); if (rc) return rc;
+            const int64_t r0 = k0 + TILE, R = Jend - r0;
+            if (R <= 0) continue;
+            GemmDesc u{};   // rest of the outer block: B[r0:Jend] -= L[r0:Jend, k] X_k
+            u.a_kmajor = 0; u.b_nmajor = 1; u.lower = 0; u.M = R; u.N = ncols; u.K = TILE; u.alpha = -1.0; u.beta = 1.0;
+            u.A = L + r0 * ldl + k0; u.lda = ldl; u.B = B + k0 * ldb; u.ldb = ldb; u.C = B + r0 * ldb; u.ldc = ldb;
+            rc = launch_gemm(h, u); if (rc) return rc;
+        }
+        if (np > Jend) {
+            GemmDesc u{};   // everything below: B[Jend:] -= L[Jend:, J0:Jend] X[J0:Jend]
+            u.a_kmajor = 0; u.b_nmajor = 1; u.lower = 0; u.M = np - Jend; u.N = ncols; u.K = Jend - J0; u.alpha = -1.0; u.beta = 1.0;
+            u.A = L + Jend * ldl + J0; u.lda = ldl; u.B = B + J0 * ldb; u.ldb = ldb; u.C = B + Jend * ldb; u.ldc = ldb;
+            rc = launch_gemm(h, u); if (rc) return rc;
+        }
     }
     return 0;
 }
 
+// backward half, same two block sizes, from the last outer block to the first
 static int trsm_bwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t ncols, int64_t ldb) {
-    const int64_t np = pad128(n);
+    const int64_t np = pad128(n), NB = h->outer_block;
     int rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
-    for (int64_t k0 = np - TILE; k0 >= 0; k0 -= TILE) {
-        GemmDesc d{};   // X_k = inv(L_kk)^T Y_k
-        d.a_kmajor = 1; d.b_nmajor = 1; d.lower = 0; d.M = TILE; d.N = ncols; d.K = TILE; d.alpha = 1.0; d.beta = 0.0;
-        d.A = h->linv + (k0 / TILE) * LEAF_DOUBLES; d.lda = TILE;
-        d.B = B + k0 * ldb; d.ldb = ldb; d.C = B + k0 * ldb; d.ldc = ldb;
-        rc = launch_gemm(h, d); if (rc) return rc;
-        if (k0 == 0) continue;
-        GemmDesc u{};   // Y[0:k0] -= L[k-block, 0:k0]^T X_k
-        u.a_kmajor = 1; u.b_nmajor = 1; u.lower = 0; u.M = k0; u.N = ncols; u.K = TILE; u.alpha = -1.0; u.beta = 1.0;
-        u.A = L + k0 * ldl; u.lda = ldl; u.B = B + k0 * ldb; u.ldb = ldb; u.C = B; u.ldc = ldb;
-        rc = launch_gemm(h, u); if (rc) return rc;
+    const int64_t npan = (np + NB - 1) / NB;
+    for (int64_t J = npan - 1; J >= 0; --J) {
+        const int64_t J0 = J * NB, Jend = (J0 + NB < np) ? J0 + NB : np;
+        for (int64_t k0 = Jend - TILE; k0 >= J0; k0 -= TILE) {
+            GemmDesc d{};   // X_k = inv(L_kk)^T Y_k
+            d.a_kmajor = 1; d.b_nmajor = 1; d.lower = 0; d.M = TILE; d.N = ncols; d.K = TILE; d.alpha = 1.0; d.beta = 0.0;
+            d.A = h->linv + (k0 / TILE) * LEAF_DOUBLES; d.lda = TILE;
+            d.B = B + k0 * ldb; d.ldb = ldb; d.C = B + k0 * ldb; d.ldc = ldb;
+            rc = launch_gemm(h, d); if (rc) return rc;
+            if (k0 == J0) continue;
+            GemmDesc u{};   // rest of the outer block: Y[J0:k0] -= L[k, J0:k0]^T X_k
+            u.a_kmajor = 1; u.b_nmajor = 1; u.lower = 0; u.M = k0 - J0; u.N = ncols; u.K = TILE; u.alpha = -1.0; u.beta = 1.0;
+            u.A = L + k0 * ldl + J0; u.lda = ldl; u.B = B + k0 * ldb; u.ldb = ldb; u.C = B + J0 * ldb; u.ldc = ldb;
+            rc = launch_gemm(h, u); if (rc) return rc;
+        }
+        if (J0 > 0) {
+            GemmDesc u{};   // everything above: Y[0:J0] -= L[J0:Jend, 0:J0]^T X[J0:Jend]
+            u.a_kmajor = 1; u.b_nmajor = 1; u.lower = 0; u.M = J0; u.N = ncols; u.K = Jend - J0; u.alpha = -1.0; u.beta = 1.0;
+            u.A = L + J0 * ldl; u.lda = ldl; u.B = B + J0 * ldb; u.ldb = ldb; u.C = B; u.ldc = ldb;
+            rc = launch_gemm(h, u); if (rc) return rc;
+        }
     }
     return 0;
 }
