@@ -96,6 +96,10 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
         h->outer_block_big = value; return 0;
     }
     if (!strcmp(key, "big_threshold")) { h->big_threshold = value; return 0; }
+    if (!strcmp(key, "inner_block")) {
+        if (value != 0 && (value < 128 || value % 128)) { fvgp_set_error("inner_block must be 0 or a multiple of 128"); return -3; }
+        h->inner_block = value; return 0;
+    }
     fvgp_set_error(std::string("unknown option ") + key);
     return -2;
 }
@@ -201,15 +205,29 @@ static int panel_factor(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_
 
 // trailing update with the factored panel [J0, Jend): block columns [c0, c1) of the trailing matrix
 // (rows c0..np), lower tiles only:  A[c0:, c0:c1] -= L[c0:, J0:Jend] L[c0:c1, J0:Jend]^T
-static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, int64_t J0, int64_t Jend, int64_t c0, int64_t c1) {
+static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, int64_t J0, int64_t Jend, int64_t c0, int64_t c1, int role = 1) {
     if (c1 <= c0 || np <= c0) return 0;
     GemmDesc s{};
     s.a_kmajor = 0; s.b_nmajor = 0; s.lower = 1; s.M = np - c0; s.N = c1 - c0; s.K = Jend - J0;
-    s.alpha = -1.0; s.beta = 1.0; s.role = 1;
+    s.alpha = -1.0; s.beta = 1.0; s.role = role;
     s.A = A + c0 * lda + J0; s.lda = lda;
     s.B = A + c0 * lda + J0; s.ldb = lda;
     s.C = A + c0 * lda + c0; s.ldc = lda;
     return launch_gemm(h, s);
+}
+
+// a panel wider than `inner_block` is factored in sub-panels of that width: 128-column steps inside a sub-panel,
+// then one update of the remaining columns of the panel with K = inner_block -- a third block size between the
+// leaf (128) and the trailing update (panel width), so that wide panels do not pay for their width in K = 128 work
+static int panel_factor_nested(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+    const int64_t inner = h->inner_block;
+    if (inner <= 0 || Jend - J0 <= inner) return panel_factor(h, A, n, np, lda, J0, Jend);
+    for (int64_t s0 = J0; s0 < Jend; s0 += inner) {
+        const int64_t s1 = (s0 + inner < Jend) ? s0 + inner : Jend;
+        int rc = panel_factor(h, A, n, np, lda, s0, s1); if (rc) return rc;
+        if (s1 < Jend) { rc = trailing_update(h, A, np, lda, s0, s1, s1, Jend, 0); if (rc) return rc; }
+    }
+    return 0;
 }
 
 static double lower_flops(int64_t M, int64_t N, int64_t K) {     // algorithmic flops of a lower-tile update
@@ -270,7 +288,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     const bool la = h->lookahead && npan > 2;
     if (!la) {
         for (size_t J = 0; J < npan; ++J) {
-            rc = panel_factor(h, A, n, np, lda, bnd[J], bnd[J + 1]); if (rc) return rc;
+            rc = panel_factor_nested(h, A, n, np, lda, bnd[J], bnd[J + 1]); if (rc) return rc;
             if (np > bnd[J + 1]) { rc = timed_update(bnd[J], bnd[J + 1], bnd[J + 1], np); if (rc) return rc; }
         }
     } else {
@@ -282,7 +300,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             HIPCHK(hipEventCreateWithFlags(&h->ev_cols, hipEventDisableTiming));
         }
         hipStream_t mainS = h->stream, sideS = h->side;
-        rc = panel_factor(h, A, n, np, lda, bnd[0], bnd[1]); if (rc) return rc;      // panel 0 on the main stream
+        rc = panel_factor_nested(h, A, n, np, lda, bnd[0], bnd[1]); if (rc) return rc;      // panel 0 on the main stream
         for (size_t J = 0; J + 1 < npan; ++J) {
             const int64_t J0 = bnd[J], Jend = bnd[J + 1], Nend = bnd[J + 2];           // next panel = [Jend, Nend)
             // (1) main: bring the next panel's block columns up to date with panel J
@@ -291,7 +309,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             // (2) side: factor the next panel as soon as (1) is done ...
             HIPCHK(hipStreamWaitEvent(sideS, h->ev_cols, 0));
             h->stream = sideS;
-            rc = panel_factor(h, A, n, np, lda, Jend, Nend);
+            rc = panel_factor_nested(h, A, n, np, lda, Jend, Nend);
             h->stream = mainS;
             if (rc) return rc;
             HIPCHK(hipEventRecord(h->ev_panel, sideS));

@@ -32,8 +32,9 @@ struct fvgp_handle {
     size_t vec_cap = 0;
     // options
     int64_t outer_block = 1024;
-    int64_t outer_block_big = 0, big_threshold = 24576;   // optional wider panels while the trailing matrix is large
+    int64_t outer_block_big = 2048, big_threshold = 24576;   // wider panels while the trailing matrix is large
     int profile = 0;
+    int64_t inner_block = 512;        // sub-panel width inside panels wider than this (0 = off)
     int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel
     hipEvent_t ev_panel = nullptr, ev_cols = nullptr;

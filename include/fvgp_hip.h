@@ -68,6 +68,7 @@ int fvgp_hip_stream_create(void **out_stream, int device, int high_priority, con
 int fvgp_hip_stream_destroy(void *stream);
 /* keys: "outer_block" (panel width = K of the trailing update, multiple of 128; default 1024),
  *       "outer_block_big" / "big_threshold" (optional wider panels while more rows than the threshold remain),
+ *       "inner_block" (sub-panel width inside panels wider than it: a third block size; 0 = off),
  *       "lookahead" (0/1: factor the next panel on a high-priority side stream under the trailing update),
  *       "profile" (0/1: time the trailing-update launches with HIP events -> fvgp_hip_get_profile) */
 int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value);
