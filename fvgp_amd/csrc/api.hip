@@ -96,6 +96,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
         h->outer_block_big = value; return 0;
     }
     if (!strcmp(key, "big_threshold")) { h->big_threshold = value; return 0; }
+    if (!strcmp(key, "gemm_probe")) { h->gemm_probe = (int)value; return 0; }
     if (!strcmp(key, "inner_block")) {
         if (value != 0 && (value < 128 || value % 128)) { fvgp_set_error("inner_block must be 0 or a multiple of 128"); return -3; }
         h->inner_block = value; return 0;
@@ -842,6 +843,7 @@ int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t
     GemmDesc g{};
     g.a_kmajor = a_kmajor; g.b_nmajor = b_nmajor; g.lower = lower; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.probe = h->gemm_probe;
     return launch_gemm(h, g);
 }
 

@@ -35,6 +35,7 @@ struct fvgp_handle {
     int64_t outer_block_big = 2048, big_threshold = 24576;   // wider panels while the trailing matrix is large
     int profile = 0;
     int64_t inner_block = 512;        // sub-panel width inside panels wider than this (0 = off)
+    int gemm_probe = 0;               // fvgp_hip_gemm launches a K-loop timing probe instead (diagnostics)
     int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel
     hipEvent_t ev_panel = nullptr, ev_cols = nullptr;
@@ -71,6 +72,7 @@ struct GemmDesc {
     // B (b_nmajor = 0 only) as an all-gather leaves it: `bc_ranks` chunks of `bc_blocks` 128-row blocks, chunk q
     // holding the blocks q, q + bc_ranks, ...; output tile column tj reads block tj + bc_off of that cyclic order
     int bc_ranks = 1, bc_blocks = 0, bc_off = 0;
+    int probe = 0;                    // timing probe variant of the K loop (diagnostics only)
     int rev_m = 0;                    // walk the tile rows from the last to the first (per-tile K grows with ti: longest first)
 };
 int launch_gemm(fvgp_handle *h, const GemmDesc &g);

@@ -110,7 +110,7 @@ __host__ __device__ inline long xcd_remap(long b, long nwg, int tiles_n) {
 
 // ROLE only names the instantiation (0 generic, 1 trailing update of the Cholesky) so that profilers list
 // the kernel the metric lives in under its own symbol
-template <int AKM, int BNM, int ROLE>
+template <int AKM, int BNM, int ROLE, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // 76 KB, a little more than the 72 KB of operand images: the look-ahead leaf kernel (73 KB) must fit
     // into the LDS range one retiring workgroup of this kernel frees
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
-        if (more) {
+        if (more && !(DBG & 1)) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 ga[p] += astep; gb[p] += bstep;
@@ -218,21 +218,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         for (int s = 0; s < 4; ++s) {
             double a[4], bv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = pa[fa[i] + s * SA]; bv[i] = pb[fb[i] + s * SB]; }
+            for (int i = 0; i < 4; ++i) {
+                if (DBG & 4) { a[i] = ra[i][0] + s; bv[i] = rb[i][1] + s; }       // probe: no LDS reads
+                else { a[i] = pa[fa[i] + s * SA]; bv[i] = pb[fb[i] + s * SB]; }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (more) {
+        if (more && !(DBG & 1)) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 *reinterpret_cast<double2_t *>(&smem[cur ^ 1][0][sa[p]]) = ra[p];
                 *reinterpret_cast<double2_t *>(&smem[cur ^ 1][1][sb[p]]) = rb[p];
             }
         }
-        __syncthreads();
+        if (!(DBG & 2)) __syncthreads();
     }
 
     // epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile.  The read-modify-write of C
@@ -368,6 +371,15 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
     if (g.ntiles == 0) return 0;
     dim3 grid((unsigned)g.ntiles), block(256);
+    if (d.probe) {
+        // timing probes of the K loop with parts of it removed (results are meaningless): 1 no global loads / LDS
+        // writes, 2 no barrier, 4 no LDS fragment reads -- tools/gemm_probe.py
+#define PR(V) case V: hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 0, V>), grid, block, 0, h->stream, g); break
+        switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); PR(6); PR(7); default: return -3; }
+#undef PR
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
 #define GO(AK, BN) do { if (d.role == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 1>), grid, block, 0, h->stream, g); \
                         else hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 0>), grid, block, 0, h->stream, g); } while (0)
     if (!d.a_kmajor && !d.b_nmajor) GO(0, 0);
