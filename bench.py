@@ -211,7 +211,7 @@ def main():
     for t in range(args.warmup):
         vals.append(H.loglik(0, xd, theta_at(t), vd, ymd, KV, alpha))
     H.set_option("profile", 1)
-    prof = {"launches": 0.0, "ms": 0.0, "flops": 0.0, "potrf_ms": 0.0}
+    prof = {"launches": 0.0, "ms": 0.0, "flops": 0.0, "potrf_ms": 0.0, "kmat_ms": 0.0, "kmat_bytes": 0.0, "tail_ms": 0.0}
     sync_all()
     t0 = time.perf_counter()
     for t in range(args.steps):
@@ -250,6 +250,13 @@ def main():
             "cholesky_tflops": potrf_tflops,
             "cholesky_frac_of_fp64_mfma_peak": potrf_tflops / PEAK_FP64_MFMA_TFLOPS,
             "loglik_last": ll,
+            # the other stages of the evaluation, HIP events on the launch stream inside the timed region
+            "k_assembly": {"kernel": "kmat_kernel (pairwise distance + RBF, + noise on the diagonal; lower 128-tiles written once)",
+                           "bound": "hbm", "achieved": prof["kmat_bytes"] / (prof["kmat_ms"] * 1e-3) / 1e9 if prof["kmat_ms"] > 0 else 0.0,
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": prof["kmat_bytes"] / (prof["kmat_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS if prof["kmat_ms"] > 0 else 0.0,
+                           "ms_per_eval": prof["kmat_ms"] / args.steps, "algorithmic_bytes_per_eval": prof["kmat_bytes"] / args.steps},
+            "after_factorisation_ms_per_eval": prof["tail_ms"] / args.steps,
             "roofline": {
                 "kernel": "gemm_f64_kernel<0, 0, 1> (trailing update of the blocked Cholesky, lower tiles)",
                 "bound": "mfma", "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",

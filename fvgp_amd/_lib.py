@@ -193,9 +193,10 @@ class Handle:
         _check(lib().fvgp_hip_set_option(self._h, key.encode(), int(value)), "fvgp_hip_set_option")
 
     def get_profile(self):
-        out = (ctypes.c_double * 4)()
+        out = (ctypes.c_double * 8)()
         _check(lib().fvgp_hip_get_profile(self._h, out), "fvgp_hip_get_profile")
-        return {"launches": out[0], "ms": out[1], "flops": out[2], "potrf_ms": out[3]}
+        return {"launches": out[0], "ms": out[1], "flops": out[2], "potrf_ms": out[3],
+                "kmat_ms": out[4], "kmat_bytes": out[5], "tail_ms": out[6]}
 
     # -- ABI calls -----------------------------------------------------------------------------
     def kmat(self, kernel_id, x1, x2, theta, K, vdiag=None, uplo=FULL, pad=PAD_NONE):

@@ -41,6 +41,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
+    for (auto e : h->ev_stage) if (e) (void)hipEventDestroy(e);
     if (h->ev_cols) (void)hipEventDestroy(h->ev_cols);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->linv) (void)hipFree(h->linv);
@@ -109,6 +110,7 @@ int fvgp_hip_get_profile(fvgp_handle *h, double *out) {
     if (!h) return -1;
     if (!out) return -2;
     out[0] = h->prof_launches; out[1] = h->prof_ms; out[2] = h->prof_flops; out[3] = h->prof_total_ms;
+    out[4] = h->prof_kmat_ms; out[5] = h->prof_kmat_bytes; out[6] = h->prof_tail_ms; out[7] = 0.0;
     return 0;
 }
 
@@ -629,7 +631,12 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     KmatDesc k{};
     rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &k); if (rc) return rc;
     k.x1 = x; k.n1 = n; k.x2 = x; k.n2 = n; k.vdiag = vdiag; k.K = KV; k.ldk = ld; k.uplo = FVGP_LOWER; k.pad = 1;
+    if (h->profile) {
+        for (auto &e : h->ev_stage) if (!e) HIPCHK(hipEventCreate(&e));
+        HIPCHK(hipEventRecord(h->ev_stage[0], h->stream));
+    }
     rc = launch_kmat(h, k); if (rc) return rc;
+    if (h->profile) HIPCHK(hipEventRecord(h->ev_stage[1], h->stream));
     // forward solve fused into the factorisation: (y-m)^T is appended as rows n..n+ncol-1 of the padded
     // matrix (diagonal entry large enough to keep the block PD); the panel TRSM / trailing updates then
     // leave z^T = (L^-1 (y-m))^T in those rows and quad = |z|^2.  Needs ncol free padding rows.
@@ -639,6 +646,7 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     rc = potrf_driver(h, KV, n, ld, &info); if (rc) return rc;
     if (info_host) *info_host = info;
     if (info != 0) { out_host[0] = out_host[1] = out_host[2] = NAN; return 0; }
+    if (h->profile) HIPCHK(hipEventRecord(h->ev_stage[2], h->stream));
     rc = launch_sum(h, h->logdet_parts, np / TILE, h->red); if (rc) return rc;
     if (fused) {
         rc = launch_rowsumsq(h, KV, ld, n, ncol, n, h->red + 1); if (rc) return rc;
@@ -666,8 +674,17 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
         rc = potrs_vec(h, KV, n, ld, alpha, ncol, ncol, true); if (rc) return rc;
         rc = launch_dot_rows(h, ymean, ncol, alpha, ncol, n, ncol, h->red + 1); if (rc) return rc;
     }
+    if (h->profile) HIPCHK(hipEventRecord(h->ev_stage[3], h->stream));
     double r[2];
     rc = read_back(h, h->red, r, 2); if (rc) return rc;
+    if (h->profile) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_stage[0], h->ev_stage[1])); h->prof_kmat_ms = ms;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_stage[2], h->ev_stage[3])); h->prof_tail_ms = ms;
+        // lower 128-tiles written once (+ the padded diagonal), x read once
+        const double tiles = (double)(np / TILE) * (double)(np / TILE + 1) * 0.5;
+        h->prof_kmat_bytes = tiles * TILE * TILE * 8.0 + (double)n * d * 8.0;
+    }
     const double logdet = 2.0 * r[0], quad = r[1] / (double)ncol;
     out_host[0] = -0.5 * (quad + logdet + (double)n * log(2.0 * M_PI));
     out_host[1] = logdet;

@@ -43,6 +43,8 @@ struct fvgp_handle {
     std::vector<hipEvent_t> ev;
     std::vector<double> ev_flops;
     double prof_launches = 0, prof_ms = 0, prof_flops = 0, prof_total_ms = 0;
+    double prof_kmat_ms = 0, prof_kmat_bytes = 0, prof_tail_ms = 0;   // fused evaluation: assembly, everything after the factorisation
+    hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 constexpr int RED_SLOTS = 4096;
 

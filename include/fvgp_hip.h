@@ -73,8 +73,11 @@ int fvgp_hip_stream_destroy(void *stream);
  *       "profile" (0/1: time the trailing-update launches with HIP events -> fvgp_hip_get_profile) */
 int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value);
 /* out[0] = number of trailing-update launches of the last potrf, out[1] = their summed
- * duration in ms, out[2] = their summed algorithmic flops, out[3] = whole-potrf ms */
-int fvgp_hip_get_profile(fvgp_handle *h, double *out4_host);
+ * duration in ms, out[2] = their summed algorithmic flops, out[3] = whole-potrf ms; of the last fused
+ * evaluation (fvgp_hip_loglik): out[4] = covariance-assembly ms, out[5] = its algorithmic bytes (lower
+ * 128-tiles written once), out[6] = ms of everything after the factorisation (backward solve, reductions);
+ * out[7] reserved.  out needs 8 doubles. */
+int fvgp_hip_get_profile(fvgp_handle *h, double *out8_host);
 
 /* ---- covariance assembly -------------------------------------------------------------
  * replaces GPprior.compute_covariances -> kernel(x1,x2,hps) (gp_prior.py:217-224) and,
