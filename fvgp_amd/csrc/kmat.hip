@@ -69,32 +69,45 @@ __global__ __launch_bounds__(256) void kmat_kernel(KArgs a) {
     __syncthreads();
 
     const bool ok0 = c0 < a.n2, ok1 = c1 < a.n2;
-    for (int rr = wave; rr < 128; rr += 4) {
-        const long row = row0 + rr;
-        const bool rok = row < a.n1;
-        if (!rok && !a.pad) break;   // rows are ascending per wave
-        double s0 = 0.0, s1 = 0.0;
+    // two rows per trip: the second row's exp chain fills the latency of the first, and the stores go out
+    // non-temporal (the matrix is written once and next read by another kernel: no reason to keep it in L2)
+    for (int rb = wave; rb < 128; rb += 8) {
+        double v[2][2];
+        bool live[2];
 #pragma unroll
-        for (int k = 0; k < DD; ++k) {
-            if (k < d) {
-                const double xr = sx[rr * DD + k];
-                const double e0 = (xr - u0[k]) * il[k], e1 = (xr - u1[k]) * il[k];
-                s0 = fma(e0, e0, s0); s1 = fma(e1, e1, s1);
+        for (int u = 0; u < 2; ++u) {
+            const int rr = rb + 4 * u;
+            const long row = row0 + rr;
+            const bool rok = row < a.n1;
+            live[u] = rok || a.pad;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < DD; ++k) {
+                if (k < d) {
+                    const double xr = sx[rr * DD + k];
+                    const double e0 = (xr - u0[k]) * il[k], e1 = (xr - u1[k]) * il[k];
+                    s0 = fma(e0, e0, s0); s1 = fma(e1, e1, s1);
+                }
             }
+            double v0 = radial<KIND>(s0, a.sig), v1 = radial<KIND>(s1, a.sig);
+            if (!(rok && ok0)) v0 = (a.pad == 1 && row == c0) ? 1.0 : 0.0;
+            if (!(rok && ok1)) v1 = (a.pad == 1 && row == c1) ? 1.0 : 0.0;
+            if (a.vdiag != nullptr && rok) {
+                if (row == c0 && ok0) v0 += a.vdiag[row];
+                if (row == c1 && ok1) v1 += a.vdiag[row];
+            }
+            v[u][0] = v0; v[u][1] = v1;
         }
-        double v0 = radial<KIND>(s0, a.sig), v1 = radial<KIND>(s1, a.sig);
-        if (!(rok && ok0)) v0 = (a.pad == 1 && row == c0) ? 1.0 : 0.0;
-        if (!(rok && ok1)) v1 = (a.pad == 1 && row == c1) ? 1.0 : 0.0;
-        if (a.vdiag != nullptr && rok) {
-            if (row == c0 && ok0) v0 += a.vdiag[row];
-            if (row == c1 && ok1) v1 += a.vdiag[row];
-        }
-        double *dst = a.K + row * a.ldk + c0;
-        if (a.pad || (ok0 && ok1)) {
-            if (a.vec_ok) *reinterpret_cast<double2_t *>(dst) = (double2_t){v0, v1};
-            else { dst[0] = v0; dst[1] = v1; }
-        } else if (ok0) {
-            dst[0] = v0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!live[u]) continue;
+            double *dst = a.K + (row0 + rb + 4 * u) * a.ldk + c0;
+            if (a.pad || (ok0 && ok1)) {
+                if (a.vec_ok) __builtin_nontemporal_store((double2_t){v[u][0], v[u][1]}, reinterpret_cast<double2_t *>(dst));
+                else { __builtin_nontemporal_store(v[u][0], dst); __builtin_nontemporal_store(v[u][1], dst + 1); }
+            } else if (ok0) {
+                __builtin_nontemporal_store(v[u][0], dst);
+            }
         }
     }
 }
