@@ -128,7 +128,7 @@ def sharded_main(args, x, y, world, rank, local, dist):
                        "n": n, "d": d, "kernel": "rbf_ard", "parallelism": r["parallelism"]},
             "whole_eval_tflops_equiv": r["tflops_per_gpu"] * world, "loglik_last": r["loglik_last"],
             "all_gather_bytes_per_rank_per_eval": r["all_gather_bytes_per_rank_per_eval"],
-            "roofline": {"kernel": "gemm_f64_kernel<0, 0, 1> (row-sharded trailing update)", "bound": "mfma",
+            "roofline": {"kernel": "gemm_f64_kernel<0, 0, 1, 0> (row-sharded trailing update)", "bound": "mfma",
                          "achieved": r["tflops_per_gpu"], "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": r["tflops_per_gpu"] / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                          "note": "whole-evaluation N^3/3 flops per GPU-second (collectives and solves included)"},
@@ -231,7 +231,7 @@ def main():
 
     if rank == 0:
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")
         if os.path.exists(tfile) and n == 50000:
             # HBM-side bytes per trailing-update launch from the committed rocprofv3 --pmc passes of this same
             # command (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); not re-measured live
@@ -258,7 +258,7 @@ def main():
                            "ms_per_eval": prof["kmat_ms"] / args.steps, "algorithmic_bytes_per_eval": prof["kmat_bytes"] / args.steps},
             "after_factorisation_ms_per_eval": prof["tail_ms"] / args.steps,
             "roofline": {
-                "kernel": "gemm_f64_kernel<0, 0, 1> (trailing update of the blocked Cholesky, lower tiles)",
+                "kernel": "gemm_f64_kernel<0, 0, 1, 0> (trailing update of the blocked Cholesky, lower tiles)",
                 "bound": "mfma", "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                 "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1.0),
