@@ -180,6 +180,34 @@ def test_potrf_solve_logdet(H, n, outer):
     H.set_option("outer_block", 512)
 
 
+@pytest.mark.parametrize("sched", [dict(outer_block=512, outer_block_big=1024, big_threshold=0, inner_block=256, lookahead=1),
+                                   dict(outer_block=256, outer_block_big=1024, big_threshold=1500, inner_block=128, lookahead=1),
+                                   dict(outer_block=256, outer_block_big=768, big_threshold=0, inner_block=512, lookahead=1),
+                                   dict(outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0),
+                                   dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1)])
+def test_potrf_panel_schedules_agree(H, sched):
+    """Every panel schedule (regular / wide panels, sub-panels of a third block size, with and without look-ahead)
+    is the same factorisation: compare with LAPACK on one matrix.  The last entry is the library default."""
+    from fvgp_amd._lib import pad128
+    n = 3000
+    M = _spd(n, 17)
+    Lref = np.tril(sla.cho_factor(M, lower=True)[0])
+    for k, v in sched.items():
+        H.set_option(k, v)
+    try:
+        npad = pad128(n)
+        buf = np.zeros((npad, npad))
+        buf[:n, :n] = np.tril(M)
+        A = H.to_device(buf)
+        assert H.potrf(A, n) == 0
+        L = np.tril(A.cpu().numpy()[:n, :n])
+        assert np.max(np.abs(L - Lref)) / np.max(np.abs(Lref)) < 1e-13
+        np.testing.assert_allclose(H.logdet(A, n), 2 * np.sum(np.log(np.diag(Lref))), rtol=1e-13)
+    finally:
+        for k, v in dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1).items():
+            H.set_option(k, v)
+
+
 def test_potrf_nonpd_info(H):
     """dpotrf info: order of the first non-positive leading minor (tests/test_fvgp.py:4653-4665)."""
     fx = load_golden("G7_nonpd.npz")
