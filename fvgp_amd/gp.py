@@ -26,9 +26,10 @@ from . import _lib
 from . import kernels as _kernels
 from .device import default_handle
 from .gp_lin_alg import NonPositiveDefiniteError, _non_pd_message
+from .gp_validation import ValidationMixin
 
 
-class GP:
+class GP(ValidationMixin):
     def __init__(
         self,
         x_data,

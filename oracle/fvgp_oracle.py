@@ -511,6 +511,75 @@ class OracleGP:
         return grad, -self.neg_log_likelihood_gradient(hyperparameters=thps)
 
 
+# ---------------------------------------------------------------------------------------------
+# validation scores and P x P information measures (fvgp/gp.py:1754-2071, gp_posterior.py:391-552),
+# restated on OracleGP's posterior -- callers of the path, kept here so the facade's versions have a checker
+# ---------------------------------------------------------------------------------------------
+def validation_scores(o, x_test, y_test, interval=0.95):
+    from scipy.stats import norm
+    mean = o.posterior_mean(x_test)["m(x)"]
+    v = o.posterior_covariance(x_test)["v(x)"]
+    vn = o.posterior_covariance(x_test, add_noise=True)["v(x)"]
+    out = {}
+    out["rmse"] = np.sqrt(np.sum((y_test - mean) ** 2) / y_test.size)                      # gp.py:1784-1805
+    out["nrmse"] = out["rmse"] / (np.max(y_test) - np.min(y_test))                         # :1807-1825
+    out["mae"] = np.mean(np.abs(y_test - mean))                                            # :1994-2014
+    out["mape"] = np.mean(np.abs((y_test - mean) / y_test))                                # :2016-2038
+    out["r2"] = 1. - np.sum((y_test - mean) ** 2) / np.sum((y_test - np.mean(y_test)) ** 2)   # :1854-1874
+    nl = np.mean(0.5 * np.log(2 * np.pi * v) + 0.5 * ((y_test - mean) ** 2) / v)           # :1827-1852
+    out["nlpd"] = nl
+    bm, bv = np.mean(o.y_data), np.var(o.y_data)                                           # :2040-2071
+    out["msll"] = nl - np.mean(0.5 * np.log(2 * np.pi * bv) + 0.5 * ((y_test - bm) ** 2) / bv)
+    sigma = np.sqrt(v)                                                                     # :1754-1782
+    res = abs(sigma * ((1. / np.sqrt(np.pi)) - 2. * norm.pdf((y_test - mean) / sigma)
+                       - (((y_test - mean) / sigma) * (2. * norm.cdf((y_test - mean) / sigma) - 1.))))
+    out["crps_mean"], out["crps_std"] = np.mean(res), np.sqrt(np.var(res))
+    sn = np.sqrt(vn)                                                                       # :1876-1992
+    z = norm.ppf(1 - (1 - interval) / 2)
+    lo, hi = mean - z * sn, mean + z * sn
+    out["picp"] = np.mean((y_test >= lo) & (y_test <= hi))
+    out["mpiw"] = np.mean(2 * z * np.sqrt(np.clip(vn, 0.0, None)))
+    a = 1 - interval
+    out["interval_score"] = np.mean((hi - lo) + (2 / a) * np.maximum(lo - y_test, 0) + (2 / a) * np.maximum(y_test - hi, 0))
+    return out
+
+
+def kl_div(mu1, mu2, S1, S2):
+    """gp_posterior.py:408-424."""
+    ld1 = np.linalg.slogdet(S1)[1]
+    ld2 = np.linalg.slogdet(S2)[1]
+    x1 = np.linalg.solve(S2, S1)
+    mu = np.subtract(mu2, mu1)
+    x2 = np.linalg.solve(S2, mu)
+    return abs(0.5 * (np.trace(x1) + x2 @ mu - float(len(mu)) + (ld2 - ld1)))
+
+
+def information_measures(o, x_pred, comp_mean, comp_cov):
+    """gp_kl_div, gp_relative_information_entropy(_set), posterior_probability (gp_posterior.py:426-440,494-552)."""
+    pm = o.posterior_mean(x_pred)["m(x)_flat"]
+    S = o.posterior_covariance(x_pred)["S_flat"]
+    eye = np.identity(len(S))
+    out = {"kl_div": kl_div(pm, comp_mean, S + eye * 1e-9, comp_cov + eye * 1e-9)}
+    kk = o.kernel(x_pred, x_pred, o.hyperparameters) + eye * 1e-9
+    out["rie"] = kl_div(o.mean(x_pred), pm, kk, S + eye * 1e-9)
+    rie_set = []
+    for i in range(len(x_pred)):
+        xi = x_pred[i].reshape(1, -1)
+        rie_set.append(kl_div(o.mean(xi), o.posterior_mean(xi)["m(x)_flat"], o.kernel(xi, xi, o.hyperparameters) + 1e-9,
+                              o.posterior_covariance(xi)["S_flat"] + 1e-9))
+    out["rie_set"] = np.array(rie_set)
+    gcov = o.posterior_covariance(x_pred, add_noise=True)["S_flat"]
+    gi, ci = np.linalg.inv(gcov), np.linalg.inv(comp_cov)
+    cov = np.linalg.inv(gi + ci)
+    mu = cov @ gi @ pm + cov @ ci @ comp_mean
+    C = 0.5 * (((pm.T @ gi + comp_mean.T @ ci).T @ cov @ (gi @ pm + ci @ comp_mean))
+               - (pm.T @ gi @ pm + comp_mean.T @ ci @ comp_mean)).squeeze()
+    ln_p = (C + 0.5 * np.linalg.slogdet(cov)[1]) - (np.log((2.0 * np.pi) ** (len(mu) / 2.0))
+                                                    + 0.5 * (np.linalg.slogdet(gcov)[1] + np.linalg.slogdet(comp_cov)[1]))
+    out["pp_mu"], out["pp_cov"], out["pp_prob"] = mu, cov, np.exp(ln_p)
+    return out
+
+
 def log_likelihood_once(x, y, noise_variances, hps, kernel="rbf_ard"):
     """One metric unit on the CPU: K-assembly + addKV + potrf + potrs + logdet + scalar.
     Used as bench.py's cpu_baseline ("port").  Returns (value, dict of stage seconds)."""

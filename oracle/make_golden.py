@@ -336,6 +336,40 @@ def main():
         check("G9m." + tag, b, a, 1e-9)
     np.savez_compressed(os.path.join(OUT, "G9m_derivatives_fvgp_4x64.npz"), kernel="matern32_ard", **fx9m)
 
+    # ---- G10: validation scores and P x P information measures (callers of the posterior) ----------------
+    x, y = synth(400, 2)
+    nv = np.full(400, 0.01)
+    th = np.array([1.1, 0.35, 0.45])
+    gp = fvgp.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function=ref_rbf)
+    o = orc.OracleGP(x, y, th, nv, kernel="rbf_ard")
+    rng = np.random.default_rng(77)
+    xt = rng.random((40, 2))
+    yt = np.sin(3.0 * np.sum(xt, axis=1)) + 0.1 * rng.standard_normal(40)
+    ref_scores = {"rmse": gp.rmse(xt, yt), "nrmse": gp.nrmse(xt, yt), "mae": gp.mae(xt, yt), "mape": gp.mape(xt, yt),
+                  "r2": gp.r2(xt, yt), "nlpd": gp.nlpd(xt, yt), "msll": gp.msll(xt, yt),
+                  "crps_mean": gp.crps(xt, yt)[0], "crps_std": gp.crps(xt, yt)[1], "picp": gp.picp(xt, yt),
+                  "mpiw": gp.mpiw(xt), "interval_score": gp.interval_score(xt, yt)}
+    osc = orc.validation_scores(o, xt, yt)
+    for k2, v2 in ref_scores.items():
+        check("G10." + k2, osc[k2], v2, 1e-10)
+    cc = gp.coverage_curve(xt, yt)
+    xq = rng.random((6, 2))
+    cm = rng.standard_normal(6) * 0.1 + np.sin(3.0 * np.sum(xq, axis=1))
+    Bq = rng.standard_normal((6, 6))
+    cq = Bq @ Bq.T * 0.01 + 0.05 * np.eye(6)
+    ref_info = {"kl_div": gp.gp_kl_div(xq, cm, cq)["kl-div"], "rie": gp.gp_relative_information_entropy(xq)["RIE"],
+                "rie_set": gp.gp_relative_information_entropy_set(xq)["RIE"]}
+    pp = gp.posterior_probability(xq, cm, cq)
+    ref_info.update(pp_mu=pp["mu"], pp_cov=pp["covariance"], pp_prob=pp["probability"])
+    oi = orc.information_measures(o, xq, cm, cq)
+    for k2, v2 in ref_info.items():
+        check("G10." + k2, oi[k2], v2, 1e-8)
+    np.savez_compressed(os.path.join(OUT, "G10_scores_rbf_n400_d2.npz"), kernel="rbf_ard", x=x, y=y, noise_variances=nv, theta=th,
+                        x_test=xt, y_test=yt, x_q=xq, comp_mean=cm, comp_cov=cq,
+                        coverage_target=np.array(cc["target_coverage"]), coverage_measured=np.array(cc["measured_coverage"]),
+                        grid2d=fvgp.GP.make_2d_x_pred([0, 1], [2, 3], 4, 3), grid1d=fvgp.GP.make_1d_x_pred([0, 2], 5),
+                        **{"score_" + k2: v2 for k2, v2 in ref_scores.items()}, **{"info_" + k2: v2 for k2, v2 in ref_info.items()})
+
     print(f"{'check':32s} {'rel.diff':>10s} {'tol':>8s}")
     for tag, r, tol in report:
         print(f"{tag:32s} {r:10.2e} {tol:8.0e}")

@@ -330,3 +330,32 @@ def test_finite_difference_derivatives_match_the_reference():
     r = gm.posterior_covariance_grad(xp5, x_out=xo, direction=1)
     np.testing.assert_allclose(r["dv/dx"], fm["dv_dir1"], rtol=0, atol=5e-5 * s6)
     np.testing.assert_allclose(r["dS/dx"], fm["dS_dir1"], rtol=0, atol=5e-5 * s6)
+
+
+def test_validation_scores_and_information_measures_match_the_reference():
+    """The facade's scores (fvgp_amd/gp_validation.py) on the device posterior against the reference's values."""
+    import fvgp_amd
+    fx = load_golden("G10_scores_rbf_n400_d2.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], noise_variances=fx["noise_variances"],
+                         kernel_function="rbf_ard")
+    xt, yt = fx["x_test"], fx["y_test"]
+    got = {"rmse": gp.rmse(xt, yt), "nrmse": gp.nrmse(xt, yt), "mae": gp.mae(xt, yt), "mape": gp.mape(xt, yt), "r2": gp.r2(xt, yt),
+           "nlpd": gp.nlpd(xt, yt), "msll": gp.msll(xt, yt), "crps_mean": gp.crps(xt, yt)[0], "crps_std": gp.crps(xt, yt)[1],
+           "picp": gp.picp(xt, yt), "mpiw": gp.mpiw(xt), "interval_score": gp.interval_score(xt, yt)}
+    for k, v in got.items():
+        np.testing.assert_allclose(v, fx["score_" + k], rtol=1e-7, err_msg=k)
+    cc = gp.coverage_curve(xt, yt)
+    np.testing.assert_allclose(cc["target_coverage"], fx["coverage_target"])
+    np.testing.assert_allclose(cc["measured_coverage"], fx["coverage_measured"], atol=1e-12)
+    xq, cm, cq = fx["x_q"], fx["comp_mean"], fx["comp_cov"]
+    np.testing.assert_allclose(gp.gp_kl_div(xq, cm, cq)["kl-div"], fx["info_kl_div"], rtol=1e-6)
+    np.testing.assert_allclose(gp.gp_relative_information_entropy(xq)["RIE"], fx["info_rie"], rtol=1e-6)
+    np.testing.assert_allclose(gp.gp_relative_information_entropy_set(xq)["RIE"], fx["info_rie_set"], rtol=1e-6)
+    pp = gp.posterior_probability(xq, cm, cq)
+    np.testing.assert_allclose(pp["mu"], fx["info_pp_mu"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(pp["covariance"], fx["info_pp_cov"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(pp["probability"], fx["info_pp_prob"], rtol=1e-6)
+    assert np.array_equal(fvgp_amd.GP.make_2d_x_pred([0, 1], [2, 3], 4, 3), fx["grid2d"])
+    assert np.array_equal(fvgp_amd.GP.make_1d_x_pred([0, 2], 5), fx["grid1d"])

@@ -148,3 +148,16 @@ def test_finite_difference_derivatives_match_the_reference():
     assert om.posterior_mean_grad(xp5, x_out=xo)["dm/dx"].shape == fm["dm_all"].shape == (6, 2, 4)
     np.testing.assert_allclose(om.posterior_mean_grad(xp5, x_out=xo)["dm/dx"], fm["dm_all"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(om.posterior_covariance_grad(xp5, x_out=xo, direction=1)["dS/dx"], fm["dS_dir1"], rtol=0, atol=1e-9)
+
+
+def test_validation_scores_and_information_measures_match_the_reference():
+    """RMSE .. interval score (fvgp/gp.py:1754-2071) and the P x P KL / RIE / posterior-probability measures
+    (gp_posterior.py:408-552) restated on the oracle's posterior."""
+    fx = load_golden("G10_scores_rbf_n400_d2.npz")
+    o = orc.OracleGP(fx["x"], fx["y"], fx["theta"], fx["noise_variances"], kernel="rbf_ard")
+    sc = orc.validation_scores(o, fx["x_test"], fx["y_test"])
+    for k, v in sc.items():
+        np.testing.assert_allclose(v, fx["score_" + k], rtol=1e-10, err_msg=k)
+    info = orc.information_measures(o, fx["x_q"], fx["comp_mean"], fx["comp_cov"])
+    for k, v in info.items():
+        np.testing.assert_allclose(v, fx["info_" + k], rtol=1e-8, atol=1e-12, err_msg=k)
