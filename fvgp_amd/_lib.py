@@ -22,7 +22,7 @@ MAX_RHS_VEC = 8
 
 # every symbol include/fvgp_hip.h declares (tests check the library exports each of them)
 SYMBOLS = [
-    "fvgp_hip_version", "fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_create",
+    "fvgp_hip_version", "fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_workspace_bytes", "fvgp_hip_create",
     "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_stream_create", "fvgp_hip_stream_destroy", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_posterior", "fvgp_hip_gemm",
@@ -75,6 +75,8 @@ def lib():
     L.fvgp_hip_last_error_string.restype = ctypes.c_char_p
     L.fvgp_hip_padded_dim.restype = c_l
     L.fvgp_hip_padded_dim.argtypes = [c_l]
+    L.fvgp_hip_workspace_bytes.argtypes = [c_l, c_l]
+    L.fvgp_hip_workspace_bytes.restype = c_l
     L.fvgp_hip_create.argtypes = [ctypes.POINTER(c_p), c_i, c_p]
     L.fvgp_hip_destroy.argtypes = [c_p]
     L.fvgp_hip_sync.argtypes = [c_p]
@@ -104,7 +106,7 @@ def lib():
     L.fvgp_hip_debug_tile_map.argtypes = [c_i, c_i, c_i, c_i, c_i, P_i, P_i, c_l]
     L.fvgp_hip_debug_tile_map.restype = c_l
     for s in SYMBOLS:
-        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map"):
+        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map", "fvgp_hip_workspace_bytes"):
             getattr(L, s).restype = c_i
     _lib = L
     return L

@@ -17,6 +17,15 @@ extern "C" {
 
 int fvgp_hip_version(void) { return 100; }
 const char *fvgp_hip_last_error_string(void) { return g_err.c_str(); }
+int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred) {
+    // what a handle allocates on the device for problems of n points (and npred prediction points):
+    // inverted 128 x 128 diagonal blocks + per-leaf log-det partials + the solve / posterior scratch + reductions
+    if (n <= 0 || npred < 0) return -1;
+    const int64_t np = pad128(n), nblk = np / TILE, pp = pad128(npred);
+    const int64_t vec = np * 16 + pp * 16 > np * 8 ? np * 16 + pp * 16 : np * 8;      // posterior mean widening vs vector sweeps
+    return (nblk * LEAF_DOUBLES + nblk + (npred > 0 ? vec : np * 8) + RED_SLOTS) * (int64_t)sizeof(double) + (int64_t)sizeof(int);
+}
+
 int64_t fvgp_hip_padded_dim(int64_t n) { return pad128(n); }
 
 int fvgp_hip_create(fvgp_handle **out, int device, void *stream) {

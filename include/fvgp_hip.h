@@ -56,6 +56,9 @@ enum fvgp_uplo { FVGP_FULL = 0, FVGP_LOWER = 1 };
 int fvgp_hip_version(void);
 const char *fvgp_hip_last_error_string(void);
 int64_t fvgp_hip_padded_dim(int64_t n);
+/* device bytes a handle allocates by itself for problems of n points (npred prediction points, 0 = none);
+ * every N x N buffer is the caller's (gp_kv.py keeps Chol_factor / KVinvY as attributes the same way) */
+int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred);
 
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL */
 int fvgp_hip_create(fvgp_handle **out, int device, void *stream);

@@ -121,3 +121,12 @@ def test_named_kernel_resolution():
     with pytest.raises(ValueError):
         kernels.resolve("nope")
     assert kernels.rbf_ard.n_hyperparameters(3) == 4 and kernels.rbf_iso.n_hyperparameters(3) == 2
+
+
+def test_workspace_bytes_query(L):
+    """Handle-scoped device memory is small and monotone; every N x N buffer is the caller's (SURVEY 8b ownership)."""
+    w50 = L.fvgp_hip_workspace_bytes(50000, 0)
+    assert 50e6 < w50 < 60e6                       # 391 inverted 128x128 blocks dominate
+    assert L.fvgp_hip_workspace_bytes(50000, 1000) > w50
+    assert L.fvgp_hip_workspace_bytes(20000, 0) < w50
+    assert L.fvgp_hip_workspace_bytes(0, 0) == -1 and L.fvgp_hip_workspace_bytes(10, -1) == -1
