@@ -231,7 +231,7 @@ def main():
 
     if rank == 0:
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
         if os.path.exists(tfile) and n == 50000:
             # HBM-side bytes per trailing-update launch from the committed rocprofv3 --pmc passes of this same
             # command (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); not re-measured live
