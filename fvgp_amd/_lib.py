@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libfvgp_hip.so")
+LIB_PATH = os.environ.get("FVGP_HIP_LIB", os.path.join(CSRC, "libfvgp_hip.so"))     # FVGP_HIP_LIB: A/B another build of the same ABI
 
 KERNEL_IDS = {"rbf_ard": 0, "matern32_ard": 1, "matern52_ard": 2,
               "rbf_iso": 3, "matern32_iso": 4, "matern52_iso": 5}

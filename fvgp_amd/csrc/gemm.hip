@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const double *pb = &smem[cur][1][0];
         // the fragment reads and MFMAs of this wave go out at raised priority; the memory phase of the K step (global
         // loads above, LDS writes and barrier below) yields to the co-resident workgroup's MFMAs (+1.3 % on 8192^3)
-        if (DBG != 8) __builtin_amdgcn_s_setprio(1);
+        if (DBG != 8) __builtin_amdgcn_s_setprio(ROLE ? 1 : 2);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             double a[4], bv[4];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (DBG != 8) __builtin_amdgcn_s_setprio(0);
+        if (DBG != 8) __builtin_amdgcn_s_setprio(ROLE ? 0 : 1);
         if (more && !(DBG & 1)) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {

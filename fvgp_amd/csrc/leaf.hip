@@ -122,6 +122,9 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
     __shared__ double sT[NT * TSZ];      // 73,728 B
     __shared__ double srd[128];          // 1 / L_aa
     __shared__ double slog[8];
+    // the leaf sits on the critical path of the panel chain and shares its SIMDs with trailing-update waves
+    // (look-ahead): its instructions go first
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     double *A = g.A + (long)blockIdx.x * g.a_stride;
