@@ -69,7 +69,8 @@ def _run_file(world, tmp_path, **kw):
 
 @pytest.mark.parametrize("world,n,panel,kernel,ncol", [(2, 700, 256, "rbf_ard", 1), (3, 900, 128, "matern52_ard", 1),
                                                        (2, 1100, 384, "matern32_ard", 2), (4, 1300, 256, "rbf_ard", 1),
-                                                       (4, 300, 128, "rbf_ard", 1)])
+                                                       (4, 300, 128, "rbf_ard", 1), (8, 2100, 256, "rbf_ard", 1),
+                                                       (5, 1500, 384, "matern52_ard", 2), (8, 2100, 1024, "rbf_ard", 1)])
 def test_sharded_loglik_equals_dense(tmp_path, world, n, panel, kernel, ncol):
     d = 3
     theta = [1.0, 0.3, 0.35, 0.4]
