@@ -52,7 +52,7 @@ def test_single_rank_hip_ops_match_fused_path():
     np.testing.assert_allclose(ll, oracle, rtol=1e-10)
 
 
-@pytest.mark.parametrize("world,n,panel", [(2, 2000, 256), (3, 1700, 384)])
+@pytest.mark.parametrize("world,n,panel", [(2, 2000, 256), (3, 1700, 384), (8, 2500, 256)])
 def test_ranks_sharing_one_gpu_over_gloo(tmp_path, world, n, panel):
     f = tmp_path / "worker.py"
     f.write_text(WORKER.format(root=ROOT, n=n, panel=panel))
