@@ -763,8 +763,12 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
     // cross covariance k(x_data, x_pred) (gp_prior.py:200-215), zero padding
     k.x1 = x; k.n1 = n; k.x2 = xpred; k.n2 = P; k.vdiag = nullptr; k.K = kx; k.ldk = ldk; k.uplo = FVGP_FULL; k.pad = 2;
     rc = launch_kmat(h, k); if (rc) return rc;
-    if (mean_out) {
-        // mean = k^T alpha: GEMM with alpha widened to 128 columns in the handle scratch;
+    if (mean_out && ncol <= FVGP_MAX_RHS_VEC) {
+        // mean = k^T alpha: one streaming pass over k (k is read once: 8 N P bytes), fixed-order reduction
+        rc = ensure_scratch(h, (kt_alpha_scratch_doubles(n, P, ncol) + 7) / 8); if (rc) return rc;
+        rc = launch_kt_alpha(h, kx, ldk, alpha, ncol, n, P, h->vec, mean_out); if (rc) return rc;
+    } else if (mean_out) {
+        // many columns of y: GEMM with alpha widened to 128 columns in the handle scratch;
         // the (Pp x 128) result goes to the tail of the same scratch
         rc = ensure_scratch(h, np * 16 + Pp * 16); if (rc) return rc;
         double *aw = h->vec;
