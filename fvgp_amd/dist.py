@@ -71,8 +71,15 @@ class HipOps:
         self.chain = HipOps(_lib.Handle(self.H.device, stream=side.cuda_stream), _stream=side)
 
     def close(self):
+        """Release what this object created: the chain-side handle, and with reserve_cus the main handle and both
+        CU-masked streams -- handles first, they synchronise their stream when destroyed."""
         self.torch.cuda.synchronize(self.H.device)
-        for st in getattr(self, "_owned", []):
+        if self.chain is not self:
+            self.chain.H.close()
+        owned = getattr(self, "_owned", [])
+        if owned:
+            self.H.close()
+        for st in owned:
             _lib.destroy_stream(st)
         self._owned = []
 

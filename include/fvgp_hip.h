@@ -60,7 +60,8 @@ int64_t fvgp_hip_padded_dim(int64_t n);
  * every N x N buffer is the caller's (gp_kv.py keeps Chol_factor / KVinvY as attributes the same way) */
 int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred);
 
-/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL */
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL; it must outlive the handle
+ * (fvgp_hip_destroy synchronises it) */
 int fvgp_hip_create(fvgp_handle **out, int device, void *stream);
 int fvgp_hip_destroy(fvgp_handle *h);
 int fvgp_hip_sync(fvgp_handle *h);
