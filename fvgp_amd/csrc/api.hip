@@ -766,7 +766,7 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
     if (mean_out && ncol <= FVGP_MAX_RHS_VEC) {
         // mean = k^T alpha: one streaming pass over k (k is read once: 8 N P bytes), fixed-order reduction
         rc = ensure_scratch(h, (kt_alpha_scratch_doubles(n, P, ncol) + 7) / 8); if (rc) return rc;
-        rc = launch_kt_alpha(h, kx, ldk, alpha, ncol, n, P, h->vec, mean_out); if (rc) return rc;
+        rc = launch_kt_alpha(h, kx, ldk, alpha, ncol, ncol, n, P, h->vec, mean_out, ncol, 1.0, 0); if (rc) return rc;
     } else if (mean_out) {
         // many columns of y: GEMM with alpha widened to 128 columns in the handle scratch;
         // the (Pp x 128) result goes to the tail of the same scratch
@@ -781,15 +781,23 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
         rc = launch_copy_cols(h, mw, 128, mean_out, ncol, P, ncol, P, ncol); if (rc) return rc;
     }
     if (var_out || S_out) {
-        rc = trsm_fwd_gemm(h, L, n, ldl, kx, Pp, ldk); if (rc) return rc;   // kx <- L^-1 k
+        const bool few = P <= 4;      // a handful of prediction points (acquisition-function optimisers ask for one at a
+                                      // time): vector sweeps instead of 128-wide GEMM tiles; measured break-even between 4 and 8
+        if (few) { rc = potrs_vec(h, L, n, ldl, kx, P, ldk, false); if (rc) return rc; }       // kx <- L^-1 k
+        else { rc = trsm_fwd_gemm(h, L, n, ldl, kx, Pp, ldk); if (rc) return rc; }
         if (S_out) {
             KmatDesc kk = k;
             kk.x1 = xpred; kk.n1 = P; kk.x2 = xpred; kk.n2 = P; kk.K = S_out; kk.ldk = lds; kk.uplo = FVGP_FULL; kk.pad = 2;
             rc = launch_kmat(h, kk); if (rc) return rc;
-            GemmDesc g{};
-            g.a_kmajor = 1; g.b_nmajor = 1; g.lower = 0; g.M = Pp; g.N = Pp; g.K = np; g.alpha = -1.0; g.beta = 1.0;
-            g.A = kx; g.lda = ldk; g.B = kx; g.ldb = ldk; g.C = S_out; g.ldc = lds;
-            rc = launch_gemm(h, g); if (rc) return rc;
+            if (few) {   // S -= V^T V as a streaming pass over V (P x P outputs)
+                rc = ensure_scratch(h, np + (kt_alpha_scratch_doubles(n, P, (int)P) + 7) / 8); if (rc) return rc;
+                rc = launch_kt_alpha(h, kx, ldk, kx, ldk, (int)P, n, P, h->vec + np * 8, S_out, lds, -1.0, 1); if (rc) return rc;
+            } else {
+                GemmDesc g{};
+                g.a_kmajor = 1; g.b_nmajor = 1; g.lower = 0; g.M = Pp; g.N = Pp; g.K = np; g.alpha = -1.0; g.beta = 1.0;
+                g.A = kx; g.lda = ldk; g.B = kx; g.ldb = ldk; g.C = S_out; g.ldc = lds;
+                rc = launch_gemm(h, g); if (rc) return rc;
+            }
         }
         if (var_out) {
             // v_p = k(x_p,x_p) - |L^-1 k_p|^2 ; stationary kernels: k(x,x) = signal variance

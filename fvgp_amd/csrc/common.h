@@ -125,8 +125,8 @@ int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, 
 int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D);
 int launch_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);
 int64_t kt_alpha_scratch_doubles(int64_t n, int64_t P, int ncol);
-int launch_kt_alpha(fvgp_handle *h, const double *K, int64_t ldk, const double *alpha, int ncol, int64_t n, int64_t P,
-                    double *scratch, double *out);
+int launch_kt_alpha(fvgp_handle *h, const double *K, int64_t ldk, const double *alpha, int64_t lda, int ncol, int64_t n, int64_t P,
+                    double *scratch, double *out, int64_t ldo, double scale, int accumulate);
 int launch_copy_lower_tiles(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t np);
 
 int ensure_linv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl);

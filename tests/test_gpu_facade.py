@@ -359,3 +359,22 @@ def test_validation_scores_and_information_measures_match_the_reference():
     np.testing.assert_allclose(pp["probability"], fx["info_pp_prob"], rtol=1e-6)
     assert np.array_equal(fvgp_amd.GP.make_2d_x_pred([0, 1], [2, 3], 4, 3), fx["grid2d"])
     assert np.array_equal(fvgp_amd.GP.make_1d_x_pred([0, 2], 5), fx["grid1d"])
+
+
+@pytest.mark.parametrize("P", [1, 2, 4, 5, 8])
+def test_posterior_few_points_paths_agree_with_the_oracle(P):
+    """A handful of prediction points takes the vector-sweep path (P <= 4), more the GEMM path: same numbers."""
+    import fvgp_amd
+    fx = load_golden("G2_rbf_n512_d3.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], noise_variances=fx["noise_variances"],
+                         kernel_function="rbf_ard")
+    o = orc.OracleGP(fx["x"], fx["y"], fx["theta"], fx["noise_variances"], kernel="rbf_ard")
+    xp = fx["x_pred"][:P]
+    got, want = gp.posterior_covariance(xp), o.posterior_covariance(xp)
+    np.testing.assert_allclose(got["S"], want["S"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(got["v(x)"], want["v(x)"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(gp.posterior_mean(xp)["m(x)"], o.posterior_mean(xp)["m(x)"], rtol=1e-9)
+    gotn = gp.posterior_covariance(xp, add_noise=True)
+    np.testing.assert_allclose(gotn["S"], o.posterior_covariance(xp, add_noise=True)["S"], rtol=0, atol=1e-10)

@@ -27,6 +27,6 @@ def T(f, reps=3):
 
 
 print("loglik(theta) ms", T(lambda: gp.log_likelihood(th * 1.01)))
-for P in (1000, 4000):
+for P in (1, 2, 4, 8, 64, 1000, 4000):
     xp = np.random.default_rng(2).random((P, 3))
     print(f"P={P}: posterior_mean ms", T(lambda: gp.posterior_mean(xp)), " posterior_covariance ms", T(lambda: gp.posterior_covariance(xp)))
