@@ -174,12 +174,8 @@ static int check_square(const void *A, int64_t n, int64_t ld, int argA, int argn
 }
 
 // ---------------------------------------------------------------------------------------
-// blocked right-looking Cholesky, two block sizes:
-//   inner 128: leaf (potf2 + trtri in LDS) -> panel TRSM as GEMM with inv(L_kk) -> update of
-//              the remaining columns of the current outer panel (K = 128);
-//   outer NB : one trailing SYRK per outer panel with K = NB, which carries ~all the flops
-//              and keeps the C-tile read-modify-write traffic at 8/NB bytes per flop.
-// factor the outer panel [J0, Jend): leaf / TRSM / in-panel update per 128 columns, on h->stream
+// one (sub-)panel of the blocked Cholesky, 128 columns at a time: leaf (potf2 + trtri in LDS) -> panel TRSM as a
+// GEMM with inv(L_kk) -> update of the remaining columns of this (sub-)panel (K = 128)
 static int panel_factor(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
     int rc;
     for (int64_t k0 = J0; k0 < Jend; k0 += TILE) {
@@ -249,11 +245,13 @@ static double lower_flops(int64_t M, int64_t N, int64_t K) {     // algorithmic 
 }
 
 // ---------------------------------------------------------------------------------------
-// blocked right-looking Cholesky, two block sizes:
-//   inner 128: leaf (potf2 + trtri in LDS) -> panel TRSM as GEMM with inv(L_kk) -> update of
-//              the remaining columns of the current outer panel (K = 128);
-//   outer NB : one trailing SYRK per outer panel with K = NB, which carries ~all the flops
-//              and keeps the C-tile read-modify-write traffic at 8/NB bytes per flop.
+// blocked right-looking Cholesky, three block sizes:
+//   128        : panel_factor above;
+//   inner_block: a wide outer panel is factored in sub-panels of this width, each followed by one update of the rest
+//                of the outer panel with K = inner_block (panel_factor_nested);
+//   outer NB   : one trailing SYRK per outer panel with K = NB (outer_block, or outer_block_big while more than
+//                big_threshold rows remain), which carries ~all the flops and keeps the C-tile read-modify-write
+//                traffic at 8/NB bytes per flop.
 // look-ahead (option "lookahead"): the trailing update of panel J is split into the block columns of
 // panel J+1 (done first) and the rest; panel J+1 is then factored on a second, high-priority stream
 // while the rest of the update runs on the main stream.
