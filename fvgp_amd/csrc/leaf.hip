@@ -131,15 +131,28 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
     double *linv = g.linv + (long)blockIdx.x * g.linv_stride;
 
     // ---- load the lower triangle into packed tiles; strict upper of diagonal tiles <- 0 ----------
-    for (int e = tid; e < 128 * 64; e += 512) {
-        const int row = e >> 6, c2 = (e & 63) * 2;
-        const int ti = row >> 4, tj = c2 >> 4;
-        if (tj > ti) continue;
-        double2_t v = *reinterpret_cast<const double2_t *>(A + (long)row * g.lda + c2);
-        if (c2 + 1 > row) v[1] = 0.0;
-        if (c2 > row) v[0] = 0.0;
-        double *dst = &sT[tix(ti, tj)];
-        dst[el(row & 15, c2 & 15)] = v[0]; dst[el(row & 15, (c2 & 15) + 1)] = v[1];
+    {
+        // eight loads of a thread in flight per LDS-write batch (two memory round trips instead of sixteen)
+        const int c2 = (tid & 63) * 2, tj = c2 >> 4, rbase = tid >> 6;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            double2_t v[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = rbase + 8 * (8 * hb + it);
+                v[it] = (double2_t){0.0, 0.0};
+                if (tj <= (row >> 4)) v[it] = *reinterpret_cast<const double2_t *>(A + (long)row * g.lda + c2);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = rbase + 8 * (8 * hb + it), ti = row >> 4;
+                if (tj > ti) continue;
+                if (c2 + 1 > row) v[it][1] = 0.0;
+                if (c2 > row) v[it][0] = 0.0;
+                double *dst = &sT[tix(ti, tj)];
+                dst[el(row & 15, c2 & 15)] = v[it][0]; dst[el(row & 15, (c2 & 15) + 1)] = v[it][1];
+            }
+        }
     }
     __syncthreads();
 
