@@ -52,16 +52,36 @@ def test_single_rank_hip_ops_match_fused_path():
     np.testing.assert_allclose(ll, oracle, rtol=1e-10)
 
 
-@pytest.mark.parametrize("world,n,panel", [(2, 2000, 256), (3, 1700, 384), (8, 2500, 256)])
+# The box allows at most 6 processes on its GPU: pytest + at most 4 ranks here; the 5- and 8-rank
+# partitions are covered over gloo on the CPU (tests/test_dist_cpu.py).
+@pytest.mark.parametrize("world,n,panel", [(2, 2000, 256), (3, 1700, 384), (4, 2500, 256)])
 def test_ranks_sharing_one_gpu_over_gloo(tmp_path, world, n, panel):
     f = tmp_path / "worker.py"
     f.write_text(WORKER.format(root=ROOT, n=n, panel=panel))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(f)],
-                         capture_output=True, text=True, env=env, timeout=600)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    # ranks are started directly (no torchrun launcher process): GPU holders = pytest + `world` ranks <= 5
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world))
+        so, se = open(tmp_path / f"out{r}.txt", "w+"), open(tmp_path / f"err{r}.txt", "w+")
+        procs.append((subprocess.Popen([sys.executable, str(f)], stdout=so, stderr=se, text=True, env=env), so, se))
+    try:
+        for p, _, _ in procs:
+            p.wait(timeout=600)
+    finally:
+        for p, _, _ in procs:
+            if p.poll() is None:
+                p.kill()
+    texts = []
+    for p, so, se in procs:
+        so.seek(0); se.seek(0)
+        texts.append((so.read(), se.read()))
+        so.close(); se.close()
+        assert p.returncode == 0, texts[-1][0][-2000:] + texts[-1][1][-4000:]
+
+    class res:
+        stdout = texts[0][0]
     import json
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     x, y = synth(n, 3)
