@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=18000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0:
+        ap.error("--steps must be >= 1 and --warmup >= 0")
 
     import torch
     from fvgp_amd import _lib
@@ -282,7 +284,7 @@ def main():
                 if rank == 0 and out is not None:
                     out["sharded"] = {"error": f"no result within {args.sharded_timeout:.0f} s"}
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)            # a hung collective is a failed run: the launcher must see it
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:

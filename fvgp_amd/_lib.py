@@ -27,7 +27,7 @@ SYMBOLS = [
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize",
-    "fvgp_hip_debug_tile_map", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
+    "fvgp_hip_debug_tile_map", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
 ]
 
 
@@ -84,6 +84,7 @@ def lib():
     L.fvgp_hip_stream_destroy.argtypes = [c_p]
     L.fvgp_hip_set_option.argtypes = [c_p, ctypes.c_char_p, c_l]
     L.fvgp_hip_get_profile.argtypes = [c_p, P_d]
+    L.fvgp_hip_invalidate_factor.argtypes = [c_p]
     L.fvgp_hip_kmat.argtypes = [c_p, c_i, c_p, c_l, c_p, c_l, c_i, P_d, c_i, c_p, c_p, c_l, c_i, c_i]
     L.fvgp_hip_potrf.argtypes = [c_p, c_p, c_l, c_l, P_i]
     L.fvgp_hip_potrf_dev.argtypes = [c_p, c_p, c_l, c_l, c_l, c_p, c_p]
@@ -193,6 +194,10 @@ class Handle:
 
     def set_option(self, key, value):
         _check(lib().fvgp_hip_set_option(self._h, key.encode(), int(value)), "fvgp_hip_set_option")
+
+    def invalidate_factor(self):
+        """Forget the cached diagonal-block inverses: call after writing a factor buffer by anything but potrf."""
+        _check(lib().fvgp_hip_invalidate_factor(self._h), "fvgp_hip_invalidate_factor")
 
     def get_profile(self):
         out = (ctypes.c_double * 8)()

@@ -115,6 +115,12 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     return -2;
 }
 
+int fvgp_hip_invalidate_factor(fvgp_handle *h) {
+    if (!h) return -1;
+    h->linv_L = nullptr;
+    return 0;
+}
+
 int fvgp_hip_get_profile(fvgp_handle *h, double *out) {
     if (!h) return -1;
     if (!out) return -2;
@@ -628,6 +634,7 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     if (!x) return -3;
     if (n <= 0) return -4;
     if (!theta) return -6;
+    if (!vdiag) { fvgp_set_error("loglik needs the noise variances (vdiag)"); return -8; }
     if (!ymean) return -9;
     if (ncol < 1 || ncol > FVGP_MAX_RHS_VEC) { fvgp_set_error("1 <= ncol <= 8"); return -10; }
     int rc = check_square(KV, n, ld, 11, 4, 12);

@@ -187,7 +187,8 @@ class GP(ValidationMixin):
         ymean = self.y_data - m[:, None]
         ym_dev = H.to_device(ymean)
         ncol = ymean.shape[1]
-        if self._native is not None and ncol <= _lib.MAX_RHS_VEC:
+        # the fused call bounds the appended (y-m)^T rows with 1 + |y-m|^2 / min(V): it needs positive noise
+        if self._native is not None and ncol <= _lib.MAX_RHS_VEC and float(np.min(V)) > 0.0:
             ll, logdet, quad, info = H.loglik(self._native.kernel_id, self._x_dev, hps, H.to_device(V), ym_dev, KV, alpha)
         else:
             if self._native is not None:
@@ -238,6 +239,7 @@ class GP(ValidationMixin):
             return
         H, n = self._H, self.point_number
         inv = self._L.clone()
+        H.invalidate_factor()                                     # `inv` may sit where a freed factor used to be
         work = H.empty(self._np, self._np)
         H.potri(inv, n, work)
         H.symmetrize(inv, n)
@@ -314,6 +316,7 @@ class GP(ValidationMixin):
         if np_new > n:
             Lnew[n:, n:].fill_diagonal_(1.0)
         del B, S
+        H.invalidate_factor()                                     # Lnew was filled by copies, not by potrf
         self._np, self._L = np_new, Lnew
         self._x_dev = H.to_device(self.x_data)
         ncol = self.y_data.shape[1]
@@ -777,6 +780,7 @@ class GP(ValidationMixin):
             self._L[n:, n:] = H.to_device(np.eye(self._np - n))
         self._alpha = H.zeros(self._np, self.y_data.shape[1])
         self._alpha[:n] = H.to_device(a_host)
+        H.invalidate_factor()                                     # uploaded factor: no cached block inverses belong to it
         self._work = self._work2 = self._alpha_work = None
         self._KVinv = None
         self._refresh_inverse()

@@ -82,6 +82,12 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value);
  * 128-tiles written once), out[6] = ms of everything after the factorisation (backward solve, reductions);
  * out[7] reserved.  out needs 8 doubles. */
 int fvgp_hip_get_profile(fvgp_handle *h, double *out8_host);
+/* The handle keeps the inverted 128 x 128 diagonal blocks of the LAST factor it produced or solved with, keyed
+ * on (pointer, n, ld).  A caller that fills a factor buffer by any other means than fvgp_hip_potrf / _loglik
+ * (upload of a pickled factor, bordering update, device-to-device copy: gp_kv.py:462-476,718-765) must call
+ * this before the next potrs / trsm / potri / posterior on that buffer -- an allocator may hand back the
+ * address of a freed factor of the same size. */
+int fvgp_hip_invalidate_factor(fvgp_handle *h);
 
 /* ---- covariance assembly -------------------------------------------------------------
  * replaces GPprior.compute_covariances -> kernel(x1,x2,hps) (gp_prior.py:217-224) and,
@@ -144,7 +150,9 @@ int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, cons
  *   ymean  (n, ncol) row-major = y - m   (default mean: gp_prior.py:449-458, done by caller)
  *   KV     scratch, padded_dim(n) x ld; holds the factor L on return
  *   alpha  (padded_dim(n), ncol) receives KVinvY
- *   out_host[0] = log marginal likelihood, [1] = log|KV|, [2] = sum((y-m)*KVinvY)/ncol */
+ *   out_host[0] = log marginal likelihood, [1] = log|KV|, [2] = sum((y-m)*KVinvY)/ncol
+ *   vdiag is REQUIRED here (n positive noise variances, gp_likelihood.py:89-110): returns -8 when NULL;
+ *   every entry must be positive (the facade takes the unfused kmat/potrf/potrs route otherwise). */
 int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
                     const double *theta_host, int ntheta, const double *vdiag,
                     const double *ymean, int ncol, double *KV, int64_t ld,

@@ -181,6 +181,30 @@ def test_pickle_roundtrip_and_update():
     np.testing.assert_allclose(a.log_likelihood(), fx["logliks"][2], rtol=1e-10)
 
 
+def test_unpickled_factor_never_meets_another_factors_block_inverses():
+    """The handle caches the inverted diagonal blocks of the last factor keyed on its address; torch's allocator
+    hands a freed N x N block back at the same address.  A GP unpickled into the address of a freed, different,
+    same-size GP must still answer from ITS factor (fvgp_hip_invalidate_factor)."""
+    import gc
+    import fvgp_amd
+    fx = load_golden("G2_rbf_n512_d3.npz")
+    kw = dict(noise_variances=fx["noise_variances"], kernel_function="rbf_ard")
+    keep = pickle.dumps(fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], **kw))
+    gc.collect()
+    for _ in range(3):                        # several rounds: whichever block the allocator returns, the answer stands
+        other = fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"] * np.array([3.0, 0.4, 2.0, 0.7]), **kw)
+        other.posterior_covariance(fx["x_pred"])          # leaves ITS block inverses cached under its factor's address
+        ptr = other._L.data_ptr()
+        del other
+        gc.collect()
+        gp2 = pickle.loads(keep)
+        same_block = gp2._L.data_ptr() == ptr
+        assert np.max(np.abs(gp2.posterior_covariance(fx["x_pred"])["S"] - fx["pS"])) <= 1e-10, same_block
+        np.testing.assert_allclose(gp2.posterior_mean(fx["x_pred"])["m(x)"], fx["pm"], rtol=1e-8, atol=1e-10)
+        del gp2
+        gc.collect()
+
+
 def test_rank_n_append_equals_refactorisation():
     """update_gp_data(append=True): bordering update of the device factor (gp_lin_alg.py:1310-1477) against a
     from-scratch factorisation and the reference vectors; unaligned sizes on both sides of the 128 blocks."""
