@@ -108,6 +108,42 @@ __host__ __device__ inline long xcd_remap(long b, long nwg, int tiles_n) {
     return full * per + (k >= 0 ? k : 0);
 }
 
+// epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile.  The read-modify-write of C
+// is done in two batches of 32 loads per lane, all issued before the first use, so a tile pays two
+// memory round trips instead of sixteen.
+__device__ __forceinline__ void store_tile(double4_t (&acc)[4][4], double *cbase, long ldc, double alpha, double beta) {
+    if (beta != 0.0) {
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            double old[2][4][4];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        old[ii][v][j] = cbase[((ih * 2 + ii) * 16 + 4 * v) * ldc + j * 16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        cbase[((ih * 2 + ii) * 16 + 4 * v) * ldc + j * 16] = alpha * acc[ih * 2 + ii][j][v] + beta * old[ii][v][j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cbase[(i * 16 + 4 * v) * ldc + j * 16] = alpha * acc[i][j][v];
+    }
+}
+
 // ROLE only names the instantiation (0 generic, 1 trailing update of the Cholesky) so that profilers list
 // the kernel the metric lives in under its own symbol
 template <int AKM, int BNM, int ROLE, int DBG = 0>
@@ -242,41 +278,106 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         if (!(DBG & 2)) __syncthreads();
     }
 
-    // epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile.  The read-modify-write of C
-    // is done in two batches of 32 loads per lane, all issued before the first use, so a tile pays two
-    // memory round trips instead of sixteen.
-    const double alpha = g.alpha, beta = g.beta;
-    double *cbase = g.C + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r;
-    if (beta != 0.0) {
+    store_tile(acc, g.C + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
+}
+
+// a wave-uniform pointer moved into SGPRs (readfirstlane returns int: widen each half as UNSIGNED)
+__device__ __forceinline__ const double *uniform_ptr(const double *p) {
+    const uintptr_t v = (uintptr_t)p;
+    const uintptr_t lo = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffu));
+    const uintptr_t hi = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<const double *>(lo | (hi << 32));
+}
+
+// LDS-free variant for the (M,K) x (N,K) layout (the trailing update): every wave loads its own MFMA operands straight
+// from global memory into registers.  v_mfma_f64_16x16x4 wants lane (r, q) to hold A[row r][k_q]; WHICH four k a step
+// contracts is free as long as A and B agree, so lane (r, q) takes the two consecutive doubles k0 + 2q, k0 + 2q + 1 of
+// its row (one 16-byte load) and an 8-deep K stage is two MFMAs per accumulator.  No LDS image, no barrier, no
+// fragment reads: 16 loads per 64 MFMAs per wave, each operand row fetched by the two waves that share it (through L1/L2).
+// Two register stages (k0 and k0 + 8) alternate, so a stage's loads have 32 MFMAs of cover.
+// DBG (timing probes, results meaningless): 1 no waits in the loop, 2 no loads in the loop, 4 the loads never advance (cache-resident)
+template <int ROLE, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void gemm_f64_direct_kernel(GemmArgs g) {
+    const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
+    int ti, tj;
+    if (g.lower == 2) tile_of_rs(t, g.tiles_m, g.tiles_n, g.ls, g.lo, ti, tj);
+    else tile_of(t, g.tiles_m, g.tiles_n, g.lower == 1, ti, tj);
+    if (ti >= g.tiles_m || tj >= g.tiles_n) return;
+    if (g.lower == 1 && tj > ti) return;
+    if (g.lower == 2 && tj > ti * g.ls + g.lo) return;
+    if (g.rev) ti = g.tiles_m - 1 - ti;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+
+    long kbeg = g.kb0 + g.kbi * ti + g.kbj * tj;
+    long kend = (g.ke0 < 0 ? g.K : g.ke0 + g.kei * ti + g.kej * tj);
+    if (kbeg < 0) kbeg = 0;
+    if (kend > g.K) kend = g.K;
+    const int nk = kend > kbeg ? (int)((kend - kbeg) / BK) : 0;
+
+    const long m0 = (long)ti * 128, n0 = (long)tj * 128;
+    const int idx = tj + g.bco;
+    const long nb0 = ((long)(idx % g.bcr) * g.bcb + idx / g.bcr) * 128;
+
+    // wave-uniform bases in SGPRs + one 32-bit byte offset per lane and 16-row block (a wave's 64 rows span < 4 GB)
+    const double *abase = g.A + (m0 + wm * 64) * g.lda + kbeg;
+    const double *bbase = g.B + (nb0 + wn * 64) * g.ldb + kbeg;
+    abase = uniform_ptr(abase);
+    bbase = uniform_ptr(bbase);
+    unsigned oa[4], ob[4];
 #pragma unroll
-        for (int ih = 0; ih < 2; ++ih) {
-            double old[2][4][4];
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        old[ii][v][j] = cbase[((ih * 2 + ii) * 16 + 4 * v) * g.ldc + j * 16];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        cbase[((ih * 2 + ii) * 16 + 4 * v) * g.ldc + j * 16] = alpha * acc[ih * 2 + ii][j][v] + beta * old[ii][v][j];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    cbase[(i * 16 + 4 * v) * g.ldc + j * 16] = alpha * acc[i][j][v];
+    for (int i = 0; i < 4; ++i) {
+        oa[i] = (unsigned)(((long)(i * 16 + r) * g.lda + 2 * q) * 8);
+        ob[i] = (unsigned)(((long)(i * 16 + r) * g.ldb + 2 * q) * 8);
     }
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    // The loads are issued by hand (inline asm) so that the wait in front of a stage is exactly "this stage's eight
+    // loads": hipcc merges the wait-count state of the prologue and of the loop's back edge conservatively and would
+    // wait for the stage just issued as well.  The waits carry the fragments as in/out operands, which orders the
+    // consuming MFMAs behind them.
+    double2_t a0[4], b0[4], a1[4], b1[4];
+#define FVGP_LOAD_STAGE(AF, BF, OFF)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                          \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(AF[i]) : "v"(oa[i]), "s"(abase) : "memory");       \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(BF[i]) : "v"(ob[i]), "s"(bbase) : "memory");       \
+    }
+#define FVGP_WAIT_STAGE(AF, BF, N)                                                                                           \
+    asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(AF[0]), "+v"(AF[1]), "+v"(AF[2]), "+v"(AF[3]),                             \
+                                             "+v"(BF[0]), "+v"(BF[1]), "+v"(BF[2]), "+v"(BF[3]) :: "memory")
+#define FVGP_MFMA_STAGE(AF, BF)                                                                          \
+    _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(AF[i][tt], BF[j][tt], acc[i][j], 0, 0, 0)
+    if (nk > 0) {
+        FVGP_LOAD_STAGE(a0, b0, 0)
+        FVGP_LOAD_STAGE(a1, b1, 64)
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            if (!(DBG & 4)) { abase += BK; bbase += BK; }
+            if (!(DBG & 1)) FVGP_WAIT_STAGE(a0, b0, 8);
+            FVGP_MFMA_STAGE(a0, b0);
+            if (!(DBG & 2)) { FVGP_LOAD_STAGE(a0, b0, 0) }
+            if (!(DBG & 1)) FVGP_WAIT_STAGE(a1, b1, 8);
+            FVGP_MFMA_STAGE(a1, b1);
+            if (!(DBG & 2)) { FVGP_LOAD_STAGE(a1, b1, 64) }
+        }
+        FVGP_WAIT_STAGE(a0, b0, 8);
+        FVGP_MFMA_STAGE(a0, b0);
+        FVGP_WAIT_STAGE(a1, b1, 0);
+        FVGP_MFMA_STAGE(a1, b1);
+    }
+#undef FVGP_LOAD_STAGE
+#undef FVGP_WAIT_STAGE
+#undef FVGP_MFMA_STAGE
+    store_tile(acc, g.C + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
 }
 
 __global__ void mfma_selftest_kernel(const double *A, const double *B, double *D) {
@@ -375,6 +476,13 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
     if (g.ntiles == 0) return 0;
     dim3 grid((unsigned)g.ntiles), block(256);
+    if ((d.direct || h->gemm_direct >= 2) && d.probe && !d.a_kmajor && !d.b_nmajor && d.lda < (1L << 22) && d.ldb < (1L << 22)) {
+#define PR(V) case V: hipLaunchKernelGGL((gemm_f64_direct_kernel<0, V>), grid, block, 0, h->stream, g); break
+        switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); default: return -3; }
+#undef PR
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (d.probe) {
         // timing probes of the K loop with parts of it removed (results are meaningless unless noted): 1 no global
         // loads / LDS writes, 2 no barrier, 4 no LDS fragment reads, 8 the full loop without s_setprio (correct
@@ -382,6 +490,13 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
 #define PR(V) case V: hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 0, V>), grid, block, 0, h->stream, g); break
         switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); PR(6); PR(7); PR(8); default: return -3; }
 #undef PR
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    const bool direct_ = d.direct || h->gemm_direct >= 2 || (h->gemm_direct == 1 && d.role == 1 && d.M / 128 <= h->gemm_direct_max_tiles);
+    if (direct_ && !d.probe && !d.a_kmajor && !d.b_nmajor && d.lda < (1L << 22) && d.ldb < (1L << 22)) {   // 64 rows of a wave within a 32-bit byte offset
+        if (d.role == 1) hipLaunchKernelGGL((gemm_f64_direct_kernel<1>), grid, block, 0, h->stream, g);
+        else hipLaunchKernelGGL((gemm_f64_direct_kernel<0>), grid, block, 0, h->stream, g);
         HIPCHK(hipGetLastError());
         return 0;
     }

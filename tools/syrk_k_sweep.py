@@ -1,0 +1,40 @@
+"""Trailing-update kernel alone: time per round of 512 workgroups as a function of K, with and without the C
+read-modify-write, on a compact buffer and on a window of a 50048-wide one (the in-situ leading dimension)."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fvgp_amd import _lib
+
+H = _lib.Handle(0)
+if len(sys.argv) > 1:
+    H.set_option("gemm_direct", int(sys.argv[1]))
+
+
+def timeit(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+big = torch.randn(24576 + 4096, 50048, dtype=torch.float64, device="cuda", generator=g)
+for M in (24576, 8192):
+    for wide in (0,):
+        for K in (512, 1024, 2048, 4096):
+            for beta in (0.0, 1.0):
+                if wide:
+                    A = big[:M, :K]; C = big[:M, 4096:4096 + M]
+                else:
+                    A = torch.randn(M, K, dtype=torch.float64, device="cuda", generator=g)
+                    C = torch.randn(M, M, dtype=torch.float64, device="cuda", generator=g)
+                ms = timeit(lambda: H.gemm(0, 0, 1, M, M, K, -1.0, A, A, beta, C))
+                T = M // 128; tiles = T * (T + 1) // 2
+                fl = tiles * 128 * 128 * 2.0 * K
+                print(json.dumps({"M": M, "K": K, "beta": beta, "ld": 50048 if wide else M, "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 2),
+                                  "us_per_round512": round(1e3 * ms / (tiles / 512.0), 1)}), flush=True)
+                if not wide:
+                    del A, C
