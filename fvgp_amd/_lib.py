@@ -25,7 +25,7 @@ SYMBOLS = [
     "fvgp_hip_version", "fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_workspace_bytes", "fvgp_hip_create",
     "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_stream_create", "fvgp_hip_stream_destroy", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
-    "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_posterior", "fvgp_hip_gemm",
+    "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_grad_trace", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize",
     "fvgp_hip_debug_tile_map", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
 ]
@@ -94,6 +94,7 @@ def lib():
     L.fvgp_hip_potri.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l]
     L.fvgp_hip_loglik.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_p, c_i, c_p, c_l, c_p, P_d, P_i]
     L.fvgp_hip_loglik_grad.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_i, c_i, c_p, c_l, c_p, c_l, P_d]
+    L.fvgp_hip_grad_trace.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_l, c_p, c_l, c_p, P_d]
     L.fvgp_hip_posterior.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_l, c_p, c_i, c_p, c_l,
                                      c_p, c_l, c_p, c_p, c_p, c_l]
     L.fvgp_hip_gemm.argtypes = [c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l]
@@ -273,6 +274,15 @@ class Handle:
         _check(lib().fvgp_hip_loglik_grad(self._h, int(kernel_id), _ptr(x), n, d, tp, nt, _ptr(alpha), int(ncol),
                                           int(component), _ptr(KV), KV.stride(0), _ptr(work), work.stride(0), g),
                "fvgp_hip_loglik_grad")
+        return np.array(g[:], dtype=np.float64)
+
+    def grad_trace(self, kernel_id, x, theta, W, b, partial):
+        """1/2 sum_jk (W_jk - b_j b_k) dK_jk/dtheta_i over the symmetric W (lower triangle read); b a 1-d view or None."""
+        t, tp, nt = _theta(theta)
+        g = (ctypes.c_double * nt)()
+        n, d = x.shape
+        _check(lib().fvgp_hip_grad_trace(self._h, int(kernel_id), _ptr(x), n, d, tp, nt, _ptr(W), W.stride(0),
+                                         _ptr(b), 1 if b is None else b.stride(0), _ptr(partial), g), "fvgp_hip_grad_trace")
         return np.array(g[:], dtype=np.float64)
 
     def posterior(self, kernel_id, x, theta, L, alpha, ncol, xpred, kx, mean_out=None, var_out=None, S_out=None):

@@ -456,6 +456,34 @@ static int read_back(fvgp_handle *h, const double *dev, double *host, int count)
     return 0;
 }
 
+// g_i = 1/2 sum_jk (W_jk - b_j b_k) dK_jk/dtheta_i over the lower triangle of the symmetric W (b may be null):
+// one fused pass that re-evaluates dK/dtheta in registers, per-tile partial sums reduced on the host in a fixed order
+static int grad_trace_host(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d, const double *theta, int ntheta,
+                           const double *W, int64_t ldw, const double *b, int64_t ldb, double *partial, double *grad_host) {
+    GradDesc g{};
+    int rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &g.k); if (rc) return rc;
+    g.k.x1 = x; g.k.n1 = n; g.k.x2 = x; g.k.n2 = n;
+    g.kernel_id = kernel_id;
+    const bool iso = kernel_id >= 3;
+    const int nk = iso ? 2 : d + 1;     // kernel-owned hyperparameters; the rest get a zero gradient
+    g.ntheta = nk;
+    g.W = W; g.ldw = ldw; g.b = b; g.ldb = ldb;
+    g.partial = partial;
+    int nblocks = 0;
+    rc = launch_grad_trace(h, g, &nblocks); if (rc) return rc;
+    // nblocks <= ~80k doubles per theta
+    std::vector<double> part((size_t)nblocks * nk);
+    HIPCHK(hipMemcpyAsync(part.data(), partial, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < ntheta; ++i) grad_host[i] = 0.0;
+    for (int i = 0; i < nk; ++i) {
+        long double s = 0.0L;
+        for (int bb = 0; bb < nblocks; ++bb) s += part[(size_t)bb * nk + i];
+        grad_host[i] = 0.5 * (double)s;
+    }
+    return 0;
+}
+
 extern "C" {
 
 int fvgp_hip_kmat(fvgp_handle *h, int kernel_id, const double *x1, int64_t n1, const double *x2, int64_t n2,
@@ -722,28 +750,24 @@ int fvgp_hip_loglik_grad(fvgp_handle *h, int kernel_id, const double *x, int64_t
     HIPCHK(hipSetDevice(h->device));
     int rc = fvgp_hip_potri(h, KV, n, ld, work, ldw);
     if (rc) return rc;
-    GradDesc g{};
-    rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &g.k); if (rc) return rc;
-    g.k.x1 = x; g.k.n1 = n; g.k.x2 = x; g.k.n2 = n;
-    g.kernel_id = kernel_id;
-    const bool iso = kernel_id >= 3;
-    const int nk = iso ? 2 : d + 1;     // kernel-owned hyperparameters; the rest get a zero gradient
-    g.ntheta = nk;
-    g.W = KV; g.ldw = ld; g.b = alpha + component; g.ldb = ncol;
-    g.partial = work;                    // inv(L) is dead by now: reuse as the partial-sum buffer
-    int nblocks = 0;
-    rc = launch_grad_trace(h, g, &nblocks); if (rc) return rc;
-    // reduce partial (nblocks x nk) on the host side: nblocks <= ~80k doubles per theta
-    std::vector<double> part((size_t)nblocks * nk);
-    HIPCHK(hipMemcpyAsync(part.data(), work, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < ntheta; ++i) grad_host[i] = 0.0;
-    for (int i = 0; i < nk; ++i) {
-        long double s = 0.0L;
-        for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * nk + i];
-        grad_host[i] = 0.5 * (double)s;
-    }
-    return 0;
+    // inv(L) in `work` is dead by now: reuse it as the partial-sum buffer
+    return grad_trace_host(h, kernel_id, x, n, d, theta, ntheta, KV, ld, alpha + component, ncol, work, grad_host);
+}
+
+int fvgp_hip_grad_trace(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                        const double *theta, int ntheta, const double *W, int64_t ldw,
+                        const double *b, int64_t ldb, double *partial, double *grad_host) {
+    if (!h) return -1;
+    if (!x) return -3;
+    if (n <= 0) return -4;
+    if (!theta) return -6;
+    if (!W) return -8;
+    if (ldw < n || (ldw & 1) || ((uintptr_t)W & 15)) return -9;
+    if (b && ldb < 1) return -11;
+    if (!partial) return -12;
+    if (!grad_host) return -13;
+    HIPCHK(hipSetDevice(h->device));
+    return grad_trace_host(h, kernel_id, x, n, d, theta, ntheta, W, ldw, b, ldb, partial, grad_host);
 }
 
 int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,

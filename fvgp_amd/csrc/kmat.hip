@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void grad_trace_kernel(GArgs a) {
         long gr = row0 + rr; if (gr >= a.n) gr = a.n - 1;
         sx[rr * DD + kk] = a.x[gr * d + kk];
     }
-    if (tid < 128) { long gr = row0 + tid; sb[tid] = gr < a.n ? a.b[gr * a.ldb] : 0.0; }
+    if (tid < 128) { long gr = row0 + tid; sb[tid] = (a.b && gr < a.n) ? a.b[gr * a.ldb] : 0.0; }
     const long c0 = col0 + 2 * lane, c1 = c0 + 1;
     double u0[DD], u1[DD], il[DD];
     const long g0 = c0 < a.n ? c0 : a.n - 1, g1 = c1 < a.n ? c1 : a.n - 1;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void grad_trace_kernel(GArgs a) {
         if (k < d) { u0[k] = a.x[g0 * d + k]; u1[k] = a.x[g1 * d + k]; il[k] = a.invl[k]; }
         else { u0[k] = 0.0; u1[k] = 0.0; il[k] = 0.0; }
     }
-    const double bc0 = c0 < a.n ? a.b[c0 * a.ldb] : 0.0, bc1 = c1 < a.n ? a.b[c1 * a.ldb] : 0.0;
+    const double bc0 = (a.b && c0 < a.n) ? a.b[c0 * a.ldb] : 0.0, bc1 = (a.b && c1 < a.n) ? a.b[c1 * a.ldb] : 0.0;
     __syncthreads();
 
     double gs = 0.0;          // d/dsig accumulator

@@ -123,6 +123,25 @@ class HipOps:
     def syrk_rowshard(self, M, N, K, A, B, C, scale, off, b_ranks, b_blocks, b_off):
         self.H.syrk_rowshard(M, N, K, A, B, C, scale, off, b_ranks, b_blocks, b_off)
 
+    def kmat(self, kernel_id, x1, x2, theta, out, vdiag=None, pad=_lib.PAD_ZERO):
+        self.H.kmat(kernel_id, x1, x2, theta, out, vdiag=vdiag, pad=pad)
+
+    def gemm(self, a_kmajor, b_nmajor, lower, M, N, K, alpha, A, B, beta, C):
+        self.H.gemm(a_kmajor, b_nmajor, lower, M, N, K, alpha, A, B, beta, C)
+
+    def trsm_lower(self, L, n, B, nrhs):
+        """B <- L^-1 B with a factored diagonal block this object keeps across evaluations: the handle's cached block
+        inverses are keyed on the address, so they are dropped first"""
+        self.H.invalidate_factor()
+        self.H.trsm_lower(L, n, B, nrhs)
+
+    def trsm_lower_t(self, L, n, B, nrhs):
+        self.H.invalidate_factor()
+        self.H.trsm_lower_t(L, n, B, nrhs)
+
+    def grad_trace(self, kernel_id, x, theta, W, b, partial):
+        return self.H.grad_trace(kernel_id, x, theta, W, b, partial)
+
     def sync(self):
         self.H.sync()
 
@@ -191,6 +210,11 @@ class ShardedGP:
         if self.P > 1:
             self._T = o.zeros((self.NB + self.nloc * TILE) * self.NB)   # tall panel: diagonal block + local rows
             self._recv = [o.zeros(self.P * self.nb_max * TILE * self.NB) for _ in range(2)]
+            # the factored NB x NB diagonal blocks, replicated: the panel-local part of every later solve
+            # (N x NB doubles per rank, 0.4 GB at N = 50k)
+            self._Dfac = o.zeros(self.npan, self.NB, self.NB)
+        self.theta = None
+        self.alpha = None                  # KVinvY, replicated, (np_, 128) with the first ncol columns in use
         self._into_tensor = self.P > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.collective_events = None      # set to [] to collect (kind, bytes, start, end) per collective
 
@@ -268,6 +292,7 @@ class ShardedGP:
             self._timed("all_reduce", 8.0 * w * w, self._all_reduce, D)
             low.copy_(A[L0 * TILE:, J0:Jend])
             o.panel_potrf_dev(T, w, w + kt, n_valid, info, ld)
+            self._Dfac[J, :w, :w].copy_(D)
             if mine is not None:
                 A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)).copy_(mine)
             A[lb * TILE:, J0:Jend].copy_(low[(lb - L0) * TILE:])
@@ -311,9 +336,39 @@ class ShardedGP:
             self._update(J, bnd[J + 2], self.np_)
         o.join()
 
-    def log_likelihood(self, theta):
-        """GPMarginalLikelihood.log_likelihood(theta) (gp_marginal_likelihood.py:137-179) on the sharded matrix.
-        Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated on every rank."""
+    def set_targets(self, ymean, noise_variances):
+        """Replace (y - m) (n, ncol) and the noise variances (n,) -- the O(N) host-side results of the mean and noise
+        functions at the hyperparameters about to be evaluated (gp_prior.py:226-234, gp_likelihood.py:89-110)."""
+        ymean = np.asarray(ymean, dtype=np.float64).reshape(self.n, -1)
+        assert ymean.shape[1] == self.ncol
+        zt = np.zeros((TILE, self.np_))
+        zt[:self.ncol, :self.n] = ymean.T
+        self.zt.copy_(self.ops.to_device(zt))
+        self.v_host = np.asarray(noise_variances, dtype=np.float64)
+        sel = self._diag_cols.cpu().numpy()
+        dv = np.ones(len(sel))
+        dv[sel < self.n] = self.v_host[sel[sel < self.n]]
+        self._diag_add.copy_(self.ops.to_device(dv))
+
+    def _diag_block(self, J):
+        """the factored diagonal block of panel J (lower triangle), on this rank"""
+        J0, Jend = self.bnd[J], self.bnd[J + 1]
+        if self.P == 1:
+            return self.A[J0:Jend, J0:Jend]
+        return self._Dfac[J, :Jend - J0, :Jend - J0]
+
+    def _panel_rows(self, J):
+        """(la, lb, first position, J0, Jend): local blocks [la, lb) are this rank's rows of panel J; they sit at the
+        positions first, first + P, ... of the panel's 128-row blocks"""
+        J0, Jend = self.bnd[J], self.bnd[J + 1]
+        b0, b1 = J0 // TILE, Jend // TILE
+        la = max(0, -(-(b0 - self.p) // self.P))
+        lb = max(la, max(0, -(-(b1 - self.p) // self.P)))
+        return la, lb, la * self.P + self.p - b0, J0, Jend
+
+    def evaluate(self, theta, want_alpha=False):
+        """One pass of the path on the sharded matrix: assemble, factor (the forward solve rides along), optionally
+        the backward solve.  Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated."""
         torch = self.torch
         with self.ops.stream():
             self.assemble(theta)
@@ -323,6 +378,133 @@ class ShardedGP:
         bad = np.nonzero(out[2:])[0]
         if len(bad):
             J = int(bad[0])
+            self.theta = None
             raise np.linalg.LinAlgError(f"{self.bnd[J] + int(out[2 + J])}-th leading minor of the array is not positive definite")
+        self.theta = np.array(theta, dtype=np.float64)
+        self.alpha = None
         quad, logdet = float(out[0]) / self.ncol, float(out[1])
+        if want_alpha:
+            self.solve_backward()
         return -0.5 * (quad + logdet + self.n * math.log(2.0 * math.pi)), logdet, quad
+
+    def log_likelihood(self, theta):
+        """GPMarginalLikelihood.log_likelihood(theta) (gp_marginal_likelihood.py:137-179) on the sharded matrix.
+        Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated on every rank."""
+        return self.evaluate(theta)
+
+    # -- solves with the distributed factor ---------------------------------------------------------
+    def solve_backward(self):
+        """KVinvY = L^-T z (gp_kv.py:574-593, the second half of cho_solve), replicated on every rank.
+        Column sweep over the panels from the last to the first: the rows of panel J are solved against the replicated
+        diagonal block (redundantly, no traffic), then every rank adds L[its rows of J, columns left of J]^T alpha_J to
+        its own partial sum; one all-reduce of an NB x 128 slice per panel completes the right-hand side of the next."""
+        o, A, P = self.ops, self.A, self.P
+        with o.stream():
+            Y = A[self.zrow:self.zrow + TILE, :self.np_].t().contiguous()     # z (np_, 128), replicated
+            S = o.zeros(self.np_, TILE)                                       # this rank's partial sums
+            alpha = o.zeros(self.np_, TILE)
+            for J in range(self.npan - 1, -1, -1):
+                la, lb, first, J0, Jend = self._panel_rows(J)
+                w = Jend - J0
+                G = S[J0:Jend].clone()
+                self._all_reduce(G)
+                G = Y[J0:Jend] - G
+                o.trsm_lower_t(self._diag_block(J), w, G, TILE)
+                alpha[J0:Jend].copy_(G)
+                if lb > la and J0 > 0:
+                    mine = G.view(w // TILE, TILE, TILE)[first::P][:lb - la].reshape(-1, TILE).contiguous()
+                    o.gemm(1, 1, 0, J0, TILE, (lb - la) * TILE, 1.0, A[la * TILE:lb * TILE, :J0], mine, 1.0, S[:J0])
+        self.alpha = alpha
+        return alpha
+
+    def forward_trsm(self, B, triangular=False):
+        """B <- this rank's rows of L^-1 B_global, for a right-hand side distributed by rows like the matrix itself
+        (B: nb_max*128 local rows x m columns, m a multiple of 128).  Per panel: the panel's rows are summed to every
+        rank, solved against the replicated diagonal block, and applied to the rank's later rows as one GEMM.
+        triangular: B_global is lower triangular (the identity: inv(L)), so panel J only carries its first Jend columns."""
+        o, A, P = self.ops, self.A, self.P
+        m = B.shape[1]
+        assert m % TILE == 0 and B.shape[0] >= self.nb_max * TILE
+        with o.stream():
+            G_all = o.zeros(self.NB * m)
+            for J in range(self.npan):
+                la, lb, first, J0, Jend = self._panel_rows(J)
+                w = Jend - J0
+                mJ = min(m, Jend) if triangular else m
+                G = G_all[:w * mJ].view(w, mJ)                           # contiguous: the collective needs it
+                if P > 1:
+                    G.zero_()
+                    if lb > la:
+                        G.unflatten(0, (w // TILE, TILE))[first::P][:lb - la].copy_(B[la * TILE:lb * TILE, :mJ].unflatten(0, (lb - la, TILE)))
+                    self._all_reduce(G)
+                else:
+                    G.copy_(B[J0:Jend, :mJ])
+                o.trsm_lower(self._diag_block(J), w, G, mJ)
+                if lb > la:
+                    B[la * TILE:lb * TILE, :mJ].unflatten(0, (lb - la, TILE)).copy_(G.unflatten(0, (w // TILE, TILE))[first::P][:lb - la])
+                below = (self.nb_max - lb) * TILE
+                if below > 0:
+                    o.gemm(0, 1, 0, below, mJ, w, -1.0, A[lb * TILE:self.nb_max * TILE, J0:Jend], G, 1.0,
+                           B[lb * TILE:self.nb_max * TILE, :mJ])
+        return B
+
+    def posterior(self, x_pred, want_cov=True):
+        """k^T KVinvY and kk - k^T KV^-1 k (gp_posterior.py:139-182,229-288) at the factored hyperparameters: every rank
+        assembles its own rows of k(x_data, x_pred); the mean and V^T V (V = L^-1 k) are summed over the ranks.
+        Returns host arrays (P_pred, ncol) and (P_pred, P_pred) or None, replicated."""
+        assert self.theta is not None, "evaluate() first"
+        o = self.ops
+        if self.alpha is None:
+            self.solve_backward()
+        x_pred = np.ascontiguousarray(x_pred, dtype=np.float64)
+        npred = len(x_pred)
+        pp = _lib.pad128(npred)
+        rows = self.nb_max * TILE
+        with o.stream():
+            xp = o.to_device(x_pred)
+            k = o.zeros(rows, pp)
+            if self.nv > 0:
+                o.kmat(self.kernel_id, self.x_loc, xp, self.theta, k)
+            a_loc = o.zeros(rows, TILE)
+            inside = self.gidx < self.np_
+            a_loc[:int(inside.sum())] = self.alpha[self.torch.as_tensor(self.gidx[inside], device=self.alpha.device)]
+            mean = o.zeros(pp, TILE)
+            o.gemm(1, 1, 0, pp, TILE, rows, 1.0, k, a_loc, 0.0, mean)
+            self._all_reduce(mean)
+            S = None
+            if want_cov:
+                self.forward_trsm(k)
+                S = o.zeros(pp, pp)
+                if self.p == 0:
+                    o.kmat(self.kernel_id, xp, xp, self.theta, S)
+                o.gemm(1, 1, 0, pp, pp, rows, -1.0, k, k, 1.0, S)
+                self._all_reduce(S)
+            o.sync()
+        return mean[:npred, :self.ncol].cpu().numpy(), (None if S is None else S[:npred, :npred].cpu().numpy())
+
+    def gradient(self, component=0):
+        """1/2 (tr(KV^-1 dK_i) - b^T dK_i b), b = KVinvY[:, component] (gp_marginal_likelihood.py:262-300) for the
+        kernel-owned hyperparameters.  inv(L) is built by rows with the distributed forward solve; each rank forms the
+        Gram matrix of ITS rows (the sum over ranks is KV^-1, never formed) and runs the fused trace pass on it; the
+        (H,) partial results are summed over the ranks."""
+        assert self.theta is not None, "evaluate() first"
+        o, torch = self.ops, self.torch
+        if self.alpha is None:
+            self.solve_backward()
+        rows = self.nb_max * TILE
+        with o.stream():
+            W = o.zeros(rows, self.np_)
+            inside = self.gidx < self.np_
+            li = torch.as_tensor(np.nonzero(inside)[0], device=W.device)
+            W[li, torch.as_tensor(self.gidx[inside], device=W.device)] = 1.0          # this rank's rows of the identity
+            self.forward_trsm(W, triangular=True)
+            Gp = o.zeros(self.np_, self.np_)
+            o.gemm(1, 1, 1, self.np_, self.np_, rows, 1.0, W, W, 0.0, Gp)
+            del W
+            nt = self.np_ // TILE
+            partial = o.zeros(nt * (nt + 1) // 2 * (self.d + 2))
+            b = self.alpha[:, component] if self.p == 0 else None
+            g = o.grad_trace(self.kernel_id, self.x_all, self.theta, Gp, b, partial)
+            gt = torch.as_tensor(g, device=Gp.device)
+            self._all_reduce(gt)
+            return gt.cpu().numpy()

@@ -83,7 +83,19 @@ class GP(ValidationMixin):
         self.args = {} if args is None else args
         self.compute_device = "gpu"
         self.ram_economy = ram_economy
-        self._H = default_handle()
+        # distribution switch (the reference's gp2Scale= / dask_client= constructor flags, gp.py:419-439):
+        # args["process_group"] = a torch.distributed group (or True for the default group) row-shards K+V over
+        # the group's ranks, one process per GPU (fvgp_amd/dist.py); every rank makes the same calls
+        self._sharded = self.args.get("process_group") is not None and self.args.get("process_group") is not False
+        self._sh = self._sh_work = None
+        if self._sharded:
+            if _kernels.resolve(kernel_function) is None:
+                raise NotImplementedError("the row-sharded mode assembles on the device: it takes the named kernels of fvgp_amd.kernels")
+            if self.linalg_mode != "Chol":
+                raise NotImplementedError("the row-sharded mode keeps the Cholesky factor only (linalg_mode 'Chol')")
+            self._H = None
+        else:
+            self._H = default_handle()
         self._set_data(x_data, y_data, noise_variances)
         self.x_out = None
 
@@ -134,6 +146,10 @@ class GP(ValidationMixin):
         if self.index_set_dim > 16:
             raise NotImplementedError("the assembly kernels take input dimension <= 16")
         n = self.point_number
+        if self._sharded:
+            self._np = _lib.pad128(n)
+            self._sh = self._sh_work = None          # built on first use (the kernel is resolved after this call)
+            return
         H = self._H
         self._np = _lib.pad128(n)
         self._x_dev = H.to_device(self.x_data)
@@ -179,6 +195,34 @@ class GP(ValidationMixin):
     # ------------------------------------------------------------------------------------------
     # one full pass of the hot path into (KV buffer, alpha buffer); returns (loglik, logdet, m, V)
     # ------------------------------------------------------------------------------------------
+    def _make_sharded(self):
+        from .dist import ShardedGP
+        pg = self.args.get("process_group")
+        return ShardedGP(self.x_data, self.y_data, np.ones(self.point_number), kernel=self._native.kernel_id,
+                         group=None if pg is True else pg, ops=self.args.get("shard_ops"),
+                         panel=int(self.args.get("shard_panel", 1024)), rank=self.args.get("shard_rank"),
+                         world=self.args.get("shard_world"))
+
+    def _evaluate_sharded(self, hps, state):
+        """The same pass on the row-sharded matrix: `state` True evaluates into the object that holds the GP's state
+        (KVinvY included), False into the scratch twin (gp_kv.py:574-578: an evaluation at another theta touches no state)."""
+        hps = np.asarray(hps, dtype=np.float64)
+        if self._sh is None:
+            self._sh = self._make_sharded()
+        if not state and self._sh_work is None:
+            self._sh_work = self._make_sharded()
+        sh = self._sh if state else self._sh_work
+        m = self._mean(self.x_data, hps)
+        V = self._noise(self.x_data, hps)
+        if np.ndim(V) != 1:
+            raise NotImplementedError("the row-sharded mode takes a diagonal noise model")
+        sh.set_targets(self.y_data - m[:, None], V)
+        try:
+            ll, logdet, _ = sh.evaluate(hps, want_alpha=state)
+        except np.linalg.LinAlgError as e:
+            raise NonPositiveDefiniteError(_non_pd_message(self.point_number, str(e).split("-th")[0], float(np.min(V)), 0.0)) from e
+        return ll, logdet, m, V, sh
+
     def _evaluate(self, hps, KV, alpha):
         H, n = self._H, self.point_number
         hps = np.asarray(hps, dtype=np.float64)
@@ -227,14 +271,17 @@ class GP(ValidationMixin):
         assert isinstance(hps, np.ndarray), "wrong format in hyperparameters"
         assert np.ndim(hps) == 1, "wrong format in hyperparameters"
         self._hps = np.array(hps, dtype=np.float64)
-        ll, logdet, m, V = self._evaluate(self._hps, self._L, self._alpha)
+        if self._sharded:
+            ll, logdet, m, V, _ = self._evaluate_sharded(self._hps, state=True)
+        else:
+            ll, logdet, m, V = self._evaluate(self._hps, self._L, self._alpha)
         self._loglik, self._logdet, self.m, self.V = ll, logdet, m, V
         self._K_host = None
         self._refresh_inverse()
 
     def _refresh_inverse(self):
         """CholInv mode (gp_kv.py:429-432): keep KV^-1 = POTRI(L), full symmetric, next to the factor."""
-        if self.linalg_mode != "CholInv":
+        if self.linalg_mode != "CholInv" or self._sharded:
             self._KVinv = None
             return
         H, n = self._H, self.point_number
@@ -275,7 +322,7 @@ class GP(ValidationMixin):
         else:
             nv = None
         n_old = self.point_number
-        if not (rank_n_update and self._native is not None and len(x_new) > 0):
+        if not (rank_n_update and self._native is not None and len(x_new) > 0) or self._sharded:
             self._set_data(x, y, nv)
             self.set_hyperparameters(self._hps)
             return
@@ -344,6 +391,8 @@ class GP(ValidationMixin):
         materialised on first access only."""
         if self._K_host is None:
             n = self.point_number
+            if self._sharded:
+                raise NotImplementedError("K is assembled by rows on the ranks of the process group and is not gathered")
             if self._native is not None:
                 buf = self._H.empty(n, n + (n & 1))
                 self._H.kmat(self._native.kernel_id, self._x_dev, self._x_dev, self._hps, buf)
@@ -355,12 +404,16 @@ class GP(ValidationMixin):
 
     @property
     def KVinvY(self):
+        if self._sharded:
+            return self._sh.alpha[:self.point_number, :self.y_data.shape[1]].cpu().numpy()
         self._H.sync()
         return self._alpha[:self.point_number].cpu().numpy()
 
     @property
     def Chol_factor(self):
         """tril of the device factor (what np.tril(kv.Chol_factor) is in the reference)."""
+        if self._sharded:
+            raise NotImplementedError("the factor is distributed by rows over the process group and is not gathered")
         self._H.sync()
         n = self.point_number
         return np.tril(self._L[:n, :n].cpu().numpy())
@@ -377,9 +430,12 @@ class GP(ValidationMixin):
         evaluation at the new theta that touches no state (gp_kv.py:574-578)."""
         if hyperparameters is None:
             return self._loglik
-        KV, aw = self._scratch()
         try:
-            ll, _, _, _ = self._evaluate(hyperparameters, KV, aw)
+            if self._sharded:
+                ll = self._evaluate_sharded(hyperparameters, state=False)[0]
+            else:
+                KV, aw = self._scratch()
+                ll, _, _, _ = self._evaluate(hyperparameters, KV, aw)
         except Exception as e:
             raise Exception(f"Linear algebra failed for hyperparameters {hyperparameters}: {e}") from e
         return ll
@@ -393,6 +449,8 @@ class GP(ValidationMixin):
         is non-zero (:301-308).  KV^-1 comes from POTRI on the device; dK/dtheta is re-evaluated inside
         the trace kernel, never stored."""
         H, n = self._H, self.point_number
+        if self._sharded:
+            return self._gradient_sharded(hyperparameters, component)
         if self._native is None and self._kernel_grad_callable is None:
             raise NotImplementedError("gradient with a host kernel callable needs kernel_function_grad")
         KV, aw = self._scratch()
@@ -438,6 +496,26 @@ class GP(ValidationMixin):
             g = np.where(gm == 0.0, g, 0.0) + gm
         return g
 
+    def _gradient_sharded(self, hyperparameters, component):
+        """The same gradient on the row-sharded factor (dist.ShardedGP.gradient); mean-owned hyperparameters as in the
+        single-GPU path (:281,301-308).  Noise-function hyperparameters would need diag(KV^-1), which no rank holds."""
+        if self._noise_callable is not None:
+            raise NotImplementedError("gradients of noise-function hyperparameters are not available in the row-sharded mode")
+        n = self.point_number
+        if hyperparameters is None:
+            hps, sh = self._hps, self._sh
+        else:
+            hps = np.asarray(hyperparameters, dtype=np.float64)
+            sh = self._evaluate_sharded(hps, state=False)[4]
+        g = np.asarray(sh.gradient(component), dtype=np.float64)
+        if len(g) < len(hps):
+            g = np.concatenate([g, np.zeros(len(hps) - len(g))])
+        if self._mean_callable is not None:
+            b = sh.alpha[:n, component].cpu().numpy()
+            gm = -(self._mean_grad(hps) @ b)
+            g = np.where(gm == 0.0, g, 0.0) + gm
+        return g
+
     def _central_fd(self, f, hps):
         """(H, N) central difference with step 1e-6 -- gp_likelihood.py:123-133, gp_prior.py:460-469."""
         out = np.empty((len(hps), self.point_number))
@@ -477,6 +555,9 @@ class GP(ValidationMixin):
 
     def _posterior_device(self, x_pred, hps, L, alpha, want_cov):
         """k(x_data, x_pred) assembly, mean = k^T alpha, S = kk - k^T KV^-1 k on the device."""
+        if self._sharded:
+            sh = self._sh if L is None else L
+            return sh.posterior(x_pred, want_cov=want_cov)
         H, n = self._H, self.point_number
         P = len(x_pred)
         Pp = _lib.pad128(P)
@@ -516,11 +597,17 @@ class GP(ValidationMixin):
 
     def posterior_mean(self, x_pred, hyperparameters=None, x_out=None):
         """fvgp/gp.py:1376-1431, gp_posterior.py:139-182."""
-        L, alpha, hps = self._L, self._alpha, self._hps
-        if hyperparameters is not None:
-            hps = np.asarray(hyperparameters, dtype=np.float64)
-            L, alpha = self._scratch()
-            self._evaluate(hps, L, alpha)
+        if self._sharded:
+            L, alpha, hps = None, None, self._hps
+            if hyperparameters is not None:
+                hps = np.asarray(hyperparameters, dtype=np.float64)
+                L = self._evaluate_sharded(hps, state=False)[4]            # the scratch twin, factored at hps
+        else:
+            L, alpha, hps = self._L, self._alpha, self._hps
+            if hyperparameters is not None:
+                hps = np.asarray(hyperparameters, dtype=np.float64)
+                L, alpha = self._scratch()
+                self._evaluate(hps, L, alpha)
         if x_out is None:
             x_out = self.x_out
         self._perform_input_checks(x_pred, x_out)
@@ -556,7 +643,8 @@ class GP(ValidationMixin):
             S = None
             v = self._variance_from_inverse(x_pred)
         else:
-            _, S = self._posterior_device(x_pred, self._hps, self._L, self._alpha, want_cov=True)
+            _, S = self._posterior_device(x_pred, self._hps, None if self._sharded else self._L,
+                                          None if self._sharded else self._alpha, want_cov=True)
             v = np.array(np.diag(S))
         if np.any(v < -0.0001):
             warnings.warn("Negative variances encountered. That normally means that the model is unstable. "
@@ -639,6 +727,8 @@ class GP(ValidationMixin):
         """fvgp/gp.py, gp_posterior.py:184-226: dm/dx = d(prior mean)/dx (step 1e-6) + dk/dx^T KVinvY with the
         kernel derivative taken by a forward difference of step 1e-8 (gp_prior.py:402-409).  By linearity
         dk/dx^T KVinvY is the same difference of two device evaluations of k^T KVinvY."""
+        if self._sharded:
+            raise NotImplementedError("the finite-difference posterior derivatives run on the single-GPU path only")
         L, alpha, hps = self._L, self._alpha, self._hps
         if hyperparameters is not None:
             hps = np.asarray(hyperparameters, dtype=np.float64)
@@ -679,6 +769,8 @@ class GP(ValidationMixin):
     def posterior_covariance_grad(self, x_pred, x_out=None, direction=None):
         """fvgp/gp.py, gp_posterior.py:290-331: dS/dx = dkk/dx (step 1e-6) - 2 dk/dx^T KV^-1 k (kernel step 1e-8).
         KV^-1 k is one device solve; the two cross products run on the MFMA GEMM."""
+        if self._sharded:
+            raise NotImplementedError("the finite-difference posterior derivatives run on the single-GPU path only")
         H, n = self._H, self.point_number
         if x_out is None:
             x_out = self.x_out
@@ -736,6 +828,17 @@ class GP(ValidationMixin):
             hyperparameter_bounds = self._default_bounds()
         if init_hyperparameters is None:
             init_hyperparameters = self._hps.copy()
+        if self._sharded and seed is None:
+            # every rank walks the same optimiser trajectory (each objective call is a collective): one seed for all
+            import torch
+            import torch.distributed as dist
+            pg = self.args.get("process_group")
+            t = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+            if dist.is_initialized():
+                dev = "cuda" if dist.get_backend(None if pg is True else pg) == "nccl" else "cpu"
+                t = t.to(dev)
+                dist.broadcast(t, src=0, group=None if pg is True else pg)
+            seed = int(t.item())
         hps = gp_training.train(self, np.asarray(hyperparameter_bounds, dtype=np.float64),
                                 np.asarray(init_hyperparameters, dtype=np.float64), method=method,
                                 pop_size=pop_size, tolerance=tolerance, max_iter=max_iter,
@@ -760,6 +863,8 @@ class GP(ValidationMixin):
     # pickling (fvgp/gp.py:2253-2266, gp_kv.py:718-765): host copies of the state, factor included
     # ------------------------------------------------------------------------------------------
     def __getstate__(self):
+        if self._sharded:
+            raise NotImplementedError("a row-sharded GP holds one slice of the factor per rank and is not picklable")
         self._H.sync()
         st = {k: v for k, v in self.__dict__.items()
               if k not in ("_H", "_x_dev", "_L", "_alpha", "_work", "_work2", "_alpha_work", "_KVinv")}

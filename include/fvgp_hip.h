@@ -167,6 +167,14 @@ int fvgp_hip_loglik_grad(fvgp_handle *h, int kernel_id, const double *x, int64_t
                          const double *theta_host, int ntheta, const double *alpha, int ncol, int component,
                          double *KV, int64_t ld, double *work, int64_t ldw, double *grad_host);
 
+/* the trace part of the gradient on its own: grad_host[i] = 1/2 sum_jk (W_jk - b_j b_k) dK_jk/dtheta_i over the
+ * n x n symmetric W (lower triangle read; b with stride ldb, or NULL for the pure trace 1/2 tr(W dK_i)).  The row-sharded
+ * gradient calls it on each rank's partial Gram matrix inv(L)_p^T inv(L)_p (gp_marginal_likelihood.py:262-300).
+ * partial: device scratch of T(T+1)/2 * ntheta doubles, T = ceil(n/128).  Synchronises. */
+int fvgp_hip_grad_trace(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                        const double *theta_host, int ntheta, const double *W, int64_t ldw,
+                        const double *b_or_null, int64_t ldb, double *partial, double *grad_host);
+
 /* posterior: GPposterior.posterior_mean / posterior_covariance  gp_posterior.py:139-182,229-288
  *   L: factor (padded), alpha: KVinvY (padded_dim(n), ncol)
  *   kx: scratch padded_dim(n) x ldk with ldk >= padded_dim(P); holds L^-1 k on return

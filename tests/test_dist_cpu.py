@@ -34,6 +34,65 @@ dist.destroy_process_group()
 '''
 
 
+WORKER_SOLVES = r'''
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from conftest import synth
+from dist_stub_ops import StubOps
+from fvgp_amd.dist import ShardedGP
+dist.init_process_group(backend="gloo")
+n, d, panel, kernel = {n}, {d}, {panel}, {kernel!r}
+x, y = synth(n, d)
+if {ncol} > 1:
+    y = np.stack([y, np.cos(x.sum(axis=1))], axis=1)
+gp = ShardedGP(x, y, np.full(n, 0.01), kernel=kernel, ops=StubOps(), panel=panel)
+theta = np.array({theta})
+ll, logdet, quad = gp.evaluate(theta, want_alpha=True)
+xp = np.random.default_rng(7).random(({npred}, d))
+mean, S = gp.posterior(xp)
+g = gp.gradient(component={ncol} - 1)
+out = dict(ll=ll, alpha=gp.alpha[:n, :{ncol}].numpy().tolist(), mean=mean.tolist(), S=S.tolist(), g=g.tolist())
+# every rank must hold the same replicated answers
+chk = torch.tensor([ll, float(np.sum(mean)), float(np.sum(S)), float(np.sum(g))], dtype=torch.float64)
+lo, hi = chk.clone(), chk.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+out["replicated"] = bool(torch.all(lo == hi))
+if dist.get_rank() == 0:
+    print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+WORKER_FACADE = r'''
+import os, sys, json, warnings
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from conftest import load_golden
+from dist_stub_ops import StubOps
+import fvgp_amd
+dist.init_process_group(backend="gloo")
+fx = load_golden({fixture!r})
+warnings.simplefilter("ignore")
+gp = fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], noise_variances=fx["noise_variances"],
+                 kernel_function=str(fx["kernel"]), args={{"process_group": True, "shard_ops": StubOps(), "shard_panel": {panel}}})
+out = dict(loglik=gp.log_likelihood(), logliks=[gp.log_likelihood(t) for t in fx["thetas"]], loglik_again=gp.log_likelihood(),
+           KVinvY=gp.KVinvY.tolist(), grad=gp.neg_log_likelihood_gradient(fx["theta"]).tolist(),
+           grad_cached=gp.neg_log_likelihood_gradient().tolist(),
+           pm=np.asarray(gp.posterior_mean(fx["x_pred"])["m(x)"]).tolist(),
+           pm_theta1=np.asarray(gp.posterior_mean(fx["x_pred"], hyperparameters=fx["thetas"][0])["m(x)"]).tolist(),
+           pS=gp.posterior_covariance(fx["x_pred"])["S"].tolist(),
+           pv_noise=gp.posterior_covariance(fx["x_pred"], variance_only=True, add_noise=True)["v(x)"].tolist())
+gp.set_hyperparameters(fx["thetas"][1])
+out["loglik_set"] = gp.log_likelihood()
+trained = gp.train(hyperparameter_bounds=np.array([[0.1, 10.0]] + [[0.05, 5.0]] * (len(fx["theta"]) - 1)), method="mcmc", max_iter=30)
+out["trained"] = trained.tolist()
+if dist.get_rank() == 0:
+    print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close(); return port
 
@@ -52,8 +111,8 @@ def _run(world, n, d, panel, kernel, theta, ncol=1):
     return json.loads(line[7:])
 
 
-def _run_file(world, tmp_path, **kw):
-    code = WORKER.format(root=ROOT, **kw)
+def _run_file(world, tmp_path, template=None, **kw):
+    code = (template or WORKER).format(root=ROOT, **kw)
     f = tmp_path / "worker.py"
     f.write_text(code)
     port = _free_port()
@@ -81,6 +140,52 @@ def test_sharded_loglik_equals_dense(tmp_path, world, n, panel, kernel, ncol):
     gp = orc.OracleGP(x, y, np.array(theta), np.full(n, 0.01), kernel=kernel)
     np.testing.assert_allclose(ll, gp.log_likelihood(), rtol=1e-10)
     np.testing.assert_allclose(logdet, gp.logdet_KV, rtol=1e-10)
+
+
+@pytest.mark.parametrize("world,n,panel,kernel,ncol,npred", [(2, 700, 256, "rbf_ard", 1, 40), (3, 900, 128, "matern52_ard", 1, 130),
+                                                             (4, 1000, 256, "matern32_ard", 2, 17), (3, 300, 384, "rbf_ard", 1, 5)])
+def test_sharded_solves_posterior_gradient_equal_dense(tmp_path, world, n, panel, kernel, ncol, npred):
+    """The distributed backward solve (KVinvY), the row-distributed forward solve behind the posterior covariance, and
+    the gradient through each rank's partial Gram matrix of inv(L): all against the oracle, replicated on every rank
+    (the reference's distributed == dense checks, tests/test_fvgp.py:3112-3183)."""
+    d = 3
+    theta = [1.1, 0.3, 0.35, 0.4]
+    out = _run_file(world, tmp_path, template=WORKER_SOLVES, n=n, d=d, panel=panel, kernel=kernel, theta=theta, ncol=ncol, npred=npred)
+    x, y = synth(n, d)
+    if ncol > 1:
+        y = np.stack([y, np.cos(x.sum(axis=1))], axis=1)
+    gp = orc.OracleGP(x, y, np.array(theta), np.full(n, 0.01), kernel=kernel)
+    assert out["replicated"]
+    np.testing.assert_allclose(out["ll"], gp.log_likelihood(), rtol=1e-10)
+    a = np.array(out["alpha"])
+    assert np.max(np.abs(a - gp.KVinvY)) <= 1e-8 * np.max(np.abs(gp.KVinvY))
+    xp = np.random.default_rng(7).random((npred, d))
+    pm = gp.posterior_mean(xp)["m(x)_flat"].reshape(npred, -1) - np.mean(y)
+    np.testing.assert_allclose(np.array(out["mean"]), pm, rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(np.array(out["S"]) - gp.posterior_covariance(xp)["S"])) <= 1e-10 * theta[0]
+    g_ref = gp.neg_log_likelihood_gradient(np.array(theta), component=ncol - 1)
+    np.testing.assert_allclose(np.array(out["g"]), g_ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(g_ref)))
+
+
+@pytest.mark.parametrize("world,fixture,panel", [(2, "G2_rbf_n512_d3.npz", 256), (3, "G3_matern52_n512_d3.npz", 128)])
+def test_gp_facade_routes_through_the_process_group(tmp_path, world, fixture, panel):
+    """fvgp_amd.GP(..., args={"process_group": ...}): the reference's constructor-flag switch to distributed mode
+    (gp.py:419-439).  Same public methods, compared with the reference's own golden outputs."""
+    from conftest import load_golden
+    out = _run_file(world, tmp_path, template=WORKER_FACADE, fixture=fixture, panel=panel)
+    fx = load_golden(fixture)
+    np.testing.assert_allclose(out["loglik"], fx["loglik"], rtol=1e-10)
+    np.testing.assert_allclose(out["loglik_again"], fx["loglik"], rtol=1e-10)
+    np.testing.assert_allclose(out["logliks"], fx["logliks"], rtol=1e-10)
+    assert np.max(np.abs(np.array(out["KVinvY"]) - fx["KVinvY"])) <= 1e-8 * np.max(np.abs(fx["KVinvY"]))
+    for key in ("grad", "grad_cached"):
+        np.testing.assert_allclose(out[key], fx[key], rtol=1e-8, atol=1e-9 * np.max(np.abs(fx["grad"])))
+    np.testing.assert_allclose(out["pm"], fx["pm"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(out["pm_theta1"], fx["pm_theta1"], rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(np.array(out["pS"]) - fx["pS"])) <= 1e-10 * fx["theta"][0] + 1e-12
+    assert np.max(np.abs(np.array(out["pv_noise"]) - fx["pv_noise"])) <= 1e-10 * fx["theta"][0] + 1e-12
+    np.testing.assert_allclose(out["loglik_set"], fx["logliks"][1], rtol=1e-10)
+    assert len(out["trained"]) == len(fx["theta"])
 
 
 def test_single_rank_stub_path():

@@ -32,6 +32,96 @@ dist.destroy_process_group()
 '''
 
 
+WORKER_FACADE = r'''
+import os, sys, json, warnings
+os.environ["FVGP_DEVICE"] = "0"          # every rank on the one GPU of the test box
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from conftest import load_golden
+import fvgp_amd
+torch.cuda.set_device(0)
+dist.init_process_group(backend="gloo")
+fx = load_golden({fixture!r})
+warnings.simplefilter("ignore")
+gp = fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], noise_variances=fx["noise_variances"],
+                 kernel_function=str(fx["kernel"]), args={{"process_group": True, "shard_panel": {panel}}})
+out = dict(loglik=gp.log_likelihood(), logliks=[gp.log_likelihood(t) for t in fx["thetas"]],
+           KVinvY=gp.KVinvY.tolist(), grad=gp.neg_log_likelihood_gradient(fx["theta"]).tolist(),
+           pm=np.asarray(gp.posterior_mean(fx["x_pred"])["m(x)"]).tolist(),
+           pS=gp.posterior_covariance(fx["x_pred"])["S"].tolist())
+if dist.get_rank() == 0:
+    print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def _spawn(tmp_path, code, world):
+    """ranks started directly (no torchrun launcher process): GPU holders = pytest + `world` ranks <= 5"""
+    f = tmp_path / "worker.py"
+    f.write_text(code)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world))
+        so, se = open(tmp_path / f"out{r}.txt", "w+"), open(tmp_path / f"err{r}.txt", "w+")
+        procs.append((subprocess.Popen([sys.executable, str(f)], stdout=so, stderr=se, text=True, env=env), so, se))
+    try:
+        for p, _, _ in procs:
+            p.wait(timeout=600)
+    finally:
+        for p, _, _ in procs:
+            if p.poll() is None:
+                p.kill()
+    texts = []
+    for p, so, se in procs:
+        so.seek(0); se.seek(0)
+        texts.append((so.read(), se.read()))
+        so.close(); se.close()
+        assert p.returncode == 0, texts[-1][0][-2000:] + texts[-1][1][-4000:]
+    import json
+    return json.loads([l for l in texts[0][0].splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
+@pytest.mark.parametrize("world,fixture,panel", [(2, "G2_rbf_n512_d3.npz", 256), (3, "G3_matern52_n512_d3.npz", 128)])
+def test_gp_facade_over_a_process_group_with_the_hip_ops(tmp_path, world, fixture, panel):
+    """GP(..., args={"process_group": True}) with the real HIP kernels under every rank (ranks share the one GPU of the
+    box over gloo): log-likelihood, KVinvY from the distributed backward solve, gradient through the partial Gram
+    matrices, posterior mean / covariance -- against the reference's golden outputs."""
+    from conftest import load_golden
+    out = _spawn(tmp_path, WORKER_FACADE.format(root=ROOT, fixture=fixture, panel=panel), world)
+    fx = load_golden(fixture)
+    np.testing.assert_allclose(out["loglik"], fx["loglik"], rtol=1e-10)
+    np.testing.assert_allclose(out["logliks"], fx["logliks"], rtol=1e-10)
+    assert np.max(np.abs(np.array(out["KVinvY"]) - fx["KVinvY"])) <= 1e-8 * np.max(np.abs(fx["KVinvY"]))
+    np.testing.assert_allclose(out["grad"], fx["grad"], rtol=1e-8, atol=1e-9 * np.max(np.abs(fx["grad"])))
+    np.testing.assert_allclose(out["pm"], fx["pm"], rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(np.array(out["pS"]) - fx["pS"])) <= 1e-10 * fx["theta"][0] + 1e-12
+
+
+def test_single_rank_sharded_solves_with_the_hip_ops():
+    """One rank, no process group: the panel-wise backward solve, the row-distributed forward solve and the
+    Gram-matrix gradient on the HIP kernels at a size with several panels, against the oracle."""
+    from fvgp_amd.dist import ShardedGP
+    n = 2500
+    x, y = synth(n, 3)
+    nv = np.full(n, 0.01)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    gp = ShardedGP(x, y, nv, kernel="matern52_ard", panel=512, rank=0, world=1)
+    ll, _, _ = gp.evaluate(theta, want_alpha=True)
+    ref = orc.OracleGP(x, y, theta, nv, kernel="matern52_ard")
+    np.testing.assert_allclose(ll, ref.log_likelihood(), rtol=1e-10)
+    a = gp.alpha[:n, :1].cpu().numpy()
+    assert np.max(np.abs(a - ref.KVinvY)) <= 1e-8 * np.max(np.abs(ref.KVinvY))
+    xp = np.random.default_rng(3).random((200, 3))
+    mean, S = gp.posterior(xp)
+    np.testing.assert_allclose(mean[:, 0] + np.mean(y), ref.posterior_mean(xp)["m(x)"], rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(S - ref.posterior_covariance(xp)["S"])) <= 1e-10
+    g = gp.gradient()
+    g_ref = ref.neg_log_likelihood_gradient(theta)
+    np.testing.assert_allclose(g, g_ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(g_ref)))
+
+
 def test_single_rank_hip_ops_match_fused_path():
     from fvgp_amd import _lib
     from fvgp_amd.dist import ShardedGP
@@ -56,34 +146,7 @@ def test_single_rank_hip_ops_match_fused_path():
 # partitions are covered over gloo on the CPU (tests/test_dist_cpu.py).
 @pytest.mark.parametrize("world,n,panel", [(2, 2000, 256), (3, 1700, 384), (4, 2500, 256)])
 def test_ranks_sharing_one_gpu_over_gloo(tmp_path, world, n, panel):
-    f = tmp_path / "worker.py"
-    f.write_text(WORKER.format(root=ROOT, n=n, panel=panel))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    # ranks are started directly (no torchrun launcher process): GPU holders = pytest + `world` ranks <= 5
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world))
-        so, se = open(tmp_path / f"out{r}.txt", "w+"), open(tmp_path / f"err{r}.txt", "w+")
-        procs.append((subprocess.Popen([sys.executable, str(f)], stdout=so, stderr=se, text=True, env=env), so, se))
-    try:
-        for p, _, _ in procs:
-            p.wait(timeout=600)
-    finally:
-        for p, _, _ in procs:
-            if p.poll() is None:
-                p.kill()
-    texts = []
-    for p, so, se in procs:
-        so.seek(0); se.seek(0)
-        texts.append((so.read(), se.read()))
-        so.close(); se.close()
-        assert p.returncode == 0, texts[-1][0][-2000:] + texts[-1][1][-4000:]
-
-    class res:
-        stdout = texts[0][0]
-    import json
-    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    out = _spawn(tmp_path, WORKER.format(root=ROOT, n=n, panel=panel), world)
     x, y = synth(n, 3)
     for t, (ll, logdet, quad) in enumerate(out):
         ref, _ = orc.log_likelihood_once(x, y, np.full(n, 0.01), np.array([1.0, 0.3, 0.3, 0.3]) * (1 + 0.02 * t), "rbf_ard")
