@@ -7,16 +7,21 @@ covariance assembly (+noise) -> blocked Cholesky -> two triangular solves -> log
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1: every rank evaluates its own theta sequence on its own GPU (independent replicas of the
-population of hyperparameter proposals a trainer evaluates -- SURVEY 8e "replicas-only"); no
-data-path collective, "scaling": "weak".  After the timed region the same workload is also run as ONE
-evaluation row-sharded over the ranks (block-cyclic rows, RCCL all-gather of panel factors) and reported
-under "sharded"; `--mode sharded` makes that the headline instead.  Rank 0 prints ONE JSON line.
+N = 1: the fused single-GPU evaluation (fvgp_hip_loglik).  The line also carries, measured outside the timed
+region, the other BASELINE.json configurations that fit one GPU ("configs") and the CPU restatement of the
+reference path timed on this host ("cpu_baseline").
+
+N > 1: ONE evaluation at a time, K+V row-sharded over the N ranks (block-cyclic 128-row blocks, RCCL all-gather of
+the panel factors over xGMI: fvgp_amd/dist.py) -- the partitioning the north star names; "scaling": "strong".
+The line also carries the collectives' bytes and GB/s per rank, the agreement with a single-GPU evaluation of the
+same theta, and (side record, outside the timed region) the throughput of N independent replicas.
+`--mode replicas` makes the replicas the headline instead ("scaling": "weak").  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -27,6 +32,8 @@ if ROOT not in sys.path:
 
 PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X dense fp64 matrix peak: 256 CU x 2.4 GHz x 128 flop/clk/CU
 PEAK_HBM_GBS = 8000.0
+XGMI_GBPS_PER_GPU = 7 * 153.0    # 7 links x ~153 GB/s (point-to-point)
+TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01f_pmc_traffic.json")
 
 
 def synth(n, d, seed=20240501):
@@ -36,41 +43,160 @@ def synth(n, d, seed=20240501):
     return x, y
 
 
-def cpu_baseline(n_full, d, sample_n):
-    """The oracle (numpy/scipy restatement of the reference path) timed on this host on a bounded
-    sample, scaled to N = n_full with the stage exponents (assembly, addKV, solve: N^2; potrf: N^3)."""
-    from oracle import fvgp_oracle as orc
+# ------------------------------------------------------------------------------------------------
+# CPU leg: the oracle (numpy/scipy restatement of the reference path) on this host
+# ------------------------------------------------------------------------------------------------
+def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] or [1]))
     except Exception:
-        threads = os.cpu_count() or 1
-    x, y = synth(sample_n, d)
-    nv = np.full(sample_n, 0.01)
+        return os.cpu_count() or 1
+
+
+def _host_ram_gb():
+    try:
+        import psutil
+        return psutil.virtual_memory().total / 2 ** 30
+    except Exception:
+        return 0.0
+
+
+def cpu_baseline(n_full, d, sample_n):
+    """The oracle timed on this host.  If the host has the memory (>= 100 GB: K, K+V and the factor of N = n_full)
+    and a short probe says the full size finishes in a few minutes, the FULL size is run once and reported as
+    measured; otherwise a bounded sample is run and scaled with the stage exponents (assembly, addKV, solve: N^2;
+    potrf: N^3), labelled as such."""
+    from oracle import fvgp_oracle as orc
+    threads = _blas_threads()
     theta = np.array([1.0] + [0.3] * d)
-    t0 = time.perf_counter()
-    _, st = orc.log_likelihood_once(x, y, nv, theta, "rbf_ard")
-    wall = time.perf_counter() - t0
-    r = n_full / sample_n
-    est = (st["kmat"] + st["addKV"] + st["solve_logdet"]) * r ** 2 + st["potrf"] * r ** 3
-    return {
-        "value": 1.0 / est, "unit": "evals/s", "cores": int(threads), "kind": "port",
-        "sample": (f"oracle (numpy/scipy restatement) on N={sample_n}, d={d}: kmat {st['kmat']:.2f}s addKV "
-                   f"{st['addKV']:.2f}s potrf {st['potrf']:.2f}s solve+logdet {st['solve_logdet']:.2f}s "
-                   f"(wall {wall:.1f}s, BLAS threads {threads}, host cpus {os.cpu_count()}); scaled to N={n_full} "
-                   f"with N^2 (assembly, addKV, solve) and N^3 (potrf) -> {est:.0f}s per evaluation"),
-        "measured_seconds_at_sample": wall,
-    }
+
+    def run(n):
+        x, y = synth(n, d)
+        t0 = time.perf_counter()
+        _, st = orc.log_likelihood_once(x, y, np.full(n, 0.01), theta, "rbf_ard")
+        return time.perf_counter() - t0, st
+
+    def scaled(st, r):
+        return (st["kmat"] + st["addKV"] + st["solve_logdet"]) * r ** 2 + st["potrf"] * r ** 3
+
+    ram = _host_ram_gb()
+    if sample_n <= 0:
+        probe_n = 12000
+        _, st = run(probe_n)
+        est = scaled(st, n_full / probe_n)
+        if ram >= 100.0 and est <= 300.0:
+            wall, st = run(n_full)
+            return {"value": 1.0 / wall, "unit": "evals/s", "cores": threads, "kind": "port",
+                    "sample": (f"oracle (numpy/scipy restatement) on the FULL workload N={n_full}, d={d}, one evaluation: kmat "
+                               f"{st['kmat']:.1f}s addKV {st['addKV']:.1f}s potrf {st['potrf']:.1f}s solve+logdet "
+                               f"{st['solve_logdet']:.1f}s = {wall:.1f}s wall (BLAS threads {threads}, host cpus {os.cpu_count()}, "
+                               f"RAM {ram:.0f} GB); measured, not extrapolated"),
+                    "measured_seconds": wall, "extrapolated": False}
+        sample_n = 18000
+    wall, st = run(sample_n)
+    est = scaled(st, n_full / sample_n)
+    return {"value": 1.0 / est, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": (f"oracle (numpy/scipy restatement) on N={sample_n}, d={d}: kmat {st['kmat']:.2f}s addKV "
+                       f"{st['addKV']:.2f}s potrf {st['potrf']:.2f}s solve+logdet {st['solve_logdet']:.2f}s "
+                       f"(wall {wall:.1f}s, BLAS threads {threads}, host cpus {os.cpu_count()}, RAM {ram:.0f} GB); scaled to "
+                       f"N={n_full} with N^2 (assembly, addKV, solve) and N^3 (potrf) -> {est:.0f}s per evaluation"),
+            "measured_seconds_at_sample": wall, "extrapolated": True}
 
 
-def sharded_measure(args, x, y, world, rank, local, dist, steps, warmup, check_theta=None, check_value=None):
-    """One evaluation at a time, K+V row-sharded over the ranks (fvgp_amd/dist.py).  Returns (on every rank)
-    the timing of `steps` evaluations after `warmup`, max over ranks."""
+# ------------------------------------------------------------------------------------------------
+# the other BASELINE.json configurations that fit one GPU (outside the timed region)
+# ------------------------------------------------------------------------------------------------
+def config_records():
+    """C2 (N=20k RBF + posterior at P=1000), C3 (N=50k Matern-5/2 value + gradient), C5 (fvGP 4 x 10k, d=2) through
+    the GP facade; wall time of the public call, best of two, against the fp64 MFMA bound of its flops."""
     import torch
+    import warnings
+    import fvgp_amd
+    warnings.simplefilter("ignore")
+
+    def best(f, reps=2):
+        f()
+        torch.cuda.synchronize()
+        t = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f()
+            torch.cuda.synchronize()
+            t = min(t, time.perf_counter() - t0)
+        return 1e3 * t
+
+    peak = PEAK_FP64_MFMA_TFLOPS * 1e12
+    out = {}
+    th = np.array([1.0, 0.3, 0.3, 0.3])
+    # C2
+    n = 20000
+    x, y = synth(n, 3)
+    gp = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=np.full(n, 0.01), kernel_function="rbf_ard")
+    xp = np.random.default_rng(2).random((1000, 3))
+    ll = best(lambda: gp.log_likelihood(th * 1.01))
+    out["C2"] = {"workload": "N=20000 d=3 RBF: log_likelihood(theta); posterior mean / covariance at P=1000",
+                 "loglik_ms": ll, "bound_ms": 1e3 * n ** 3 / 3 / peak, "frac": (1e3 * n ** 3 / 3 / peak) / ll,
+                 "posterior_mean_ms": best(lambda: gp.posterior_mean(xp)),
+                 "posterior_cov_ms": best(lambda: gp.posterior_covariance(xp)),
+                 "posterior_cov_bound_ms": 1e3 * (n * n * 1000.0 + 2.0 * n * 1000.0 ** 2) / peak}
+    del gp
+    torch.cuda.empty_cache()
+    # C3
+    n = 50000
+    x, y = synth(n, 3)
+    gp = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=np.full(n, 0.01), kernel_function="matern52_ard")
+    vg = best(lambda: gp.neg_log_likelihood_gradient(th * 1.01), reps=1)
+    out["C3"] = {"workload": "N=50000 d=3 Matern-5/2: log-marginal-likelihood + hyperparameter gradient (POTRF + POTRI + fused trace)",
+                 "value_grad_ms": vg, "bound_ms": 1e3 * float(n) ** 3 / peak, "frac": (1e3 * float(n) ** 3 / peak) / vg,
+                 "loglik_ms": best(lambda: gp.log_likelihood(th * 1.01), reps=1)}
+    del gp
+    torch.cuda.empty_cache()
+    # C5
+    rng = np.random.default_rng(20240501)
+    xm = rng.random((10000, 2))
+    s = xm.sum(axis=1)
+    ym = np.stack([np.sin(3 * s), np.cos(3 * s), np.linalg.norm(xm, axis=1), np.sin(3 * s) * np.cos(3 * s)], axis=1)
+    ym = ym + 0.1 * rng.standard_normal(ym.shape)
+    th5 = np.array([1.0, 0.3, 0.3, 1.0])
+    gp = fvgp_amd.fvGP(xm, ym, init_hyperparameters=th5, noise_variances=np.full(ym.shape, 0.01))
+    n = 40000
+    ll = best(lambda: gp.log_likelihood(th5 * 1.01))
+    out["C5"] = {"workload": "fvGP 4 tasks x N=10000 d=2 (index set 40000 x 3), default Matern-3/2 ARD kernel: log_likelihood(theta)",
+                 "loglik_ms": ll, "bound_ms": 1e3 * float(n) ** 3 / 3 / peak, "frac": (1e3 * float(n) ** 3 / 3 / peak) / ll}
+    del gp
+    torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def single_gpu_eval(H, _lib, x, y, thetas):
+    """fused single-GPU evaluations of the given thetas on this rank (replica leg / cross-check); returns (values, seconds)"""
+    import torch
+    n = len(x)
+    npad = _lib.pad128(n)
+    xd, vd = H.to_device(x), H.to_device(np.full(n, 0.01))
+    ymd = H.to_device((y - np.mean(y)).reshape(n, 1))
+    KV, alpha = H.empty(npad, npad), H.empty(npad, 1)
+    vals = []
+    H.loglik(0, xd, thetas[0], vd, ymd, KV, alpha)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for th in thetas:
+        ll, _, _, info = H.loglik(0, xd, th, vd, ymd, KV, alpha)
+        if info != 0:
+            raise SystemExit(f"single-GPU evaluation failed: info={info}")
+        vals.append(ll)
+    torch.cuda.synchronize()
+    return vals, time.perf_counter() - t0
+
+
+def sharded_main(args, x, y, world, rank, local, dist):
+    """N > 1 headline: one evaluation at a time row-sharded over the ranks."""
+    import torch
+    from fvgp_amd import _lib
     from fvgp_amd.dist import ShardedGP
     n, d = args.n, args.d
-    gp = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=args.outer_block or 1024,
-                   rank=rank if dist is not None else 0, world=world if dist is not None else 1)
     theta0 = np.array([1.0] + [0.3] * d)
 
     def sync_all():
@@ -79,61 +205,88 @@ def sharded_measure(args, x, y, world, rank, local, dist, steps, warmup, check_t
             dist.barrier()
         torch.cuda.synchronize()
 
-    for t in range(warmup):
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(args.sharded_timeout):
+            if rank == 0:
+                print(json.dumps({"metric": "log_marginal_likelihood_evals_per_sec", "value": 0.0, "unit": "evals/s",
+                                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                                  "scaling": "strong", "error": f"collectives did not complete within {args.sharded_timeout:.0f} s"}),
+                      flush=True)
+            os._exit(3)                # a hung collective is a failed run: the launcher must see it
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    gp = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=args.outer_block or 1024,
+                   rank=rank if dist is not None else 0, world=world if dist is not None else 1)
+    for t in range(args.warmup):
         gp.log_likelihood(theta0 * (1.0 + 0.02 * t))
+    H = gp.ops.H
+    H.set_option("profile", 1)
+    H.get_profile()
     sync_all()
     t0 = time.perf_counter()
-    for t in range(steps):
-        ll, logdet, quad = gp.log_likelihood(theta0 * (1.0 + 0.02 * (warmup + t)))
+    for t in range(args.steps):
+        ll, logdet, quad = gp.log_likelihood(theta0 * (1.0 + 0.02 * (args.warmup + t)))
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    gathered = 0.0                                                   # bytes every rank receives per evaluation
+    prof = H.get_profile()
+    H.set_option("profile", 0)
+    # one more (untimed) evaluation with events around the collectives on the chain stream
+    coll = {}
     if world > 1:
-        for J in range(gp.npan - 1):
-            k = (gp.nb_max - gp.bnd[J + 1] // 128 // world) * 128
-            gathered += 8.0 * (world - 1) * k * (gp.bnd[J + 1] - gp.bnd[J])
-    extra = {}
-    if world > 1:                                                    # one more (untimed) evaluation with events around the collectives
         gp.collective_events = []
         gp.log_likelihood(theta0)
         for kind, (calls, nbytes, ms) in gp.collective_summary().items():
-            extra[kind] = {"calls": calls, "bytes_received_per_rank": nbytes, "ms_on_chain_stream": ms,
-                           "GBps_per_rank": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None}
+            coll[kind] = {"calls_per_eval": calls, "bytes_received_per_rank_per_eval": nbytes, "ms_on_chain_stream": ms,
+                          "GBps_per_rank": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                          "frac_of_xgmi_7x153": nbytes / (ms * 1e-3) / 1e9 / XGMI_GBPS_PER_GPU if ms > 0 else None}
         gp.collective_events = None
-    if check_theta is not None:                                      # same theta as a single-GPU evaluation of this run
-        ll_c, _, _ = gp.log_likelihood(check_theta)
-        if check_value is not None:
-            extra.update({"loglik_at_check_theta": ll_c, "single_gpu_loglik_at_check_theta": check_value,
-                          "rel_diff_vs_single_gpu": abs(ll_c - check_value) / abs(check_value)})
-    return {**extra, "evals_per_s": steps / elapsed, "ms_per_eval": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
-            "tflops_per_gpu": steps * (n ** 3) / 3.0 / elapsed / 1e12 / world, "loglik_last": ll,
-            "panel": gp.NB, "all_gather_bytes_per_rank_per_eval": gathered,
-            "parallelism": f"block-cyclic 128-row blocks over {world} GPU(s), per panel: all-reduce of the diagonal "
-                           f"block, RCCL all-gather of the panel factor, one panel of look-ahead"}
-
-
-def sharded_main(args, x, y, world, rank, local, dist):
-    n, d = args.n, args.d
-    r = sharded_measure(args, x, y, world, rank, local, dist, args.steps, args.warmup)
+    theta_last = theta0 * (1.0 + 0.02 * (args.warmup + args.steps - 1))
+    del gp
+    torch.cuda.empty_cache()
+    # side record + cross-check: every rank evaluates its own theta stream on its own GPU (replicas); the first theta
+    # is the last theta of the sharded run
+    Hs = _lib.Handle(local)
+    thetas = [theta_last] + [theta0 * (1.0 + 0.02 * (100 + rank + world * t)) for t in range(max(1, min(2, args.steps)))]
+    vals, secs = single_gpu_eval(Hs, _lib, x, y, thetas)
+    Hs.close()
+    if dist is not None:
+        tt = torch.tensor([secs], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        secs = float(tt.item())
     if rank == 0:
+        syrk_tflops = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+        whole = args.steps * (n ** 3) / 3.0 / elapsed / 1e12
         out = {
-            "metric": "log_marginal_likelihood_evals_per_sec", "value": r["evals_per_s"], "unit": "evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_eval"],
+            "metric": "log_marginal_likelihood_evals_per_sec", "value": args.steps / elapsed, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"N={n} d={d} RBF(ARD) log_likelihood(theta), one evaluation row-sharded over the GPUs",
-                       "n": n, "d": d, "kernel": "rbf_ard", "parallelism": r["parallelism"]},
-            "whole_eval_tflops_equiv": r["tflops_per_gpu"] * world, "loglik_last": r["loglik_last"],
-            "all_gather_bytes_per_rank_per_eval": r["all_gather_bytes_per_rank_per_eval"],
-            "roofline": {"kernel": "gemm_f64_kernel<0, 0, 1, 0> (row-sharded trailing update)", "bound": "mfma",
-                         "achieved": r["tflops_per_gpu"], "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": r["tflops_per_gpu"] / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-                         "note": "whole-evaluation N^3/3 flops per GPU-second (collectives and solves included)"},
+            "config": {"workload": f"N={n} d={d} RBF(ARD) log_likelihood(theta): K-assembly+noise, Cholesky, forward solve, log-det; "
+                                   f"ONE evaluation row-sharded over the GPUs", "n": n, "d": d, "kernel": "rbf_ard",
+                       "parallelism": f"block-cyclic 128-row blocks over {world} GPUs; per {args.outer_block or 1024}-wide panel: all-reduce of the "
+                                      f"diagonal block, RCCL all-gather of the panel factor over xGMI, one panel of look-ahead"},
+            "cholesky_tflops": whole, "cholesky_tflops_per_gpu": whole / world,
+            "cholesky_frac_of_fp64_mfma_peak": whole / world / PEAK_FP64_MFMA_TFLOPS,
+            "loglik_last": ll,
+            "rel_diff_vs_single_gpu": abs(ll - vals[0]) / abs(vals[0]),
+            "single_gpu_loglik_at_same_theta": vals[0],
+            "collectives": coll, "xgmi_peak_GBps_per_gpu": XGMI_GBPS_PER_GPU,
+            "roofline": {"kernel": "gemm_f64_kernel<0, 0, 1, 0> (row-sharded trailing update, rank 0's launches)", "bound": "mfma",
+                         "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1.0),
+                         "algorithmic_flops_per_launch": prof["flops"] / max(prof["launches"], 1.0)},
+            "replicas": {"value": world * len(thetas) / secs, "unit": "evals/s", "scaling": "weak",
+                         "note": f"{world} independent single-GPU evaluations at a time (one theta stream per GPU), "
+                                 f"{len(thetas)} per GPU, outside the timed region"},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    done.set()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -148,16 +301,15 @@ def main():
     ap.add_argument("--d", type=int, default=3)
     ap.add_argument("--outer-block", type=int, default=0, help="K of the trailing SYRK (0 = library default)")
     ap.add_argument("--lookahead", type=int, default=-1, help="1/0: factor the next panel on a side stream (-1 = library default)")
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
-                    help="N>1: independent replicas (one theta stream per GPU, default) or ONE evaluation row-sharded "
-                         "over the GPUs (block-cyclic rows, RCCL all-gather of panel factors; strong scaling)")
+    ap.add_argument("--mode", choices=["auto", "replicas", "sharded"], default="auto",
+                    help="N>1: ONE evaluation row-sharded over the GPUs (auto / sharded: block-cyclic rows, RCCL all-gather of panel "
+                         "factors; strong scaling) or independent replicas (one theta stream per GPU; weak scaling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for tests that "
                                                       "put several ranks on one GPU)")
-    ap.add_argument("--no-sharded", action="store_true",
-                    help="N>1, replicas mode: skip the extra row-sharded measurement reported under \"sharded\"")
-    ap.add_argument("--sharded-timeout", type=float, default=240.0)
-    ap.add_argument("--cpu-sample-n", type=int, default=18000)
+    ap.add_argument("--sharded-timeout", type=float, default=600.0)
+    ap.add_argument("--cpu-sample-n", type=int, default=0, help="0 = the full workload if the host can hold it, else N=18000 scaled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C3 / C5 records measured after the timed region")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         ap.error("--steps must be >= 1 and --warmup >= 0")
@@ -184,7 +336,7 @@ def main():
 
     n, d = args.n, args.d
     x, y = synth(n, d)
-    if args.mode == "sharded":
+    if args.mode == "sharded" or (args.mode == "auto" and world > 1):
         return sharded_main(args, x, y, world, rank, local, dist)
     H = _lib.Handle(local)
     if args.outer_block:
@@ -209,9 +361,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    vals = []
     for t in range(args.warmup):
-        vals.append(H.loglik(0, xd, theta_at(t), vd, ymd, KV, alpha))
+        H.loglik(0, xd, theta_at(t), vd, ymd, KV, alpha)
     H.set_option("profile", 1)
     prof = {"launches": 0.0, "ms": 0.0, "flops": 0.0, "potrf_ms": 0.0, "kmat_ms": 0.0, "kmat_bytes": 0.0, "tail_ms": 0.0}
     sync_all()
@@ -231,13 +382,17 @@ def main():
         elapsed = float(tt.item())
     H.set_option("profile", 0)
 
+    out = None
     if rank == 0:
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
-        if os.path.exists(tfile) and n == 50000:
-            # HBM-side bytes per trailing-update launch from the committed rocprofv3 --pmc passes of this same
-            # command (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); not re-measured live
-            traffic = json.load(open(tfile)).get("bytes_per_launch")
+        traffic, traffic_source = None, None
+        for name in TRAFFIC_FILES:
+            tfile = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tfile) and n == 50000:
+                # HBM-side bytes per trailing-update launch from the committed rocprofv3 --pmc passes of this same
+                # command (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); not re-measured in this run
+                traffic = json.load(open(tfile)).get("bytes_per_launch")
+                traffic_source = f"committed rocprofv3 --pmc passes of this command (profiles/{name}); not measured live"
+                break
         evals = args.steps * world
         ms_per_step = 1e3 * elapsed / args.steps
         syrk_tflops = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
@@ -262,57 +417,27 @@ def main():
             "roofline": {
                 "kernel": "gemm_f64_kernel<0, 0, 1, 0> (trailing update of the blocked Cholesky, lower tiles)",
                 "bound": "mfma", "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                 "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1.0),
                 "algorithmic_flops_per_launch": prof["flops"] / max(prof["launches"], 1.0),
             },
         }
-        if not args.no_cpu_baseline and world == 1:       # the CPU leg is timed on rank 0 at N=1 only
+    del KV, alpha
+    H.close()
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1:
+        if not args.no_configs and n == 50000:
+            try:
+                out["configs"] = config_records()
+            except Exception as e:                                  # noqa: BLE001 -- reported in the line, the headline stands
+                out["configs"] = {"error": repr(e)[:300]}
+        if not args.no_cpu_baseline:                                # the CPU leg is timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_sample_n)
-    else:
-        out = None
-
-    # N > 1: the same workload once more as ONE evaluation row-sharded over the ranks (the partitioning the
-    # north star names), outside the timed region above, reported under "sharded".  A watchdog prints the line
-    # without it if the collectives do not come back, so the headline number can never be lost to this leg.
-    if world > 1 and not args.no_sharded:
-        import threading
-        done = threading.Event()
-
-        def watchdog():
-            if not done.wait(args.sharded_timeout):
-                if rank == 0 and out is not None:
-                    out["sharded"] = {"error": f"no result within {args.sharded_timeout:.0f} s"}
-                    print(json.dumps(out), flush=True)
-                os._exit(3)            # a hung collective is a failed run: the launcher must see it
-
-        threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            del KV, alpha
-            torch.cuda.empty_cache()
-            sh = sharded_measure(args, x, y, world, rank, local, dist, steps=3, warmup=1,
-                                 check_theta=theta0 * (1.0 + 0.02 * ((args.warmup + args.steps - 1) * world)),
-                                 check_value=ll if rank == 0 else None)
-        except Exception as e:                                  # noqa: BLE001 -- reported, not swallowed
-            sh = {"error": repr(e)[:300]}
-        if rank == 0:
-            out["sharded"] = sh
-            print(json.dumps(out), flush=True)
-            out = None
-        try:
-            dist.barrier()
-            dist.destroy_process_group()
-        except Exception:
-            pass
-        done.set()
-        H.close()
-        return
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    H.close()
 
 
 if __name__ == "__main__":

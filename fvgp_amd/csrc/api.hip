@@ -51,6 +51,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     for (auto e : h->ev) (void)hipEventDestroy(e);
     if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
     for (auto e : h->ev_stage) if (e) (void)hipEventDestroy(e);
+    for (auto e : h->rs_ev) (void)hipEventDestroy(e);
     if (h->ev_cols) (void)hipEventDestroy(h->ev_cols);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->linv) (void)hipFree(h->linv);
@@ -126,6 +127,17 @@ int fvgp_hip_invalidate_factor(fvgp_handle *h) {
 int fvgp_hip_get_profile(fvgp_handle *h, double *out) {
     if (!h) return -1;
     if (!out) return -2;
+    if (h->rs_used > 0) {
+        // the row-sharded driver enqueues its trailing updates one ABI call at a time: their events are read here
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->prof_launches = (double)h->rs_flops.size(); h->prof_ms = 0; h->prof_flops = 0;
+        for (size_t i = 0; i < h->rs_flops.size(); ++i) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h->rs_ev[2 * i], h->rs_ev[2 * i + 1]));
+            h->prof_ms += ms; h->prof_flops += h->rs_flops[i];
+        }
+        h->rs_used = 0; h->rs_flops.clear();
+    }
     out[0] = h->prof_launches; out[1] = h->prof_ms; out[2] = h->prof_flops; out[3] = h->prof_total_ms;
     out[4] = h->prof_kmat_ms; out[5] = h->prof_kmat_bytes; out[6] = h->prof_tail_ms; out[7] = 0.0;
     return 0;
@@ -857,7 +869,22 @@ int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, cons
     g.bc_ranks = b_ranks; g.bc_blocks = b_blocks; g.bc_off = b_off;
     g.M = M; g.N = N; g.K = K; g.alpha = -1.0; g.beta = 1.0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-    return launch_gemm(h, g);
+    if (!h->profile) return launch_gemm(h, g);
+    // timed with events on the launch stream; algorithmic flops = the tiles with tj <= ti * scale + off
+    while (h->rs_ev.size() < h->rs_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->rs_ev.push_back(e); }
+    double tiles = 0.0;
+    for (int64_t ti = 0; ti < M / TILE; ++ti) {
+        int64_t wdt = ti * scale + off + 1;
+        if (wdt > N / TILE) wdt = N / TILE;
+        if (wdt > 0) tiles += (double)wdt;
+    }
+    HIPCHK(hipEventRecord(h->rs_ev[h->rs_used], h->stream));
+    int rc = launch_gemm(h, g);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->rs_ev[h->rs_used + 1], h->stream));
+    h->rs_used += 2;
+    h->rs_flops.push_back(tiles * 128.0 * 128.0 * 2.0 * (double)K);
+    return 0;
 }
 
 int fvgp_hip_panel_trsm(fvgp_handle *h, const double *D, int64_t nd, int64_t ldd, double *P, int64_t rows, int64_t ldp) {

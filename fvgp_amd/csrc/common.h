@@ -47,6 +47,10 @@ struct fvgp_handle {
     double prof_launches = 0, prof_ms = 0, prof_flops = 0, prof_total_ms = 0;
     double prof_kmat_ms = 0, prof_kmat_bytes = 0, prof_tail_ms = 0;   // fused evaluation: assembly, everything after the factorisation
     hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    // row-sharded trailing updates timed since the last get_profile (option "profile")
+    std::vector<hipEvent_t> rs_ev;
+    std::vector<double> rs_flops;
+    size_t rs_used = 0;
 };
 constexpr int RED_SLOTS = 4096;
 

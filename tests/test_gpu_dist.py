@@ -169,9 +169,10 @@ def test_reserved_compute_units_give_the_same_numbers():
     ops.close()
 
 
-def test_bench_multi_rank_line_carries_the_sharded_leg(tmp_path):
-    """bench.py with 2 ranks (sharing the one GPU over gloo): ONE JSON line, replicas headline + "sharded"
-    whose log-likelihood agrees with the single-GPU evaluation of the same theta."""
+def test_bench_multi_rank_line_is_the_sharded_evaluation(tmp_path):
+    """bench.py with 2 ranks (sharing the one GPU over gloo): ONE JSON line whose headline is the row-sharded evaluation
+    ("scaling": "strong"), with the collectives' traffic, the agreement with a single-GPU evaluation of the same theta
+    and the replicas side record."""
     import json
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, FVGP_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -183,8 +184,8 @@ def test_bench_multi_rank_line_carries_the_sharded_leg(tmp_path):
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "cpu_baseline" not in out
-    sh = out["sharded"]
-    assert "error" not in sh, sh
-    assert sh["rel_diff_vs_single_gpu"] < 1e-10
-    assert sh["all_gather_bytes_per_rank_per_eval"] > 0
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and "cpu_baseline" not in out and "error" not in out
+    assert out["rel_diff_vs_single_gpu"] < 1e-10
+    assert out["collectives"]["all_gather"]["bytes_received_per_rank_per_eval"] > 0
+    assert out["roofline"]["launches"] > 0 and 0.0 < out["roofline"]["frac"] < 1.0
+    assert out["replicas"]["value"] > 0 and out["replicas"]["scaling"] == "weak"
