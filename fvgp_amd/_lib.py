@@ -26,7 +26,7 @@ SYMBOLS = [
     "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_stream_create", "fvgp_hip_stream_destroy", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_grad_trace", "fvgp_hip_posterior", "fvgp_hip_gemm",
-    "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize",
+    "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower",
     "fvgp_hip_debug_tile_map", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
 ]
 
@@ -100,6 +100,7 @@ def lib():
     L.fvgp_hip_gemm.argtypes = [c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l]
     L.fvgp_hip_mfma_selftest.argtypes = [c_p, c_p, c_p, c_p]
     L.fvgp_hip_symmetrize.argtypes = [c_p, c_p, c_l, c_l]
+    L.fvgp_hip_add_lower.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_d]
     L.fvgp_hip_mfma_peak.argtypes = [c_p, c_p, c_i, c_i]
     L.fvgp_hip_trsm_lower_t.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
     L.fvgp_hip_panel_trsm.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
@@ -303,6 +304,10 @@ class Handle:
 
     def mfma_peak(self, out, blocks, iters):
         _check(lib().fvgp_hip_mfma_peak(self._h, _ptr(out), int(blocks), int(iters)), "fvgp_hip_mfma_peak")
+
+    def add_lower(self, A, n, B, alpha=1.0):
+        """A[:n, :n] += alpha * B[:n, :n] on the lower triangle (K + V with a matrix-valued noise model)."""
+        _check(lib().fvgp_hip_add_lower(self._h, _ptr(A), int(n), A.stride(0), _ptr(B), B.stride(0), float(alpha)), "fvgp_hip_add_lower")
 
     def symmetrize(self, A, n):
         _check(lib().fvgp_hip_symmetrize(self._h, _ptr(A), int(n), A.stride(0)), "fvgp_hip_symmetrize")

@@ -963,6 +963,17 @@ int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters) {
     return launch_mfma_peak(h, out, blocks, iters);
 }
 
+int fvgp_hip_add_lower(fvgp_handle *h, double *A, int64_t n, int64_t lda, const double *B, int64_t ldb, double alpha) {
+    if (!h) return -1;
+    if (!A) return -2;
+    if (n <= 0) return -3;
+    if (lda < n) return -4;
+    if (!B) return -5;
+    if (ldb < n) return -6;
+    HIPCHK(hipSetDevice(h->device));
+    return launch_add_lower(h, A, lda, B, ldb, n, alpha);
+}
+
 int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda) {
     if (!h) return -1;
     if (!A) return -2;

@@ -268,6 +268,13 @@ __global__ void copy_lower_tiles_kernel(const double *src, long lds, double *dst
     }
 }
 
+// A[i][j] += alpha * B[i][j] on the lower triangle (j <= i < n): K + V for a matrix-valued noise model (gp_kv.py:654-657)
+__global__ void add_lower_kernel(double *A, long lda, const double *B, long ldb, long n, double alpha) {
+    const long i = blockIdx.y;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j <= i; j += (long)gridDim.x * blockDim.x)
+        A[i * lda + j] = fma(alpha, B[i * ldb + j], A[i * lda + j]);
+}
+
 // rows n..np-1 of a padded square matrix <- identity rows (lower part; the strict upper is never read)
 __global__ void pad_identity_kernel(double *A, long n, long np, long lda) {
     const long rows = np - n;
@@ -343,6 +350,13 @@ int launch_rowsumsq(fvgp_handle *h, const double *A, int64_t lda, int64_t row0, 
 int launch_rows_to_vec(fvgp_handle *h, const double *A, int64_t lda, int64_t row0, int nrows, double *vec, int C, int64_t np) {
     long tot = np * C; long blocks = (tot + 255) / 256; if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(rows_to_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, (long)lda, (long)row0, nrows, vec, C, (long)np);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_add_lower(fvgp_handle *h, double *A, int64_t lda, const double *B, int64_t ldb, int64_t n, double alpha) {
+    long bx = (n + 255) / 256; if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(add_lower_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, h->stream, A, (long)lda, B, (long)ldb, (long)n, alpha);
     HIPCHK(hipGetLastError());
     return 0;
 }

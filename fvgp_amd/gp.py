@@ -179,8 +179,7 @@ class GP(ValidationMixin):
         if self._noise_callable is not None:
             v = self._noise_callable(x, hps) if self._v_n_params == 2 else self._noise_callable(x, hps, self.args)
             v = np.asarray(v, dtype=np.float64)
-            if np.ndim(v) != 1:
-                raise NotImplementedError("matrix-valued noise functions are not on the native path; return the 1-d diagonal")
+            assert np.ndim(v) in (1, 2), "V has strange dimensionality"          # gp_kv.py:653
             return v
         if self.noise_variances is not None:
             if len(x) == len(self.noise_variances):
@@ -232,16 +231,22 @@ class GP(ValidationMixin):
         ym_dev = H.to_device(ymean)
         ncol = ymean.shape[1]
         # the fused call bounds the appended (y-m)^T rows with 1 + |y-m|^2 / min(V): it needs positive noise
-        if self._native is not None and ncol <= _lib.MAX_RHS_VEC and float(np.min(V)) > 0.0:
+        V2 = V if np.ndim(V) == 2 else None                        # matrix-valued noise: KV = K + V (gp_kv.py:654-657)
+        if V2 is not None:
+            V = np.ascontiguousarray(np.diag(V2))
+        if V2 is None and self._native is not None and ncol <= _lib.MAX_RHS_VEC and float(np.min(V)) > 0.0:
             ll, logdet, quad, info = H.loglik(self._native.kernel_id, self._x_dev, hps, H.to_device(V), ym_dev, KV, alpha)
         else:
             if self._native is not None:
-                H.kmat(self._native.kernel_id, self._x_dev, self._x_dev, hps, KV, vdiag=H.to_device(V),
+                H.kmat(self._native.kernel_id, self._x_dev, self._x_dev, hps, KV, vdiag=None if V2 is not None else H.to_device(V),
                        uplo=_lib.LOWER, pad=_lib.PAD_IDENTITY)
             else:
                 K = self._host_kernel(self.x_data, self.x_data, hps)     # slow path: N^2 over PCIe
                 KV[:n, :n] = H.to_device(K)
-                KV[:n, :n].diagonal().add_(H.to_device(V))
+                if V2 is None:
+                    KV[:n, :n].diagonal().add_(H.to_device(V))
+            if V2 is not None:
+                H.add_lower(KV, n, H.to_device(V2))                      # one N^2 upload per evaluation, added on the device
             info = H.potrf(KV, n)
             ll = logdet = float("nan")
             if info == 0:
@@ -255,7 +260,7 @@ class GP(ValidationMixin):
                 ll = -0.5 * (quad + logdet + n * np.log(2.0 * np.pi))
         if info != 0:
             raise NonPositiveDefiniteError(_non_pd_message(n, info, float(np.min(V)) if self._native is not None else None, 0.0))
-        return ll, logdet, m, V
+        return ll, logdet, m, (V if V2 is None else V2)
 
     def _scratch(self):
         if self._work is None:
@@ -481,7 +486,16 @@ class GP(ValidationMixin):
         # noise-owned hyperparameters: d/dtheta_i of diag V enters exactly like dK (gp_marginal_likelihood.py:262-267)
         if self._noise_callable is not None:
             dV = self._noise_grad(hps)
-            if np.any(dV != 0.0):
+            if np.ndim(dV) == 3:
+                # matrix-valued noise derivative (gp_marginal_likelihood.py:262-267): 1/2 (tr(KV^-1 dV_i) - b^T dV_i b),
+                # KV^-1 (lower, on the device by now) mirrored once
+                H.symmetrize(KV, n)
+                Winv, bd = KV[:n, :n], aw[:n, component]
+                for i in range(len(hps)):
+                    if np.any(dV[i] != 0.0):
+                        dVi = H.to_device(dV[i])
+                        g[i] += 0.5 * float(((Winv * dVi).sum() - bd @ (dVi @ bd)).item())
+            elif np.any(dV != 0.0):
                 H.sync()
                 b = aw[:n, component].cpu().numpy()
                 diag_inv = KV[:n, :n].diagonal().cpu().numpy() if diag_inv is None else diag_inv
@@ -518,13 +532,13 @@ class GP(ValidationMixin):
 
     def _central_fd(self, f, hps):
         """(H, N) central difference with step 1e-6 -- gp_likelihood.py:123-133, gp_prior.py:460-469."""
-        out = np.empty((len(hps), self.point_number))
+        out = []
         for i in range(len(hps)):
             tp, tm = np.array(hps, dtype=np.float64), np.array(hps, dtype=np.float64)
             tp[i] += 1e-6
             tm[i] -= 1e-6
-            out[i] = (f(self.x_data, tp) - f(self.x_data, tm)) / 2e-6
-        return out
+            out.append((f(self.x_data, tp) - f(self.x_data, tm)) / 2e-6)
+        return np.array(out)              # (H, N), or (H, N, N) for a matrix-valued noise model
 
     def _noise_grad(self, hps):
         if self._noise_grad_callable is not None:
@@ -657,9 +671,14 @@ class GP(ValidationMixin):
                 np.fill_diagonal(S, v)
         if add_noise:
             noise = self._noise(x_pred, self._hps)          # gp_posterior.py:554-569
-            v = v + noise
-            if S is not None:
-                S = S + np.diag(noise)
+            if np.ndim(noise) == 2:
+                v = v + np.diag(noise)
+                if S is not None:
+                    S = S + noise
+            else:
+                v = v + noise
+                if S is not None:
+                    S = S + np.diag(noise)
         if isinstance(x_out, np.ndarray):
             v_re = v.reshape(len(x_orig), len(x_out), order='F')
             S_re = None if S is None else \
@@ -819,10 +838,13 @@ class GP(ValidationMixin):
     # ------------------------------------------------------------------------------------------
     def train(self, hyperparameter_bounds=None, init_hyperparameters=None, method="mcmc", pop_size=20,
               tolerance=0.0001, max_iter=10000, local_optimizer="L-BFGS-B", constraints=(), info=False,
-              dask_client=None, seed=None):
-        """fvgp/gp.py:781-1141 for the methods that run without Dask/HGDL: 'mcmc' (default),
+              dask_client=None, seed=None, accept_only_if_improved=True):
+        """fvgp/gp.py:781-1141 for the methods that run without Dask/HGDL: 'mcmc' (default), 'adam',
         'global' (differential evolution), 'local'.  Every objective call is one device evaluation;
-        x, y never leave HBM.  Returns the optimised hyperparameters and sets them (gp.py:1112)."""
+        x, y never leave HBM.  Returns the optimised hyperparameters and sets them (gp.py:1112).
+        'mcmc' draws from numpy's legacy global stream like the reference (seed: a RandomState(seed) instead);
+        'local' / 'adam' results that lower the log marginal likelihood are rejected unless
+        accept_only_if_improved=False (gp.py:1086-1168)."""
         from . import gp_training
         if hyperparameter_bounds is None:
             hyperparameter_bounds = self._default_bounds()
@@ -839,11 +861,19 @@ class GP(ValidationMixin):
                 t = t.to(dev)
                 dist.broadcast(t, src=0, group=None if pg is True else pg)
             seed = int(t.item())
+        guarded = accept_only_if_improved and method in ("local", "adam")
+        incumbent = self._hps.copy() if guarded else None
+        ll_incumbent = self.log_likelihood() if guarded else None
         hps = gp_training.train(self, np.asarray(hyperparameter_bounds, dtype=np.float64),
                                 np.asarray(init_hyperparameters, dtype=np.float64), method=method,
                                 pop_size=pop_size, tolerance=tolerance, max_iter=max_iter,
                                 local_optimizer=local_optimizer, constraints=constraints, info=info, seed=seed)
         self.set_hyperparameters(np.asarray(hps, dtype=np.float64))
+        if guarded and not self.log_likelihood() >= ll_incumbent:          # exact mode: strict comparison (gp.py:1158-1160)
+            warnings.warn(f"Training with method=`{method}` returned hyperparameters with a lower log marginal likelihood "
+                          f"({self.log_likelihood()} vs. {ll_incumbent}); they were rejected and the previous hyperparameters "
+                          "kept. Pass `accept_only_if_improved=False` to accept them anyway.")
+            self.set_hyperparameters(incumbent)
         return self._hps
 
     def _default_bounds(self):

@@ -1,7 +1,7 @@
 """Training drivers -- the callers of the hot path.  Host-side optimisers around a
 device-resident objective: every objective call is one fused evaluation in HBM, theta in and a
 scalar (or (H,) gradient) out.  Mirrors the Dask-free methods of GPtraining.train
-(fvgp/gp_training.py:28-196): 'mcmc' (the default, gp_mcmc.py:96-224), 'global', 'local'.
+(fvgp/gp_training.py:28-196): 'mcmc' (the default, gp_mcmc.py:96-224), 'adam' (:576-667), 'global', 'local'.
 """
 import warnings
 
@@ -22,7 +22,11 @@ def run_mcmc(log_likelihood, bounds, x0, n_updates=10000, info=False, rng=None, 
     iterations, :181-190).  One likelihood evaluation per proposal.  Returns the reference's
     info dict; GP.train takes "median(x)" = median of the last 1 % of the trace.
     """
-    rng = np.random.default_rng() if rng is None else rng
+    # The reference draws from numpy's legacy global stream (np.random.multivariate_normal / np.random.uniform,
+    # gp_mcmc.py:214,337-341): the default here is that same module, so `np.random.seed(s)` before train() walks the
+    # reference's chain; a RandomState or a Generator may be passed instead.  The two calls below have the
+    # reference's exact argument shapes, which is what keeps a seeded chain bit-identical to its.
+    rng = np.random if rng is None else rng
     n_updates = max(int(n_updates), 2)
     dim = len(bounds)
     std = (bounds[:, 1] - bounds[:, 0]) * 0.2 / np.sqrt(12)
@@ -32,7 +36,7 @@ def run_mcmc(log_likelihood, bounds, x0, n_updates=10000, info=False, rng=None, 
     f = log_likelihood(x)
     trace_x, trace_f, jumps = [x.copy()], [], []
     for i in range(1, n_updates):
-        x_star = rng.multivariate_normal(mean=x, cov=prop_Sigma)
+        x_star = rng.multivariate_normal(mean=x, cov=prop_Sigma, size=1).reshape(len(x))
         jumped = 0.0
         if _in_bounds(x_star, bounds):
             f_star = log_likelihood(x_star)
@@ -40,7 +44,9 @@ def run_mcmc(log_likelihood, bounds, x0, n_updates=10000, info=False, rng=None, 
                 raise Exception("Likelihood evaluation = NaN in gpMCMC")
             expo = f_star - f
             ratio = np.exp(expo) if expo < 50 else 1.1
-            if ratio > rng.uniform(0.0, 1.0):
+            if np.isnan(ratio):
+                ratio = 0.0
+            if ratio > rng.uniform(0, 1, 1):
                 x, f, jumped = x_star, f_star, 1.0
         jumps.append(jumped)
         if i % K == 0:
@@ -65,6 +71,35 @@ def run_mcmc(log_likelihood, bounds, x0, n_updates=10000, info=False, rng=None, 
             "var(x)": np.var(xs[dist_index:], axis=0), "acceptance": float(np.mean(jumps)) if jumps else 0.0}
 
 
+def adam_optimize(nlml, grad_nlml, theta0, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, max_iter=1000, tol=1e-6,
+                  callback=None, early_stop=None):
+    """Adam on the negative log marginal likelihood (GPtraining.adam_optimize, gp_training.py:576-667): one value and
+    one gradient evaluation per step, bias-corrected moments, stop when the parameter update is shorter than `tol`.
+    Returns (theta, history) with history = {"theta", "nlml", "grad_norm"} as the reference keeps it."""
+    theta = np.array(theta0, dtype=np.float64)
+    m = np.zeros(theta.size)
+    v = np.zeros(theta.size)
+    history = {"theta": [], "nlml": [], "grad_norm": []}
+    for t in range(1, int(max_iter) + 1):
+        fval = nlml(theta)
+        g = np.asarray(grad_nlml(theta), dtype=np.float64)
+        m = beta1 * m + (1.0 - beta1) * g
+        v = beta2 * v + (1.0 - beta2) * (g ** 2)
+        m_hat = m / (1.0 - beta1 ** t)
+        v_hat = v / (1.0 - beta2 ** t)
+        theta_new = theta - lr * m_hat / (np.sqrt(v_hat) + eps)
+        history["theta"].append(theta.copy())
+        history["nlml"].append(fval)
+        history["grad_norm"].append(np.linalg.norm(g))
+        if callback is not None:
+            callback(theta, fval, g, t)
+        if np.linalg.norm(theta_new - theta) < tol or (early_stop is not None and early_stop()):
+            theta = theta_new
+            break
+        theta = theta_new
+    return theta, history
+
+
 def train(gp, bounds, init_hyperparameters, method="mcmc", pop_size=20, tolerance=1e-4, max_iter=10000,
           local_optimizer="L-BFGS-B", constraints=(), info=False, seed=None):
     """Dispatch on `method` (fvgp/gp_training.py:58-162).  Bounds / init checks: gp.py:1019-1036."""
@@ -75,7 +110,7 @@ def train(gp, bounds, init_hyperparameters, method="mcmc", pop_size=20, toleranc
         raise Exception("Starting hyperparameters out of bounds")
     if method == "mcmc":
         res = run_mcmc(gp.log_likelihood, bounds, init_hyperparameters, n_updates=max_iter, info=info,
-                       rng=np.random.default_rng(seed))
+                       rng=None if seed is None else np.random.RandomState(seed))
         gp.mcmc_info = res
         return res["median(x)"]
     if method == "global":
@@ -92,4 +127,14 @@ def train(gp, bounds, init_hyperparameters, method="mcmc", pop_size=20, toleranc
                            jac=gp.neg_log_likelihood_gradient, bounds=bounds, tol=tolerance,
                            constraints=constraints, options={"maxiter": max_iter})
         return res["x"]
-    raise NotImplementedError(f"train(method={method!r}): only 'mcmc', 'global' and 'local' run without Dask/HGDL")
+    if method == "adam":
+        progress = None
+        if info:
+            def progress(theta, fval, grad, iteration):                      # gp_training.py:163-177
+                if iteration % 10 == 0 or iteration == 1:
+                    print(f"fvGP adam iteration {iteration} out of {max_iter}: f(x)= {float(fval)}, |grad|= {float(np.linalg.norm(grad))}")
+        hps, history = adam_optimize(gp.neg_log_likelihood, gp.neg_log_likelihood_gradient, init_hyperparameters,
+                                     max_iter=max_iter, callback=progress)
+        gp.adam_history = history
+        return hps
+    raise NotImplementedError(f"train(method={method!r}): only 'mcmc', 'adam', 'global' and 'local' run without Dask/HGDL")

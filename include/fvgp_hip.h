@@ -203,6 +203,9 @@ int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int scale, 
 /* diagnostic: blocks x 256 threads each issue iters x 16 register-only fp64 MFMAs (2048 flop each per wave);
  * out needs blocks*256 doubles.  Gives the sustained fp64 MFMA ceiling of the device. */
 int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);
+/* A[i][j] += alpha * B[i][j] for j <= i < n: GPkv.addKV with a matrix-valued (2-d) noise model, KV = K + V
+ * (gp_kv.py:654-657); only the lower triangle, like every other symmetric buffer of this ABI */
+int fvgp_hip_add_lower(fvgp_handle *h, double *A, int64_t n, int64_t lda, const double *B, int64_t ldb, double alpha);
 /* mirror the lower triangle into the upper (for exporting K / KV^-1 to numpy) */
 int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda);
 

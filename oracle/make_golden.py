@@ -370,6 +370,27 @@ def main():
                         grid2d=fvgp.GP.make_2d_x_pred([0, 1], [2, 3], 4, 3), grid1d=fvgp.GP.make_1d_x_pred([0, 2], 5),
                         **{"score_" + k2: v2 for k2, v2 in ref_scores.items()}, **{"info_" + k2: v2 for k2, v2 in ref_info.items()})
 
+    # ---- G11: seeded training traces: the MCMC chain (numpy's legacy global stream, gp_mcmc.py:214,337-341) and the
+    #      Adam history (gp_training.py:576-667) of the reference, Matern-5/2 with its analytic gradient ---------------
+    x, y = synth(200, 2, seed=11)
+    nv = np.full(200, 0.01)
+    th = np.array([1.0, 0.4, 0.5])
+    bounds = np.array([[0.1, 5.0], [0.05, 2.0], [0.05, 2.0]])
+    gp = fvgp.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function=gp_bo._surrogate_kernel,
+                 kernel_function_grad=gp_bo._surrogate_kernel_grad)
+    np.random.seed(20240917)
+    hps_mcmc = gp.train(hyperparameter_bounds=bounds, init_hyperparameters=th, method="mcmc", max_iter=150)
+    info = gp.trainer.mcmc_info
+    gp.set_hyperparameters(th)
+    th_adam, hist = gp.trainer.adam_optimize(gp.marginal_likelihood.neg_log_likelihood, gp.marginal_likelihood.neg_log_likelihood_gradient, th, max_iter=30)
+    o = orc.OracleGP(x, y, th, nv, kernel="matern52_ard")
+    check("G11.loglik_on_chain", [o.log_likelihood(t) for t in np.asarray(info["x"])[1::25]], np.asarray(info["f(x)"])[0::25][:len(np.asarray(info["x"])[1::25])], 1e-11)
+    np.savez_compressed(os.path.join(OUT, "G11_training_traces_m52_n200_d2.npz"), kernel="matern52_ard", x=x, y=y, noise_variances=nv,
+                        theta=th, bounds=bounds, seed=20240917, mcmc_max_iter=150, mcmc_x=np.asarray(info["x"]),
+                        mcmc_f=np.asarray(info["f(x)"]), mcmc_median=np.asarray(info["median(x)"]), mcmc_result=hps_mcmc,
+                        adam_max_iter=30, adam_theta=np.asarray(hist["theta"]), adam_nlml=np.asarray(hist["nlml"]),
+                        adam_grad_norm=np.asarray(hist["grad_norm"]), adam_result=th_adam)
+
     print(f"{'check':32s} {'rel.diff':>10s} {'tol':>8s}")
     for tag, r, tol in report:
         print(f"{tag:32s} {r:10.2e} {tol:8.0e}")

@@ -162,6 +162,46 @@ def test_host_callable_kernel_slow_path_and_custom_mean_noise():
     np.testing.assert_allclose(g, fd, rtol=2e-5, atol=1e-4)
 
 
+def test_matrix_valued_noise_model():
+    """A noise function that returns a 2-d matrix: KV = K + V (gp_kv.py:654-657), gradient with the 3-d noise derivative
+    (gp_marginal_likelihood.py:262-267), add_noise with the matrix at the prediction points (gp_posterior.py:554-569)."""
+    import fvgp_amd
+    fx = load_golden("G2_rbf_n512_d3.npz")
+    x, y, th = fx["x"][:300], fx["y"][:300], fx["theta"]
+
+    def noise(xx, h):                                   # correlated noise: h[4] * (I + 0.3 exp(-|dx|^2 / 0.02))
+        d2 = ((xx[:, None, :] - xx[None, :, :]) ** 2).sum(axis=2)
+        return h[4] * (np.eye(len(xx)) + 0.3 * np.exp(-d2 / 0.02))
+
+    th5 = np.concatenate([th, [0.02]])
+    gp = fvgp_amd.GP(x, y, init_hyperparameters=th5, kernel_function="rbf_ard", noise_function=noise)
+    K = orc.rbf_ard(x, x, th5[:4])
+    KV = orc.addKV(K, noise(x, th5))
+    Lr = orc.calculate_Chol_factor(KV)
+    ym = (y - np.mean(y)).reshape(-1, 1)
+    a = orc.calculate_Chol_solve(Lr, ym)
+    ref = -0.5 * (np.sum(ym * a) + orc.calculate_Chol_logdet(Lr) + len(y) * np.log(2 * np.pi))
+    np.testing.assert_allclose(gp.log_likelihood(), ref, rtol=1e-10)
+    np.testing.assert_allclose(gp.log_likelihood(th5), ref, rtol=1e-10)
+    assert gp.V.shape == (300, 300)
+    assert np.max(np.abs(gp.KVinvY - a)) <= 1e-8 * np.max(np.abs(a))
+    # gradient: kernel part + 1/2 (tr(KV^-1 dV) - b^T dV b) for the noise level, against the dense formula
+    g = gp.neg_log_likelihood_gradient(th5)
+    KVinv = np.linalg.inv(KV)
+    b = a[:, 0]
+    dK = orc.rbf_ard_grad(x, x, th5[:4])
+    dV = noise(x, np.array([0, 0, 0, 0, 1.0]))
+    g_ref = np.array([0.5 * (np.sum(KVinv * d) - b @ d @ b) for d in list(dK) + [dV]])
+    np.testing.assert_allclose(g, g_ref, rtol=2e-6, atol=1e-6 * np.max(np.abs(g_ref)))
+    # posterior with the matrix-valued noise added at the prediction points
+    xp = fx["x_pred"]
+    k = orc.rbf_ard(x, xp, th5[:4])
+    S_ref = orc.rbf_ard(xp, xp, th5[:4]) - k.T @ KVinv @ k + noise(xp, th5)
+    pc = gp.posterior_covariance(xp, add_noise=True)
+    assert np.max(np.abs(pc["S"] - S_ref)) <= 1e-9
+    assert np.max(np.abs(pc["v(x)"] - np.diag(S_ref))) <= 1e-9
+
+
 def test_pickle_roundtrip_and_update():
     """tests/test_fvgp.py:1108-1244: an unpickled GP answers posterior queries from the pickled factor."""
     import fvgp_amd
@@ -300,6 +340,36 @@ def test_train_methods_improve_the_likelihood():
     gp.set_hyperparameters(np.array([0.5, 0.8, 0.8, 0.8]))
     gp.train(hyperparameter_bounds=bounds, method="global", max_iter=2, pop_size=4, seed=1)
     assert gp.log_likelihood() > start
+
+
+def test_train_walks_the_reference_mcmc_chain_and_adam_history():
+    """GP.train(method='mcmc' / 'adam') on the device likelihood against the reference's own seeded traces (G11): the
+    chain is the same chain (positions from the same legacy random stream, the same accept decisions), not merely a
+    better likelihood."""
+    import fvgp_amd
+    fx = load_golden("G11_training_traces_m52_n200_d2.npz")
+    gp = fvgp_amd.GP(fx["x"], fx["y"], init_hyperparameters=fx["theta"], noise_variances=fx["noise_variances"],
+                     kernel_function="matern52_ard")
+    got = gp.train(hyperparameter_bounds=fx["bounds"], init_hyperparameters=fx["theta"], method="mcmc",
+                   max_iter=int(fx["mcmc_max_iter"]), seed=int(fx["seed"]))
+    assert gp.mcmc_info["x"].shape == fx["mcmc_x"].shape
+    np.testing.assert_allclose(gp.mcmc_info["x"], fx["mcmc_x"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(gp.mcmc_info["f(x)"], fx["mcmc_f"], rtol=1e-10)
+    np.testing.assert_allclose(got, fx["mcmc_result"], rtol=1e-12)
+    np.testing.assert_allclose(gp.hyperparameters, fx["mcmc_result"], rtol=1e-12)
+    gp.set_hyperparameters(fx["theta"])
+    got = gp.train(hyperparameter_bounds=fx["bounds"], init_hyperparameters=fx["theta"], method="adam",
+                   max_iter=int(fx["adam_max_iter"]), accept_only_if_improved=False)
+    np.testing.assert_allclose(np.asarray(gp.adam_history["theta"]), fx["adam_theta"], rtol=1e-7)
+    np.testing.assert_allclose(np.asarray(gp.adam_history["nlml"]), fx["adam_nlml"], rtol=1e-9)
+    np.testing.assert_allclose(got, fx["adam_result"], rtol=1e-7)
+    # the guard: a training result that lowers the likelihood is rejected and the incumbent kept (gp.py:1086-1168)
+    gp.set_hyperparameters(fx["adam_result"])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        kept = gp.train(hyperparameter_bounds=fx["bounds"], init_hyperparameters=fx["theta"], method="adam", max_iter=1)
+    assert any("rejected" in str(i.message) for i in w)
+    np.testing.assert_array_equal(kept, fx["adam_result"])
 
 
 def test_named_kernel_is_a_reference_style_callable():

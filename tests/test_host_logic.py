@@ -112,6 +112,32 @@ def test_mcmc_driver_on_a_toy_posterior():
         gp_training.train(None, bounds, np.array([5.0, 1.0]))
 
 
+def test_training_drivers_walk_the_reference_traces():
+    """gp_training.run_mcmc / adam_optimize around the ORACLE's likelihood reproduce the reference's own seeded chain and
+    Adam history (G11: numpy's legacy global stream, gp_mcmc.py:214,337-356; gp_training.py:576-667) -- the host logic of
+    the callers, without a GPU."""
+    from conftest import load_golden
+    from oracle import fvgp_oracle as orc
+    from fvgp_amd import gp_training
+    fx = load_golden("G11_training_traces_m52_n200_d2.npz")
+    o = orc.OracleGP(fx["x"], fx["y"], fx["theta"], fx["noise_variances"], kernel="matern52_ard")
+    res = gp_training.run_mcmc(o.log_likelihood, fx["bounds"], fx["theta"], n_updates=int(fx["mcmc_max_iter"]),
+                               rng=np.random.RandomState(int(fx["seed"])))
+    assert res["x"].shape == fx["mcmc_x"].shape
+    np.testing.assert_allclose(res["x"], fx["mcmc_x"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(res["f(x)"], fx["mcmc_f"], rtol=1e-10)
+    np.testing.assert_allclose(res["median(x)"], fx["mcmc_median"], rtol=1e-12)
+    # the same through the global stream, as a user of the reference would seed it
+    np.random.seed(int(fx["seed"]))
+    res2 = gp_training.run_mcmc(o.log_likelihood, fx["bounds"], fx["theta"], n_updates=int(fx["mcmc_max_iter"]))
+    np.testing.assert_array_equal(res2["x"], res["x"])
+    th, hist = gp_training.adam_optimize(lambda t: -o.log_likelihood(t), o.neg_log_likelihood_gradient, fx["theta"],
+                                         max_iter=int(fx["adam_max_iter"]))
+    np.testing.assert_allclose(np.asarray(hist["theta"]), fx["adam_theta"], rtol=1e-7)
+    np.testing.assert_allclose(np.asarray(hist["nlml"]), fx["adam_nlml"], rtol=1e-9)
+    np.testing.assert_allclose(th, fx["adam_result"], rtol=1e-7)
+
+
 def test_named_kernel_resolution():
     from fvgp_amd import kernels
     assert kernels.resolve(None) is kernels.matern32_ard          # gp_prior.py:62-63 default
