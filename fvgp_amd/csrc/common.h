@@ -35,8 +35,7 @@ struct fvgp_handle {
     int64_t outer_block_big = 2048, big_threshold = 24576;   // wider panels while the trailing matrix is large
     int profile = 0;
     int64_t inner_block = 512;        // sub-panel width inside panels wider than this (0 = off)
-    int gemm_direct = 0;              // 1: trailing updates use the LDS-free kernel, 2: every (M,K) x (N,K) product
-    int64_t gemm_direct_max_tiles = 1 << 30;   // with gemm_direct == 1: only trailing updates of at most this many tile rows
+    int gemm_direct = 0;              // diagnostics: 1 trailing updates use the LDS-free kernel, 2 every (M,K) x (N,K) product
     int gemm_probe = 0;               // fvgp_hip_gemm launches a K-loop timing probe instead (diagnostics)
     int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel

@@ -295,8 +295,7 @@ __device__ __forceinline__ const double *uniform_ptr(const double *p) {
 // its row (one 16-byte load) and an 8-deep K stage is two MFMAs per accumulator.  No LDS image, no barrier, no
 // fragment reads: 16 loads per 64 MFMAs per wave, each operand row fetched by the two waves that share it (through L1/L2).
 // Two register stages (k0 and k0 + 8) alternate, so a stage's loads have 32 MFMAs of cover.
-// DBG (timing probes, results meaningless): 1 no waits in the loop, 2 no loads in the loop, 4 the loads never advance (cache-resident)
-template <int ROLE, int DBG = 0>
+template <int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_direct_kernel(GemmArgs g) {
     const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
     int ti, tj;
@@ -343,7 +342,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_direct_kernel(GemmArgs g) {
     // loads": hipcc merges the wait-count state of the prologue and of the loop's back edge conservatively and would
     // wait for the stage just issued as well.  The waits carry the fragments as in/out operands, which orders the
     // consuming MFMAs behind them.
-    double2_t a0[4], b0[4], a1[4], b1[4];
+    // three register stages of 8 k each rotate: the loads of a stage have 64 MFMAs of cover (the same distance the
+    // LDS kernel gives its global loads), enough for operands that come from HBM rather than the L2 / Infinity Cache
+    double2_t a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
 #define FVGP_LOAD_STAGE(AF, BF, OFF)                                                                                         \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                          \
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(AF[i]) : "v"(oa[i]), "s"(abase) : "memory");       \
@@ -358,21 +359,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_direct_kernel(GemmArgs g) {
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(AF[i][tt], BF[j][tt], acc[i][j], 0, 0, 0)
     if (nk > 0) {
+        const int ns = 2 * nk;                      // stages of 8 k
+        int st = 0;                                 // stage held by a0 / b0; a1 / b1 hold st + 1, a2 / b2 hold st + 2
         FVGP_LOAD_STAGE(a0, b0, 0)
         FVGP_LOAD_STAGE(a1, b1, 64)
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            if (!(DBG & 4)) { abase += BK; bbase += BK; }
-            if (!(DBG & 1)) FVGP_WAIT_STAGE(a0, b0, 8);
+        if (ns > 2) { FVGP_LOAD_STAGE(a2, b2, 128) }
+        // steady state: no branch inside the body; the wait in front of a stage leaves the two younger stages in flight
+        for (; st + 5 < ns; st += 3) {
+            FVGP_WAIT_STAGE(a0, b0, 16);
             FVGP_MFMA_STAGE(a0, b0);
-            if (!(DBG & 2)) { FVGP_LOAD_STAGE(a0, b0, 0) }
-            if (!(DBG & 1)) FVGP_WAIT_STAGE(a1, b1, 8);
+            FVGP_LOAD_STAGE(a0, b0, 192)
+            FVGP_WAIT_STAGE(a1, b1, 16);
             FVGP_MFMA_STAGE(a1, b1);
-            if (!(DBG & 2)) { FVGP_LOAD_STAGE(a1, b1, 64) }
+            FVGP_LOAD_STAGE(a1, b1, 256)
+            FVGP_WAIT_STAGE(a2, b2, 16);
+            FVGP_MFMA_STAGE(a2, b2);
+            FVGP_LOAD_STAGE(a2, b2, 320)
+            abase += 24; bbase += 24;
         }
-        FVGP_WAIT_STAGE(a0, b0, 8);
-        FVGP_MFMA_STAGE(a0, b0);
+        // the last two to five stages
+        FVGP_WAIT_STAGE(a0, b0, 0);
         FVGP_WAIT_STAGE(a1, b1, 0);
+        if (ns > 2) FVGP_WAIT_STAGE(a2, b2, 0);
+        FVGP_MFMA_STAGE(a0, b0);
+        if (st + 3 < ns) { FVGP_LOAD_STAGE(a0, b0, 192) }
         FVGP_MFMA_STAGE(a1, b1);
+        if (st + 4 < ns) { FVGP_LOAD_STAGE(a1, b1, 256) }
+        if (st + 2 < ns) { FVGP_MFMA_STAGE(a2, b2); }
+        if (st + 3 < ns) { FVGP_WAIT_STAGE(a0, b0, 0); FVGP_MFMA_STAGE(a0, b0); }
+        if (st + 4 < ns) { FVGP_WAIT_STAGE(a1, b1, 0); FVGP_MFMA_STAGE(a1, b1); }
     }
 #undef FVGP_LOAD_STAGE
 #undef FVGP_WAIT_STAGE
@@ -469,6 +484,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.alpha = d.alpha; g.beta = d.beta; g.K = d.K;
     g.tiles_m = (int)(d.M / 128); g.tiles_n = (int)(d.N / 128); g.lower = d.lower; g.ls = d.lower_scale; g.lo = d.lower_off;
     g.bcr = d.bc_ranks; g.bcb = d.bc_blocks; g.bco = d.bc_off; g.rev = d.rev_m;
+
     if (d.rev_m && d.lower) { fvgp_set_error("gemm: rev_m is for full (non-triangular) tile grids"); return -3; }
     if (d.bc_ranks < 1) return -7;
     if ((d.bc_ranks > 1 || d.bc_off) && d.b_nmajor) { fvgp_set_error("gemm: block-cyclic B needs the (N, K) layout"); return -7; }
@@ -476,13 +492,6 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
     if (g.ntiles == 0) return 0;
     dim3 grid((unsigned)g.ntiles), block(256);
-    if ((d.direct || h->gemm_direct >= 2) && d.probe && !d.a_kmajor && !d.b_nmajor && d.lda < (1L << 22) && d.ldb < (1L << 22)) {
-#define PR(V) case V: hipLaunchKernelGGL((gemm_f64_direct_kernel<0, V>), grid, block, 0, h->stream, g); break
-        switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); default: return -3; }
-#undef PR
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
     if (d.probe) {
         // timing probes of the K loop with parts of it removed (results are meaningless unless noted): 1 no global
         // loads / LDS writes, 2 no barrier, 4 no LDS fragment reads, 8 the full loop without s_setprio (correct
@@ -493,7 +502,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         HIPCHK(hipGetLastError());
         return 0;
     }
-    const bool direct_ = d.direct || h->gemm_direct >= 2 || (h->gemm_direct == 1 && d.role == 1 && d.M / 128 <= h->gemm_direct_max_tiles);
+    const bool direct_ = d.direct || h->gemm_direct >= 2 || (h->gemm_direct == 1 && d.role == 1);
     if (direct_ && !d.probe && !d.a_kmajor && !d.b_nmajor && d.lda < (1L << 22) && d.ldb < (1L << 22)) {   // 64 rows of a wave within a 32-bit byte offset
         if (d.role == 1) hipLaunchKernelGGL((gemm_f64_direct_kernel<1>), grid, block, 0, h->stream, g);
         else hipLaunchKernelGGL((gemm_f64_direct_kernel<0>), grid, block, 0, h->stream, g);
