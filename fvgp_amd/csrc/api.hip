@@ -109,6 +109,8 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "big_threshold")) { h->big_threshold = value; return 0; }
     if (!strcmp(key, "gemm_probe")) { h->gemm_probe = (int)value; return 0; }
     if (!strcmp(key, "gemm_direct")) { h->gemm_direct = (int)value; return 0; }
+    if (!strcmp(key, "small_tile_max")) { h->small_tile_max = value; return 0; }
+    if (!strcmp(key, "small_tile_max_update")) { h->small_tile_max_update = value; return 0; }
     if (!strcmp(key, "inner_block")) {
         if (value != 0 && (value < 128 || value % 128)) { fvgp_set_error("inner_block must be 0 or a multiple of 128"); return -3; }
         h->inner_block = value; return 0;

@@ -36,6 +36,8 @@ struct fvgp_handle {
     int profile = 0;
     int64_t inner_block = 512;        // sub-panel width inside panels wider than this (0 = off)
     int gemm_direct = 0;              // diagnostics: 1 trailing updates use the LDS-free kernel, 2 every (M,K) x (N,K) product
+    int64_t small_tile_max_update = 512;   // trailing updates of at most this many 128-tiles also run on 64-tiles
+    int64_t small_tile_max = 160;     // (M,K) x (N,K) products of at most this many 128-tiles and K <= 512 run on 64-tiles
     int gemm_probe = 0;               // fvgp_hip_gemm launches a K-loop timing probe instead (diagnostics)
     int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel

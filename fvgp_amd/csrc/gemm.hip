@@ -281,6 +281,115 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     store_tile(acc, g.C + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
 }
 
+// Small-tile variant for the latency-bound steps of the panel chain (TRSM by the inverted diagonal block, in-panel
+// update with K = 128) when a launch has too few 128 x 128 tiles to fill the chip: TM x TN tiles of a quarter the size,
+// so four times the workgroups share the same product and a K = 128 tile is 16 MFMAs per wave instead of 64.
+// (M,K) x (N,K) layout only, plain K range, plain tile grid (a launch this small has nothing to gain from the
+// XCD-aware order).  <64, 64> for products whose result does not alias an operand; <32, 128> for the in-place TRSM
+// (C is A): a workgroup then owns whole rows, so nobody overwrites operand columns another workgroup still reads.
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
+    constexpr int WN = TN / 32, WM = 4 / WN;          // 4 waves of 32 x 32 each
+    static_assert(WM * 32 == TM && WN * 32 == TN, "four waves of 32 x 32");
+    constexpr int PA = TM / 32, PB = TN / 32;          // load passes of 256 threads x 16 bytes per operand image
+    __shared__ double smem[2][(TM + TN) * LDK];
+    const int tn = (g.tiles_n * 128) / TN;             // tiles per row of the tile grid
+    const int ti = blockIdx.x / tn, tj = blockIdx.x % tn;
+    const long m0 = (long)ti * TM, n0 = (long)tj * TN;
+    if (g.lower == 1 && n0 / 128 > m0 / 128) return;   // whole 128-tiles on / below the diagonal, as the ABI says
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 15, q = lane >> 4;
+    const int nk = (int)(g.K / BK);
+
+    const double *ga[PA]; const double *gb[PB];
+    int sa[PA], sb[PB];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
+        ga[p] = g.A + (m0 + row) * g.lda + kc;
+        sa[p] = row * LDK + kc;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
+        gb[p] = g.B + (n0 + row) * g.ldb + kc;
+        sb[p] = (TM + row) * LDK + kc;
+    }
+    int fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        fa[i] = (wm * 32 + i * 16 + r) * LDK + q;
+        fb[i] = (TM + wn * 32 + i * 16 + r) * LDK + q;
+    }
+    double4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // the read-modify-write operand of the epilogue is fetched up front: its latency hides under the K loop
+    double *cbase = g.C + (m0 + wm * 32 + q) * g.ldc + n0 + wn * 32 + r;
+    double old[2][4][2];
+    if (g.beta != 0.0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) old[i][v][j] = cbase[(i * 16 + 4 * v) * g.ldc + j * 16];
+    }
+    double2_t ra[PA], rb[PB];
+    if (nk > 0) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const double2_t *>(ga[p]);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const double2_t *>(gb[p]);
+#pragma unroll
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<double2_t *>(&smem[0][sa[p]]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<double2_t *>(&smem[0][sb[p]]) = rb[p];
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) { ga[p] += BK; ra[p] = *reinterpret_cast<const double2_t *>(ga[p]); }
+#pragma unroll
+            for (int p = 0; p < PB; ++p) { gb[p] += BK; rb[p] = *reinterpret_cast<const double2_t *>(gb[p]); }
+        }
+        const double *ps = &smem[cur][0];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            double a[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a[i] = ps[fa[i] + s4 * 4]; bv[i] = ps[fb[i] + s4 * 4]; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) *reinterpret_cast<double2_t *>(&smem[cur ^ 1][sa[p]]) = ra[p];
+#pragma unroll
+            for (int p = 0; p < PB; ++p) *reinterpret_cast<double2_t *>(&smem[cur ^ 1][sb[p]]) = rb[p];
+        }
+        __syncthreads();
+    }
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                cbase[(i * 16 + 4 * v) * g.ldc + j * 16] = alpha * acc[i][j][v] + (beta != 0.0 ? beta * old[i][v][j] : 0.0);
+}
+
 // a wave-uniform pointer moved into SGPRs (readfirstlane returns int: widen each half as UNSIGNED)
 __device__ __forceinline__ const double *uniform_ptr(const double *p) {
     const uintptr_t v = (uintptr_t)p;
@@ -499,6 +608,20 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
 #define PR(V) case V: hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 0, V>), grid, block, 0, h->stream, g); break
         switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); PR(6); PR(7); PR(8); default: return -3; }
 #undef PR
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    // too few 128-tiles to fill the chip and a short K (the panel chain's steps): 64-tiles
+    const long t128 = (long)g.tiles_m * g.tiles_n;
+    // (a trailing update that small -- under about one round of 128-tiles -- is a step of the chain too: the columns of
+    // the next panel wait for it)
+    const bool few = d.role == 1 ? (t128 <= h->small_tile_max_update) : (t128 <= h->small_tile_max && d.K <= 512);
+    if (!d.probe && !d.a_kmajor && !d.b_nmajor && d.lower != 2 && d.bc_ranks == 1 && d.bc_off == 0 && !d.rev_m && few &&
+        d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && h->gemm_direct < 2) {
+        if ((const double *)d.C == d.A || (const double *)d.C == d.B)            // in place: a workgroup owns whole rows
+            hipLaunchKernelGGL((gemm_f64_small_kernel<32, 128>), dim3((unsigned)(t128 * 4)), block, 0, h->stream, g);
+        else
+            hipLaunchKernelGGL((gemm_f64_small_kernel<64, 64>), dim3((unsigned)(t128 * 4)), block, 0, h->stream, g);
         HIPCHK(hipGetLastError());
         return 0;
     }

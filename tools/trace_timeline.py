@@ -21,7 +21,7 @@ def main():
     for r in rows:
         r["s"], r["e"], r["k"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])
     rows.sort(key=lambda r: r["s"])
-    starts = [i for i, r in enumerate(rows) if r["k"] == "kmat_kernel" and int(r["Grid_Size_Y"]) > 100]
+    starts = [i for i, r in enumerate(rows) if r["k"] == "kmat_kernel" and int(r["Grid_Size_Y"]) > 8]
     which = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 1
     lo = starts[which]
     hi = starts[which + 1] if which + 1 < len(starts) else len(rows)
