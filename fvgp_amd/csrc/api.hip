@@ -109,6 +109,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "big_threshold")) { h->big_threshold = value; return 0; }
     if (!strcmp(key, "gemm_probe")) { h->gemm_probe = (int)value; return 0; }
     if (!strcmp(key, "gemm_direct")) { h->gemm_direct = (int)value; return 0; }
+    if (!strcmp(key, "leaf_stamps")) { h->leaf_stamps = reinterpret_cast<unsigned long *>((uintptr_t)value); return 0; }
     if (!strcmp(key, "small_tile_max")) { h->small_tile_max = value; return 0; }
     if (!strcmp(key, "small_tile_max_update")) { h->small_tile_max_update = value; return 0; }
     if (!strcmp(key, "inner_block")) {
@@ -234,7 +235,9 @@ static int panel_factor(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_
 
 // trailing update with the factored panel [J0, Jend): block columns [c0, c1) of the trailing matrix
 // (rows c0..np), lower tiles only:  A[c0:, c0:c1] -= L[c0:, J0:Jend] L[c0:c1, J0:Jend]^T
-static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, int64_t J0, int64_t Jend, int64_t c0, int64_t c1, int role = 1) {
+static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, int64_t J0, int64_t Jend, int64_t c0, int64_t c1, int role = 1,
+                           bool *big_kernel = nullptr) {
+    if (big_kernel) *big_kernel = false;
     if (c1 <= c0 || np <= c0) return 0;
     GemmDesc s{};
     s.a_kmajor = 0; s.b_nmajor = 0; s.lower = 1; s.M = np - c0; s.N = c1 - c0; s.K = Jend - J0;
@@ -242,6 +245,7 @@ static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, i
     s.A = A + c0 * lda + J0; s.lda = lda;
     s.B = A + c0 * lda + J0; s.ldb = lda;
     s.C = A + c0 * lda + c0; s.ldc = lda;
+    if (big_kernel) *big_kernel = !gemm_takes_small_tiles(h, s);
     return launch_gemm(h, s);
 }
 
@@ -296,11 +300,13 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     auto timed_update = [&](int64_t J0, int64_t Jend, int64_t c0, int64_t c1) -> int {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) { int r = get_event(&e0); if (r) return r; HIPCHK(hipEventRecord(e0, h->stream)); }
-        int r = trailing_update(h, A, np, lda, J0, Jend, c0, c1);
+        bool big = false;
+        int r = trailing_update(h, A, np, lda, J0, Jend, c0, c1, 1, &big);
         if (r) return r;
         if (profile) {
+            // only launches of the kernel the roofline names count (sub-round updates run the small-tile kernel): 0 flops = skipped
             r = get_event(&e1); if (r) return r; HIPCHK(hipEventRecord(e1, h->stream));
-            h->ev_flops.push_back(lower_flops(np - c0, c1 - c0, Jend - J0));
+            h->ev_flops.push_back(big ? lower_flops(np - c0, c1 - c0, Jend - J0) : 0.0);
         }
         return 0;
     };
@@ -364,11 +370,12 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     if (info_host) *info_host = info;
     h->linv_L = A; h->linv_n = n; h->linv_ld = lda;
     if (h->profile) {
-        h->prof_launches = (double)h->ev_flops.size(); h->prof_ms = 0; h->prof_flops = 0;
+        h->prof_launches = 0; h->prof_ms = 0; h->prof_flops = 0;
         for (size_t i = 0; i < h->ev_flops.size(); ++i) {
+            if (h->ev_flops[i] <= 0.0) continue;
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, h->ev[1 + 2 * i], h->ev[2 + 2 * i]));
-            h->prof_ms += ms; h->prof_flops += h->ev_flops[i];
+            h->prof_ms += ms; h->prof_flops += h->ev_flops[i]; h->prof_launches += 1.0;
         }
         float tot = 0.f;
         HIPCHK(hipEventElapsedTime(&tot, e_begin, e_end));

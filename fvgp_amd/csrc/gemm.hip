@@ -582,6 +582,15 @@ long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int ls, int lo, in
     return nwg;
 }
 
+// a trailing update that small -- under about one round of 128-tiles -- is a step of the chain too: the columns of the
+// next panel wait for it
+bool gemm_takes_small_tiles(const fvgp_handle *h, const GemmDesc &d) {
+    const long t128 = (long)(d.M / 128) * (d.N / 128);
+    const bool few = d.role == 1 ? (t128 <= h->small_tile_max_update) : (t128 <= h->small_tile_max && d.K <= 512);
+    return !d.probe && !d.a_kmajor && !d.b_nmajor && d.lower != 2 && d.bc_ranks == 1 && d.bc_off == 0 && !d.rev_m && few &&
+           d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && h->gemm_direct < 2;
+}
+
 int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     if (d.M <= 0 || d.N <= 0) return 0;
     if (d.M % 128 || d.N % 128 || d.K % BK || d.K < 0) { fvgp_set_error("gemm: M,N must be multiples of 128 and K of 16"); return -5; }
@@ -611,13 +620,8 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         HIPCHK(hipGetLastError());
         return 0;
     }
-    // too few 128-tiles to fill the chip and a short K (the panel chain's steps): 64-tiles
-    const long t128 = (long)g.tiles_m * g.tiles_n;
-    // (a trailing update that small -- under about one round of 128-tiles -- is a step of the chain too: the columns of
-    // the next panel wait for it)
-    const bool few = d.role == 1 ? (t128 <= h->small_tile_max_update) : (t128 <= h->small_tile_max && d.K <= 512);
-    if (!d.probe && !d.a_kmajor && !d.b_nmajor && d.lower != 2 && d.bc_ranks == 1 && d.bc_off == 0 && !d.rev_m && few &&
-        d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && h->gemm_direct < 2) {
+    if (gemm_takes_small_tiles(h, d)) {             // too few 128-tiles to fill the chip (the panel chain's steps): 64-tiles
+        const long t128 = (long)g.tiles_m * g.tiles_n;
         if ((const double *)d.C == d.A || (const double *)d.C == d.B)            // in place: a workgroup owns whole rows
             hipLaunchKernelGGL((gemm_f64_small_kernel<32, 128>), dim3((unsigned)(t128 * 4)), block, 0, h->stream, g);
         else

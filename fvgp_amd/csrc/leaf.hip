@@ -43,6 +43,7 @@ struct LeafArgs {
     int do_factor;
     int nvalid;                   // rows of this block that count for log-det and info (rest is padding)
     long a_stride, linv_stride;   // batched mode: block b at A + b*a_stride
+    unsigned long *stamps;        // diagnostics: s_memtime at the phase boundaries (nullptr in the product path)
 };
 
 __device__ __forceinline__ double4_t mfma(double a, double b, double4_t c) {
@@ -129,6 +130,9 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
     const int r = lane & 15, q = lane >> 4;
     double *A = g.A + (long)blockIdx.x * g.a_stride;
     double *linv = g.linv + (long)blockIdx.x * g.linv_stride;
+    int nst = 0;
+#define FVGP_STAMP() do { if (g.stamps && tid == 0) g.stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
+    FVGP_STAMP();
 
     // ---- load the lower triangle into packed tiles; strict upper of diagonal tiles <- 0 ----------
     {
@@ -155,6 +159,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
         }
     }
     __syncthreads();
+    FVGP_STAMP();
 
     if (g.do_factor) {
         if (wave == 0) {
@@ -208,6 +213,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
                     atomicCAS(g.info, 0, g.info_base + (int)blockIdx.x * 128 + 16 * (p + 1) + bad + 1);
             }
             __syncthreads();
+            FVGP_STAMP();
         }
         // ---- L back to global (lower triangle only) and the log-diagonal sum ---------------------------
         for (int e = tid; e < 128 * 128; e += 512) {
@@ -223,6 +229,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
             __syncthreads();
             if (tid == 0) g.logdet_part[blockIdx.x] = slog[0] + slog[1];
         }
+        FVGP_STAMP();
     } else {
         if (tid < 128) srd[tid] = 1.0 / sT[tix(tid >> 4, tid >> 4) + el(tid & 15, tid & 15)];
         __syncthreads();
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
         }
     }
     __syncthreads();
+    FVGP_STAMP();
 
     // ---- block column `wave` of inv(L), kept in registers in MFMA B-operand layout -----------------------
     {
@@ -295,6 +303,8 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
             }
         }
     }
+    FVGP_STAMP();
+#undef FVGP_STAMP
 }
 
 }  // namespace
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
 int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid) {
     LeafArgs g;
     g.A = A; g.lda = lda; g.linv = linv; g.logdet_part = logdet_part; g.info = h->dinfo; g.info_base = info_base;
-    g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid;
+    g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid; g.stamps = h->leaf_stamps;
     hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
@@ -312,7 +322,7 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
     if (nblk <= 0) return 0;
     LeafArgs g;
     g.A = const_cast<double *>(L); g.lda = ldl; g.linv = linv; g.logdet_part = nullptr; g.info = h->dinfo; g.info_base = 0;
-    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128;
+    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr;
     hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)nblk), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;

@@ -1,0 +1,22 @@
+"""Phase breakdown of the 128 x 128 leaf kernel from in-kernel s_memtime stamps (diagnostic option "leaf_stamps")."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from fvgp_amd import _lib
+H = _lib.Handle(0)
+rng = np.random.default_rng(0)
+B = rng.standard_normal((256, 256)); M = B @ B.T + 256 * np.eye(256)
+A = H.to_device(np.tril(M))
+stamps = torch.zeros(32, dtype=torch.int64, device="cuda")
+H.set_option("leaf_stamps", stamps.data_ptr())
+for rep in range(3):
+    A.copy_(H.to_device(np.tril(M)))
+    H.potrf(A, 256)
+torch.cuda.synchronize()
+H.set_option("leaf_stamps", 0)
+s = stamps.cpu().numpy()
+names = ["load"] + [f"step p={p}" for p in range(8)] + ["store L + logdet", "diag-tile inverses", "block-column inverse + store"]
+d = np.diff(s[:len(names) + 1])
+for nme, c in zip(names, d):
+    print(f"{nme:32s} {c:8d} cycles  {c / 100.0:7.2f} us (s_memtime 100 MHz)")
+print("total", (s[len(names)] - s[0]) / 100.0, "us")
