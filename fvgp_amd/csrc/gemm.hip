@@ -286,13 +286,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 // so four times the workgroups share the same product and a K = 128 tile is 16 MFMAs per wave instead of 64.
 // (M,K) x (N,K) layout only, plain K range, plain tile grid (a launch this small has nothing to gain from the
 // XCD-aware order).  <64, 64> for products whose result does not alias an operand; <32, 128> for the in-place TRSM
-// (C is A): a workgroup then owns whole rows, so nobody overwrites operand columns another workgroup still reads.
-template <int TM, int TN>
+// (C is A): a workgroup then owns whole rows, so nobody overwrites operand columns another workgroup still reads;
+// <128, 32> likewise for C = inv(L_kk) B in place of B (K, N): a workgroup owns whole columns.  BNM: B stored (K, N).
+template <int TM, int TN, int BNM>
 __global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
-    constexpr int WN = TN / 32, WM = 4 / WN;          // 4 waves of 32 x 32 each
-    static_assert(WM * 32 == TM && WN * 32 == TN, "four waves of 32 x 32");
-    constexpr int PA = TM / 32, PB = TN / 32;          // load passes of 256 threads x 16 bytes per operand image
-    __shared__ double smem[2][(TM + TN) * LDK];
+    constexpr int WN = TN / 32, WM = TM / 32;          // 4 waves of 32 x 32 each
+    static_assert(WM * WN == 4, "four waves of 32 x 32");
+    constexpr int PA = TM / 32;                        // load passes of 256 threads x 16 bytes: A image (TM x 16, k-minor)
+    constexpr int PB = TN / 32;                        //   B image: (TN x 16, k-minor) or, BNM, (16 x TN, n-minor)
+    constexpr int LDN = TN + 16;                       // row stride of the n-minor B image (16 mod 32 doubles: conflict-free reads)
+    constexpr int IMA = TM * LDK, IMB = BNM ? 16 * LDN : TN * LDK;
+    __shared__ double smem[2][IMA + IMB];
     const int tn = (g.tiles_n * 128) / TN;             // tiles per row of the tile grid
     const int ti = blockIdx.x / tn, tj = blockIdx.x % tn;
     const long m0 = (long)ti * TM, n0 = (long)tj * TN;
@@ -311,18 +315,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
         ga[p] = g.A + (m0 + row) * g.lda + kc;
         sa[p] = row * LDK + kc;
     }
+    constexpr int TPR = TN / 2;                         // BNM: threads per k-row of the B image
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-        const int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
-        gb[p] = g.B + (n0 + row) * g.ldb + kc;
-        sb[p] = (TM + row) * LDK + kc;
+        if (BNM) {
+            const int kr = p * (256 / TPR) + tid / TPR, nc = (tid % TPR) * 2;
+            gb[p] = g.B + (long)kr * g.ldb + n0 + nc;
+            sb[p] = IMA + kr * LDN + nc;
+        } else {
+            const int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
+            gb[p] = g.B + (n0 + row) * g.ldb + kc;
+            sb[p] = IMA + row * LDK + kc;
+        }
     }
+    const long bstep = BNM ? (long)BK * g.ldb : BK;
     int fa[2], fb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         fa[i] = (wm * 32 + i * 16 + r) * LDK + q;
-        fb[i] = (TM + wn * 32 + i * 16 + r) * LDK + q;
+        fb[i] = IMA + (BNM ? (q * LDN + wn * 32 + i * 16 + r) : ((wn * 32 + i * 16 + r) * LDK + q));
     }
+    constexpr int SB = BNM ? 4 * LDN : 4;
     double4_t acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -358,14 +371,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < PA; ++p) { ga[p] += BK; ra[p] = *reinterpret_cast<const double2_t *>(ga[p]); }
 #pragma unroll
-            for (int p = 0; p < PB; ++p) { gb[p] += BK; rb[p] = *reinterpret_cast<const double2_t *>(gb[p]); }
+            for (int p = 0; p < PB; ++p) { gb[p] += bstep; rb[p] = *reinterpret_cast<const double2_t *>(gb[p]); }
         }
         const double *ps = &smem[cur][0];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             double a[2], bv[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { a[i] = ps[fa[i] + s4 * 4]; bv[i] = ps[fb[i] + s4 * 4]; }
+            for (int i = 0; i < 2; ++i) { a[i] = ps[fa[i] + s4 * 4]; bv[i] = ps[fb[i] + s4 * SB]; }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -587,7 +600,8 @@ long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int ls, int lo, in
 bool gemm_takes_small_tiles(const fvgp_handle *h, const GemmDesc &d) {
     const long t128 = (long)(d.M / 128) * (d.N / 128);
     const bool few = d.role == 1 ? (t128 <= h->small_tile_max_update) : (t128 <= h->small_tile_max && d.K <= 512);
-    return !d.probe && !d.a_kmajor && !d.b_nmajor && d.lower != 2 && d.bc_ranks == 1 && d.bc_off == 0 && !d.rev_m && few &&
+    if (d.b_nmajor && ((const double *)d.C == d.A || ((const double *)d.C == d.B && d.M != 128))) return false;
+    return !d.probe && !d.a_kmajor && d.lower != 2 && d.bc_ranks == 1 && d.bc_off == 0 && !d.rev_m && few &&
            d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && h->gemm_direct < 2;
 }
 
@@ -622,10 +636,18 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     }
     if (gemm_takes_small_tiles(h, d)) {             // too few 128-tiles to fill the chip (the panel chain's steps): 64-tiles
         const long t128 = (long)g.tiles_m * g.tiles_n;
-        if ((const double *)d.C == d.A || (const double *)d.C == d.B)            // in place: a workgroup owns whole rows
-            hipLaunchKernelGGL((gemm_f64_small_kernel<32, 128>), dim3((unsigned)(t128 * 4)), block, 0, h->stream, g);
-        else
-            hipLaunchKernelGGL((gemm_f64_small_kernel<64, 64>), dim3((unsigned)(t128 * 4)), block, 0, h->stream, g);
+        const dim3 sg((unsigned)(t128 * 4));
+        if (!d.b_nmajor) {
+            if ((const double *)d.C == d.A || (const double *)d.C == d.B)         // in place: a workgroup owns whole rows
+                hipLaunchKernelGGL((gemm_f64_small_kernel<32, 128, 0>), sg, block, 0, h->stream, g);
+            else
+                hipLaunchKernelGGL((gemm_f64_small_kernel<64, 64, 0>), sg, block, 0, h->stream, g);
+        } else {
+            if ((const double *)d.C == d.B)                                        // in place of B (K, N), K == M: whole columns
+                hipLaunchKernelGGL((gemm_f64_small_kernel<128, 32, 1>), sg, block, 0, h->stream, g);
+            else
+                hipLaunchKernelGGL((gemm_f64_small_kernel<64, 64, 1>), sg, block, 0, h->stream, g);
+        }
         HIPCHK(hipGetLastError());
         return 0;
     }

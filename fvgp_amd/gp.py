@@ -222,7 +222,10 @@ class GP(ValidationMixin):
             raise NonPositiveDefiniteError(_non_pd_message(self.point_number, str(e).split("-th")[0], float(np.min(V)), 0.0)) from e
         return ll, logdet, m, V, sh
 
-    def _evaluate(self, hps, KV, alpha):
+    def _evaluate(self, hps, KV, alpha, need_alpha=True):
+        """need_alpha=False: the caller wants the likelihood only.  The forward solve rides along in the factorisation
+        (quad = |L^-1 (y-m)|^2), so the backward solve that would produce KVinvY is skipped when the fused call can
+        run without it (it needs ncol free padding rows)."""
         H, n = self._H, self.point_number
         hps = np.asarray(hps, dtype=np.float64)
         m = self._mean(self.x_data, hps)
@@ -235,7 +238,9 @@ class GP(ValidationMixin):
         if V2 is not None:
             V = np.ascontiguousarray(np.diag(V2))
         if V2 is None and self._native is not None and ncol <= _lib.MAX_RHS_VEC and float(np.min(V)) > 0.0:
-            ll, logdet, quad, info = H.loglik(self._native.kernel_id, self._x_dev, hps, H.to_device(V), ym_dev, KV, alpha)
+            skip = (not need_alpha) and (self._np - n) >= ncol
+            ll, logdet, quad, info = H.loglik(self._native.kernel_id, self._x_dev, hps, H.to_device(V), ym_dev, KV,
+                                              None if skip else alpha)
         else:
             if self._native is not None:
                 H.kmat(self._native.kernel_id, self._x_dev, self._x_dev, hps, KV, vdiag=None if V2 is not None else H.to_device(V),
@@ -440,7 +445,7 @@ class GP(ValidationMixin):
                 ll = self._evaluate_sharded(hyperparameters, state=False)[0]
             else:
                 KV, aw = self._scratch()
-                ll, _, _, _ = self._evaluate(hyperparameters, KV, aw)
+                ll, _, _, _ = self._evaluate(hyperparameters, KV, aw, need_alpha=False)
         except Exception as e:
             raise Exception(f"Linear algebra failed for hyperparameters {hyperparameters}: {e}") from e
         return ll
