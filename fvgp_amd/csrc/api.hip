@@ -877,7 +877,7 @@ int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, cons
     g.bc_ranks = b_ranks; g.bc_blocks = b_blocks; g.bc_off = b_off;
     g.M = M; g.N = N; g.K = K; g.alpha = -1.0; g.beta = 1.0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-    if (!h->profile) return launch_gemm(h, g);
+    if (!h->profile || gemm_takes_small_tiles(h, g)) return launch_gemm(h, g);      // only launches of the kernel the roofline names are timed
     // timed with events on the launch stream; algorithmic flops = the tiles with tj <= ti * scale + off
     while (h->rs_ev.size() < h->rs_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->rs_ev.push_back(e); }
     double tiles = 0.0;

@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
     const int ti = blockIdx.x / tn, tj = blockIdx.x % tn;
     const long m0 = (long)ti * TM, n0 = (long)tj * TN;
     if (g.lower == 1 && n0 / 128 > m0 / 128) return;   // whole 128-tiles on / below the diagonal, as the ABI says
+    if (g.lower == 2 && n0 / 128 > (m0 / 128) * g.ls + g.lo) return;        // row-sharded trailing update: this rank's block rows
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -323,8 +324,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
             gb[p] = g.B + (long)kr * g.ldb + n0 + nc;
             sb[p] = IMA + kr * LDN + nc;
         } else {
+            // B rows in all-gather (block-cyclic) order, as in the 128-tile kernel: 128-row block `idx` of the cyclic order
             const int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
-            gb[p] = g.B + (n0 + row) * g.ldb + kc;
+            const int idx = (int)(n0 / 128) + g.bco;
+            const long nb0 = ((long)(idx % g.bcr) * g.bcb + idx / g.bcr) * 128 + n0 % 128;
+            gb[p] = g.B + (nb0 + row) * g.ldb + kc;
             sb[p] = IMA + row * LDK + kc;
         }
     }
@@ -601,7 +605,8 @@ bool gemm_takes_small_tiles(const fvgp_handle *h, const GemmDesc &d) {
     const long t128 = (long)(d.M / 128) * (d.N / 128);
     const bool few = d.role == 1 ? (t128 <= h->small_tile_max_update) : (t128 <= h->small_tile_max && d.K <= 512);
     if (d.b_nmajor && ((const double *)d.C == d.A || ((const double *)d.C == d.B && d.M != 128))) return false;
-    return !d.probe && !d.a_kmajor && d.lower != 2 && d.bc_ranks == 1 && d.bc_off == 0 && !d.rev_m && few &&
+    if (d.b_nmajor && (d.lower == 2 || d.bc_ranks != 1 || d.bc_off != 0)) return false;
+    return !d.probe && !d.a_kmajor && !d.rev_m && few &&
            d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && h->gemm_direct < 2;
 }
 

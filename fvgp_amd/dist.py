@@ -41,7 +41,7 @@ class HipOps:
     operations bound to a second, high-priority stream: the panel chain (diagonal-block factorisation, panel
     solve, all-gather) runs there while the main stream applies the previous panel to the trailing matrix."""
 
-    def __init__(self, handle=None, reserve_cus=0, n_cus=256, _stream=None):
+    def __init__(self, handle=None, reserve_cus=0, n_cus=256, _stream=None, chain_everywhere=True):
         """reserve_cus > 0 (a multiple of 8): the chain gets that many compute units of its own and the main
         stream the rest, through CU-masked streams -- worth it once the panel chain, not the trailing update,
         is the critical path (many ranks, small local matrices).  Mask bit i is CU i/8 of XCD i%8 on this part
@@ -59,10 +59,14 @@ class HipOps:
             side_cus = list(range(n_cus - reserve_cus, n_cus))
             main_cus = sorted(set(range(n_cus)) - set(side_cus))
             sm = _lib.create_stream(dev, cu_mask=main_cus)
-            ss = _lib.create_stream(dev, cu_mask=side_cus)
-            self._owned = [sm, ss]
+            self._owned = [sm]
             self._stream = torch.cuda.ExternalStream(sm, device=dev)
-            side = torch.cuda.ExternalStream(ss, device=dev)
+            if chain_everywhere:       # the chain may use every CU: the reserved ones are always free for it, the rest as they free up
+                side = torch.cuda.Stream(device=dev, priority=-1)
+            else:
+                ss = _lib.create_stream(dev, cu_mask=side_cus)
+                self._owned.append(ss)
+                side = torch.cuda.ExternalStream(ss, device=dev)
             self.H = _lib.Handle(dev, stream=sm)
         else:
             self.H = handle or default_handle()

@@ -178,7 +178,7 @@ def test_bench_multi_rank_line_is_the_sharded_evaluation(tmp_path):
     env = dict(os.environ, FVGP_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--npoints", "5000", "--backend", "gloo"],
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--npoints", "12000", "--backend", "gloo"],
                          capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]

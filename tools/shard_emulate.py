@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--panel", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--reserve-cus", type=int, default=0)
+    ap.add_argument("--chain-masked", type=int, default=0)
     args = ap.parse_args()
     import torch
     from fvgp_amd.dist import ShardedGP, HipOps
@@ -40,7 +41,7 @@ def main():
     x = rng.random((args.n, 3))
     y = np.sin(3 * x.sum(axis=1)) + 0.1 * rng.standard_normal(args.n)
     gp = Emulated(x, y, np.full(args.n, 0.01), kernel="rbf_ard", panel=args.panel, rank=args.rank, world=args.world,
-                  ops=HipOps(reserve_cus=args.reserve_cus))
+                  ops=HipOps(reserve_cus=args.reserve_cus, chain_everywhere=not args.chain_masked))
     gp._into_tensor = False
     theta = np.array([1.0, 0.3, 0.3, 0.3])
 
