@@ -43,6 +43,7 @@ struct LeafArgs {
     int do_factor;
     int nvalid;                   // rows of this block that count for log-det and info (rest is padding)
     long a_stride, linv_stride;   // batched mode: block b at A + b*a_stride
+    int variant;                  // diagnostics: bit 0 = dot-product TRSM rows (the round-1 form; 3.5 us slower per leaf)
     unsigned long *stamps;        // diagnostics: s_memtime at the phase boundaries (nullptr in the product path)
 };
 
@@ -177,17 +178,29 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
                 double x[16];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) x[c] = rowp[el(a, c)];
+                // column sweep: a finished x[j] is applied to all later entries at once (independent FMAs), so the dependent
+                // path is 16 x (scale, one FMA) instead of a j-term dot product per entry
+                if (g.variant & 1) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    double s = x[j];
+                    for (int j = 0; j < 16; ++j) {
+                        double s = x[j];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) if (k < j) s = fma(-x[k], Lp[el(j, k)], s);
-                    x[j] = s * srd[16 * p + j];
+                        for (int k = 0; k < 16; ++k) if (k < j) s = fma(-x[k], Lp[el(j, k)], s);
+                        x[j] = s * srd[16 * p + j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        x[j] *= srd[16 * p + j];
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) if (c > j) x[c] = fma(-x[j], Lp[el(c, j)], x[c]);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 16; ++c) rowp[el(a, c)] = x[c];
             }
             __syncthreads();
+            FVGP_STAMP();
             // ---- trailing update C_ij -= X_i X_j^T, p < j <= i <= 7 ---------------------------------------
             const int T = 7 - p;
             const int ntile = T * (T + 1) / 2;
@@ -207,6 +220,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) if (i != j || r <= q + 4 * v) C[el(q + 4 * v, r)] = acc[v];
             }
+            FVGP_STAMP();
             if (wave == 0 && p < 7) {
                 const int bad = diag_factor(&sT[tix(p + 1, p + 1)], &srd[16 * (p + 1)], lane);
                 if (bad >= 0 && lane == 0 && 16 * (p + 1) + bad < g.nvalid)
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
 int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid) {
     LeafArgs g;
     g.A = A; g.lda = lda; g.linv = linv; g.logdet_part = logdet_part; g.info = h->dinfo; g.info_base = info_base;
-    g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid; g.stamps = h->leaf_stamps;
+    g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid; g.stamps = h->leaf_stamps; g.variant = h->leaf_variant;
     hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
@@ -322,7 +336,7 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
     if (nblk <= 0) return 0;
     LeafArgs g;
     g.A = const_cast<double *>(L); g.lda = ldl; g.linv = linv; g.logdet_part = nullptr; g.info = h->dinfo; g.info_base = 0;
-    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr;
+    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr; g.variant = 0;
     hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)nblk), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;

@@ -7,7 +7,7 @@ H = _lib.Handle(0)
 rng = np.random.default_rng(0)
 B = rng.standard_normal((256, 256)); M = B @ B.T + 256 * np.eye(256)
 A = H.to_device(np.tril(M))
-stamps = torch.zeros(32, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(64, dtype=torch.int64, device="cuda")
 H.set_option("leaf_stamps", stamps.data_ptr())
 for rep in range(3):
     A.copy_(H.to_device(np.tril(M)))
@@ -15,8 +15,13 @@ for rep in range(3):
 torch.cuda.synchronize()
 H.set_option("leaf_stamps", 0)
 s = stamps.cpu().numpy()
-names = ["load"] + [f"step p={p}" for p in range(8)] + ["store L + logdet", "diag-tile inverses", "block-column inverse + store"]
+names = ["load", "diag tile 0 + TRSM p=0"]
+for p in range(8):
+    names += [f"p={p} updates (wave 0: its tile)", f"p={p} diag tile {p + 1} + sync"]
+    if p < 7:
+        names += [f"p={p + 1} TRSM rows + sync"]
+names += ["store L + logdet", "diag-tile inverses", "block-column inverse + store"]
 d = np.diff(s[:len(names) + 1])
 for nme, c in zip(names, d):
-    print(f"{nme:32s} {c:8d} cycles  {c / 100.0:7.2f} us (s_memtime 100 MHz)")
-print("total", (s[len(names)] - s[0]) / 100.0, "us")
+    print(f"{nme:36s} {c:8d} cycles")
+print("total", s[len(names)] - s[0], "cycles =", (s[len(names)] - s[0]) / 2.4e3, "us at 2.4 GHz")
