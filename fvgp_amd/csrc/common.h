@@ -38,7 +38,6 @@ struct fvgp_handle {
     int gemm_direct = 0;              // diagnostics: 1 trailing updates use the LDS-free kernel, 2 every (M,K) x (N,K) product
     int64_t small_tile_max_update = 512;   // trailing updates of at most this many 128-tiles also run on 64-tiles
     int64_t small_tile_max = 160;     // (M,K) x (N,K) products of at most this many 128-tiles and K <= 512 run on 64-tiles
-    int leaf_variant = 0;             // diagnostics: see LeafArgs.variant
     unsigned long *leaf_stamps = nullptr;   // diagnostics (option "leaf_stamps" = device pointer): phase timestamps of the leaf kernel
     int gemm_probe = 0;               // fvgp_hip_gemm launches a K-loop timing probe instead (diagnostics)
     int lookahead = 1;

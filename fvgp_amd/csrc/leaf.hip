@@ -43,7 +43,6 @@ struct LeafArgs {
     int do_factor;
     int nvalid;                   // rows of this block that count for log-det and info (rest is padding)
     long a_stride, linv_stride;   // batched mode: block b at A + b*a_stride
-    int variant;                  // diagnostics: bit 0 = dot-product TRSM rows (the round-1 form; 3.5 us slower per leaf)
     unsigned long *stamps;        // diagnostics: s_memtime at the phase boundaries (nullptr in the product path)
 };
 
@@ -74,20 +73,29 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 
 template <int J>
 struct Col {
-    // column J of the left-looking factorisation; lane `row` holds row `row` of the tile in a[]
+    // column J of the factorisation, lane `row` holds row `row` of the tile in a[]; right-looking: a[c], c > J, already carries A[row][c] - sum_{k<J} L[row][k] L[c][k]; once column J is final it
+    // is applied to the later columns at once (independent FMAs)
     static __device__ __forceinline__ void step(double (&a)[16], double (&rd)[16], int row, int &bad) {
-        double s = a[J];
-#pragma unroll
-        for (int k = 0; k < J; ++k) s = fma(-a[k], bcast<J>(a[k]), s);
-        const double dj = bcast<J>(s);
+        const double dj = bcast<J>(a[J]);
         if (!(dj > 0.0) && bad < 0) bad = J;
         const double y = rsqrt_nr(dj);
-        double piv = dj * y;                                   // sqrt(dj), one correction step
+        double piv = dj * y;
         piv = fma(fma(-piv, piv, dj), 0.5 * y, piv);
         rd[J] = y;
-        a[J] = (row == J) ? piv : (row > J ? s * y : 0.0);
+        const double lj = (row == J) ? piv : (row > J ? a[J] * y : 0.0);
+        a[J] = lj;
+        Later<J + 1>::apply(a, lj);
         if constexpr (J < 15) Col<J + 1>::step(a, rd, row, bad);
     }
+    template <int C>
+    struct Later {
+        static __device__ __forceinline__ void apply(double (&a)[16], double lj) {
+            if constexpr (C < 16) {
+                a[C] = fma(-lj, bcast<C>(lj), a[C]);
+                Later<C + 1>::apply(a, lj);
+            }
+        }
+    };
 };
 
 template <int I>
@@ -180,21 +188,11 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
                 for (int c = 0; c < 16; ++c) x[c] = rowp[el(a, c)];
                 // column sweep: a finished x[j] is applied to all later entries at once (independent FMAs), so the dependent
                 // path is 16 x (scale, one FMA) instead of a j-term dot product per entry
-                if (g.variant & 1) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        double s = x[j];
+                for (int j = 0; j < 16; ++j) {
+                    x[j] *= srd[16 * p + j];
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) if (k < j) s = fma(-x[k], Lp[el(j, k)], s);
-                        x[j] = s * srd[16 * p + j];
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        x[j] *= srd[16 * p + j];
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) if (c > j) x[c] = fma(-x[j], Lp[el(c, j)], x[c]);
-                    }
+                    for (int c = 0; c < 16; ++c) if (c > j) x[c] = fma(-x[j], Lp[el(c, j)], x[c]);
                 }
 #pragma unroll
                 for (int c = 0; c < 16; ++c) rowp[el(a, c)] = x[c];
@@ -326,7 +324,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
 int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid) {
     LeafArgs g;
     g.A = A; g.lda = lda; g.linv = linv; g.logdet_part = logdet_part; g.info = h->dinfo; g.info_base = info_base;
-    g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid; g.stamps = h->leaf_stamps; g.variant = h->leaf_variant;
+    g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid; g.stamps = h->leaf_stamps;
     hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
@@ -336,7 +334,7 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
     if (nblk <= 0) return 0;
     LeafArgs g;
     g.A = const_cast<double *>(L); g.lda = ldl; g.linv = linv; g.logdet_part = nullptr; g.info = h->dinfo; g.info_base = 0;
-    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr; g.variant = 0;
+    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr;
     hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)nblk), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
