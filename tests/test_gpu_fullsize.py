@@ -70,6 +70,30 @@ def test_config2_n20000_rbf_posterior():
     np.testing.assert_allclose(pm[:16], (kx.T @ alpha).cpu().numpy() + np.mean(y), rtol=1e-9, atol=1e-11)
 
 
+def test_config2_n20000_against_the_oracle():
+    """C2 at its FULL size against the oracle itself (the box's host runs N=20k in seconds): log-likelihood, log-det, KVinvY,
+    posterior mean and covariance -- the same tolerances as the golden-vector tests."""
+    import fvgp_amd
+    from oracle import fvgp_oracle as orc
+    n = 20000
+    x, y = synth(n, 3)
+    nv = np.full(n, 0.01)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    gp = fvgp_amd.GP(x, y, init_hyperparameters=theta, noise_variances=nv, kernel_function="rbf_ard")
+    ref = orc.OracleGP(x, y, theta, nv, kernel="rbf_ard")
+    np.testing.assert_allclose(gp.log_likelihood(), ref.log_likelihood(), rtol=1e-10)
+    np.testing.assert_allclose(gp.logdet_KV, ref.logdet_KV, rtol=1e-10)
+    assert np.max(np.abs(gp.KVinvY - ref.KVinvY)) <= 1e-8 * np.max(np.abs(ref.KVinvY))
+    np.testing.assert_allclose(gp._L.diagonal()[:n:97].cpu().numpy(), np.diag(ref.Chol_factor)[::97], rtol=1e-10)
+    xp = np.random.default_rng(2).random((200, 3))
+    np.testing.assert_allclose(gp.posterior_mean(xp)["m(x)"], ref.posterior_mean(xp)["m(x)"], rtol=1e-8, atol=1e-10)
+    pc, rc = gp.posterior_covariance(xp), ref.posterior_covariance(xp)
+    assert np.max(np.abs(pc["S"] - rc["S"])) <= 1e-10 * theta[0]
+    assert np.max(np.abs(pc["v(x)"] - rc["v(x)"])) <= 1e-10 * theta[0]
+    t2 = theta * np.array([1.3, 0.8, 1.1, 0.9])
+    np.testing.assert_allclose(gp.log_likelihood(t2), ref.log_likelihood(t2), rtol=1e-10)
+
+
 def test_config3_n50000_matern52_value_and_gradient():
     """C3: N=50k d=3 Matern-5/2: log marginal likelihood + hyperparameter gradient on one MI355X."""
     import fvgp_amd
@@ -117,6 +141,40 @@ def test_config5_multitask_4x10000():
     assert np.max(np.abs(pm[:, 0] - np.sin(3 * s2))) < 0.15 and np.max(np.abs(pm[:, 1] - np.cos(3 * s2))) < 0.15
     pc = gp.posterior_covariance(xp)
     assert pc["S"].shape == (32, 32, 4, 4) and pc["v(x)"].shape == (32, 4) and np.all(pc["v(x)"] >= 0)
+
+
+def test_config5_shape_4x2500_against_the_oracle():
+    """C5's shape at a quarter of its size (4 tasks x 2 500 points -> N = 10 000 over the index set; the oracle runs it in seconds)
+    against the oracle's multi-task restatement: index-set transform, log-likelihood, gradient, posterior reshapes."""
+    import fvgp_amd
+    from oracle import fvgp_oracle as orc
+    rng = np.random.default_rng(20240501)
+    xm = rng.random((2500, 2))
+    s = xm.sum(axis=1)
+    ym = np.stack([np.sin(3 * s), np.cos(3 * s), np.linalg.norm(xm, axis=1), np.sin(3 * s) * np.cos(3 * s)], axis=1)
+    ym = ym + 0.05 * rng.standard_normal(ym.shape)
+    theta = np.array([1.0, 0.3, 0.3, 1.0])
+    nvm = np.full(ym.shape, 0.01)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = fvgp_amd.fvGP(xm, ym, init_hyperparameters=theta, noise_variances=nvm)
+    xi, yi, nvi = orc.transform_index_set(xm, ym, nvm)
+    assert np.array_equal(gp.x_data, xi) and np.array_equal(gp.y_data[:, 0], yi)
+    ref = orc.OracleGP(xi, yi, theta, nvi, kernel="matern32_ard", x_out=np.arange(4))
+    np.testing.assert_allclose(gp.log_likelihood(), ref.log_likelihood(), rtol=1e-10)
+    t2 = theta * np.array([1.2, 0.9, 1.1, 0.8])
+    np.testing.assert_allclose(gp.log_likelihood(t2), ref.log_likelihood(t2), rtol=1e-10)
+    assert np.max(np.abs(gp.KVinvY - ref.KVinvY)) <= 1e-8 * np.max(np.abs(ref.KVinvY))
+    g, g_ref = gp.neg_log_likelihood_gradient(theta), ref.neg_log_likelihood_gradient_potri(theta)
+    np.testing.assert_allclose(g, g_ref, rtol=1e-7, atol=1e-8 * np.max(np.abs(g_ref)))
+    xp = rng.random((16, 2))
+    pm, rm = gp.posterior_mean(xp), ref.posterior_mean(xp)
+    assert pm["m(x)"].shape == (16, 4)
+    np.testing.assert_allclose(pm["m(x)"], rm["m(x)"], rtol=1e-8, atol=1e-10)
+    pc, rc = gp.posterior_covariance(xp), ref.posterior_covariance(xp)
+    assert pc["S"].shape == (16, 16, 4, 4)
+    assert np.max(np.abs(pc["S"] - rc["S"])) <= 1e-10 * theta[0]
+    assert np.max(np.abs(pc["v(x)"] - rc["v(x)"])) <= 1e-10 * theta[0]
 
 
 def test_config4_size_n100000_two_drivers_agree():
