@@ -27,7 +27,7 @@ SYMBOLS = [
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_grad_trace", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower",
-    "fvgp_hip_debug_tile_map", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
+    "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
 ]
 
 
@@ -108,8 +108,10 @@ def lib():
     L.fvgp_hip_syrk_rowshard.argtypes = [c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i]
     L.fvgp_hip_debug_tile_map.argtypes = [c_i, c_i, c_i, c_i, c_i, P_i, P_i, c_l]
     L.fvgp_hip_debug_tile_map.restype = c_l
+    L.fvgp_hip_debug_tile_table.argtypes = [c_i, c_i, c_i, c_i, c_i, P_i, c_l]
+    L.fvgp_hip_debug_tile_table.restype = c_l
     for s in SYMBOLS:
-        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map", "fvgp_hip_workspace_bytes"):
+        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_workspace_bytes"):
             getattr(L, s).restype = c_i
     _lib = L
     return L
@@ -165,7 +167,7 @@ class Handle:
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(lib().fvgp_hip_create(ctypes.byref(self._h), self.device, ctypes.c_void_p(stream)), "fvgp_hip_create")
-        for key in ("lookahead", "outer_block", "outer_block_big", "big_threshold", "inner_block", "gemm_direct", "small_tile_max", "small_tile_max_update"):        # tuning overrides, e.g. FVGP_OUTER_BLOCK=512
+        for key in ("lookahead", "outer_block", "outer_block_big", "big_threshold", "inner_block", "gemm_direct", "small_tile_max", "small_tile_max_update", "tile_tables"):        # tuning overrides, e.g. FVGP_OUTER_BLOCK=512
             val = os.environ.get("FVGP_" + key.upper())
             if val is not None:
                 self.set_option(key, int(val))

@@ -53,6 +53,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     for (auto e : h->ev_stage) if (e) (void)hipEventDestroy(e);
     for (auto e : h->rs_ev) (void)hipEventDestroy(e);
     if (h->ev_cols) (void)hipEventDestroy(h->ev_cols);
+    gemm_release_tables(h);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->linv) (void)hipFree(h->linv);
     if (h->logdet_parts) (void)hipFree(h->logdet_parts);
@@ -109,6 +110,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "big_threshold")) { h->big_threshold = value; return 0; }
     if (!strcmp(key, "gemm_probe")) { h->gemm_probe = (int)value; return 0; }
     if (!strcmp(key, "gemm_direct")) { h->gemm_direct = (int)value; return 0; }
+    if (!strcmp(key, "tile_tables")) { h->tile_tables = value ? 1 : 0; return 0; }
     if (!strcmp(key, "leaf_stamps")) { h->leaf_stamps = reinterpret_cast<unsigned long *>((uintptr_t)value); return 0; }
     if (!strcmp(key, "small_tile_max")) { h->small_tile_max = value; return 0; }
     if (!strcmp(key, "small_tile_max_update")) { h->small_tile_max_update = value; return 0; }
@@ -961,6 +963,12 @@ int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int scale, 
     if (tiles_m < 1 || tiles_n < 1 || !out_ti || !out_tj) return -1;
     if (lower < 0 || lower > 2 || (lower == 2 && scale < 1)) return -3;
     return gemm_debug_tile_map(tiles_m, tiles_n, lower, scale, off, out_ti, out_tj, cap);
+}
+
+int64_t fvgp_hip_debug_tile_table(int tiles_m, int tiles_n, int lower, int scale, int off, int *out, int64_t cap) {
+    if (tiles_m < 1 || tiles_n < 1 || tiles_m >= 32768 || tiles_n >= 32768 || !out) return -1;
+    if (lower < 0 || lower > 2 || (lower == 2 && scale < 1)) return -3;
+    return gemm_debug_tile_table(tiles_m, tiles_n, lower, scale, off, out, cap);
 }
 
 int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters) {

@@ -39,6 +39,7 @@ struct fvgp_handle {
     int64_t small_tile_max_update = 512;   // trailing updates of at most this many 128-tiles also run on 64-tiles
     int64_t small_tile_max = 160;     // (M,K) x (N,K) products of at most this many 128-tiles and K <= 512 run on 64-tiles
     unsigned long *leaf_stamps = nullptr;   // diagnostics (option "leaf_stamps" = device pointer): phase timestamps of the leaf kernel
+    int tile_tables = 1;              // plain launches of >= 1024 tiles take the XCD-balanced tile table instead of the formula map
     int gemm_probe = 0;               // fvgp_hip_gemm launches a K-loop timing probe instead (diagnostics)
     int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel
@@ -88,6 +89,8 @@ struct GemmDesc {
 };
 int launch_gemm(fvgp_handle *h, const GemmDesc &g);
 bool gemm_takes_small_tiles(const fvgp_handle *h, const GemmDesc &g);   // the launch runs gemm_f64_small_kernel, not gemm_f64_kernel
+void gemm_release_tables(fvgp_handle *h);
+long gemm_debug_tile_table(int tiles_m, int tiles_n, int lower, int ls, int lo, int *out, long cap);
 long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int ls, int lo, int *out_ti, int *out_tj, long cap);
 
 struct KmatDesc {

@@ -19,6 +19,7 @@
 //     super-tiles to the same XCD (blocks b, b+8, .. share an L2), so the row/column slabs
 //     of L21 a super-tile needs are fetched into that XCD's L2 once.
 #include "common.h"
+#include <map>
 
 namespace {
 
@@ -38,6 +39,7 @@ struct GemmArgs {
     long K;
     long kb0, kbi, kbj, ke0, kei, kej;
     long ntiles;
+    const int *tab;                   // balanced block -> tile table ((ti << 16) | tj, -1 = no tile), or nullptr: formula
 };
 
 // linear index -> (ti, tj).  Tiles are enumerated in super-tiles of 8 x SN (SN = min(8, tiles_n)),
@@ -155,13 +157,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // XCD-aware remap: hardware deals block b to XCD b%8.  Blocks b, b+8, b+16, .. (one XCD) walk whole
     // super-tiles: the 8*SN tiles of a super-tile run together on one L2, and super-tiles are dealt
     // round-robin over the XCDs so every XCD gets the same mix of full and diagonal (half-empty) ones.
-    const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
     int ti, tj;
-    if (g.lower == 2) tile_of_rs(t, g.tiles_m, g.tiles_n, g.ls, g.lo, ti, tj);
-    else tile_of(t, g.tiles_m, g.tiles_n, g.lower == 1, ti, tj);
-    if (ti >= g.tiles_m || tj >= g.tiles_n) return;
-    if (g.lower == 1 && tj > ti) return;
-    if (g.lower == 2 && tj > ti * g.ls + g.lo) return;
+    if (g.tab) {                      // balanced table: every XCD (blocks b, b + 8, ..) gets the same number of real tiles
+        const int e = g.tab[blockIdx.x];
+        if (e < 0) return;
+        ti = e >> 16; tj = e & 0xffff;
+    } else {
+        const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
+        if (g.lower == 2) tile_of_rs(t, g.tiles_m, g.tiles_n, g.ls, g.lo, ti, tj);
+        else tile_of(t, g.tiles_m, g.tiles_n, g.lower == 1, ti, tj);
+        if (ti >= g.tiles_m || tj >= g.tiles_n) return;
+        if (g.lower == 1 && tj > ti) return;
+        if (g.lower == 2 && tj > ti * g.ls + g.lo) return;
+    }
     if (g.rev) ti = g.tiles_m - 1 - ti;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -423,13 +431,19 @@ __device__ __forceinline__ const double *uniform_ptr(const double *p) {
 // Two register stages (k0 and k0 + 8) alternate, so a stage's loads have 32 MFMAs of cover.
 template <int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_direct_kernel(GemmArgs g) {
-    const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
     int ti, tj;
-    if (g.lower == 2) tile_of_rs(t, g.tiles_m, g.tiles_n, g.ls, g.lo, ti, tj);
-    else tile_of(t, g.tiles_m, g.tiles_n, g.lower == 1, ti, tj);
-    if (ti >= g.tiles_m || tj >= g.tiles_n) return;
-    if (g.lower == 1 && tj > ti) return;
-    if (g.lower == 2 && tj > ti * g.ls + g.lo) return;
+    if (g.tab) {                      // balanced table: every XCD (blocks b, b + 8, ..) gets the same number of real tiles
+        const int e = g.tab[blockIdx.x];
+        if (e < 0) return;
+        ti = e >> 16; tj = e & 0xffff;
+    } else {
+        const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
+        if (g.lower == 2) tile_of_rs(t, g.tiles_m, g.tiles_n, g.ls, g.lo, ti, tj);
+        else tile_of(t, g.tiles_m, g.tiles_n, g.lower == 1, ti, tj);
+        if (ti >= g.tiles_m || tj >= g.tiles_n) return;
+        if (g.lower == 1 && tj > ti) return;
+        if (g.lower == 2 && tj > ti * g.ls + g.lo) return;
+    }
     if (g.rev) ti = g.tiles_m - 1 - ti;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -599,6 +613,78 @@ long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int ls, int lo, in
     return nwg;
 }
 
+// ---------------------------------------------------------------------------------------
+// Balanced tile tables.  The formula map deals whole 8 x 8 super-tiles to the XCDs; diagonal super-tiles are half empty and
+// the last ones partial, so the XCD with the most real tiles sets a launch's time: +2.5 % at 130-200 tile rows, +8-10 % at
+// <= 100, +6-25 % on the row-sharded (lower == 2) grids of an 8-rank run.  The table keeps the same super-tile walk (the 64
+// tiles of a super-tile run together on one L2) but cuts the sequence of REAL tiles into eight equal contiguous runs, one per
+// XCD (block b -> XCD b % 8, entry b / 8 of its run).  Built on the host once per launch shape, kept on the device.
+struct TileTabKey {
+    int tm, tn, lower, ls, lo;
+    bool operator<(const TileTabKey &o) const {
+        if (tm != o.tm) return tm < o.tm;
+        if (tn != o.tn) return tn < o.tn;
+        if (lower != o.lower) return lower < o.lower;
+        if (ls != o.ls) return ls < o.ls;
+        return lo < o.lo;
+    }
+};
+struct TileTab { int *dev; long grid; };
+static std::map<std::pair<fvgp_handle *, TileTabKey>, TileTab> g_tabs;
+
+void gemm_release_tables(fvgp_handle *h) {
+    for (auto it = g_tabs.begin(); it != g_tabs.end();) {
+        if (it->first.first == h) { (void)hipFree(it->second.dev); it = g_tabs.erase(it); } else ++it;
+    }
+}
+
+static std::vector<int> build_tile_table(int tm, int tn, int lower, int ls, int lo) {
+    // real tiles in the formula map's own super-tile order
+    const long nform = lower == 2 ? gemm_grid_tiles_rs(tm, tn, ls, lo) : gemm_grid_tiles(tm, tn, lower == 1);
+    std::vector<int> real;
+    real.reserve((size_t)nform);
+    for (long t = 0; t < nform; ++t) {
+        int ti, tj;
+        if (lower == 2) tile_of_rs(t, tm, tn, ls, lo, ti, tj);
+        else tile_of(t, tm, tn, lower == 1, ti, tj);
+        if (ti >= tm || tj >= tn) continue;
+        if (lower == 1 && tj > ti) continue;
+        if (lower == 2 && tj > (long)ti * ls + lo) continue;
+        real.push_back((ti << 16) | tj);
+    }
+    const long T = (long)real.size();
+    const long per = (T + 7) / 8;
+    std::vector<int> tab((size_t)(per * 8), -1);
+    for (long x = 0; x < 8; ++x) {                 // XCD x takes the contiguous run [x*T/8, (x+1)*T/8)
+        const long a = x * T / 8, b = (x + 1) * T / 8;
+        for (long i = a; i < b; ++i) tab[(size_t)((i - a) * 8 + x)] = real[(size_t)i];
+    }
+    return tab;
+}
+
+// host-side view of the table for the CPU tests: entries (ti << 16) | tj or -1, returns the grid size
+long gemm_debug_tile_table(int tiles_m, int tiles_n, int lower, int ls, int lo, int *out, long cap) {
+    const std::vector<int> tab = build_tile_table(tiles_m, tiles_n, lower, ls, lo);
+    for (size_t i = 0; i < tab.size() && (long)i < cap; ++i) out[i] = tab[i];
+    return (long)tab.size();
+}
+
+static int tile_table(fvgp_handle *h, int tm, int tn, int lower, int ls, int lo, const int **dev, long *grid) {
+    const std::pair<fvgp_handle *, TileTabKey> key{h, TileTabKey{tm, tn, lower, ls, lo}};
+    auto it = g_tabs.find(key);
+    if (it == g_tabs.end()) {
+        const std::vector<int> tab = build_tile_table(tm, tn, lower, ls, lo);
+        TileTab tt{nullptr, (long)tab.size()};
+        if (tt.grid > 0) {
+            HIPCHK(hipMalloc((void **)&tt.dev, (size_t)tt.grid * sizeof(int)));
+            HIPCHK(hipMemcpy(tt.dev, tab.data(), (size_t)tt.grid * sizeof(int), hipMemcpyHostToDevice));
+        }
+        it = g_tabs.emplace(key, tt).first;
+    }
+    *dev = it->second.dev; *grid = it->second.grid;
+    return 0;
+}
+
 // a trailing update that small -- under about one round of 128-tiles -- is a step of the chain too: the columns of the
 // next panel wait for it
 bool gemm_takes_small_tiles(const fvgp_handle *h, const GemmDesc &d) {
@@ -627,6 +713,14 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     if ((d.bc_ranks > 1 || d.bc_off) && d.b_nmajor) { fvgp_set_error("gemm: block-cyclic B needs the (N, K) layout"); return -7; }
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
+    g.tab = nullptr;
+    const bool plain_k = d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && d.kei == 0 && d.kej == 0;
+    if (h->tile_tables && plain_k && !d.rev_m && !d.probe && g.tiles_m < 32768 && g.tiles_n < 32768 &&
+        g.ntiles >= 1024 && !gemm_takes_small_tiles(h, d)) {
+        // equal work per tile: balance the XCDs by tile count (launches with per-tile K ranges keep the formula map)
+        const int rc = tile_table(h, g.tiles_m, g.tiles_n, g.lower, g.ls, g.lo, &g.tab, &g.ntiles);
+        if (rc) return rc;
+    }
     if (g.ntiles == 0) return 0;
     dim3 grid((unsigned)g.ntiles), block(256);
     if (d.probe) {
