@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
 #include <vector>
 #include "../../include/fvgp_hip.h"
@@ -11,6 +12,19 @@ constexpr int LEAF_DOUBLES = TILE * TILE;
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// XCD-balanced block -> tile tables of the GEMM launches, one per launch shape (gemm.hip)
+struct TileTabKey {
+    int tm, tn, lower, ls, lo;
+    bool operator<(const TileTabKey &o) const {
+        if (tm != o.tm) return tm < o.tm;
+        if (tn != o.tn) return tn < o.tn;
+        if (lower != o.lower) return lower < o.lower;
+        if (ls != o.ls) return ls < o.ls;
+        return lo < o.lo;
+    }
+};
+struct TileTab { int *dev; long grid; };
 
 struct fvgp_handle {
     int device = 0;
@@ -39,7 +53,8 @@ struct fvgp_handle {
     int64_t small_tile_max_update = 512;   // trailing updates of at most this many 128-tiles also run on 64-tiles
     int64_t small_tile_max = 160;     // (M,K) x (N,K) products of at most this many 128-tiles and K <= 512 run on 64-tiles
     unsigned long *leaf_stamps = nullptr;   // diagnostics (option "leaf_stamps" = device pointer): phase timestamps of the leaf kernel
-    int tile_tables = 1;              // plain launches of >= 1024 tiles take the XCD-balanced tile table instead of the formula map
+    std::map<TileTabKey, TileTab> tile_tabs;   // device-resident, freed with the handle
+    int tile_tables = 1;              // plain launches of the 128-tile kernels take the XCD-balanced tile table instead of the formula map
     int gemm_probe = 0;               // fvgp_hip_gemm launches a K-loop timing probe instead (diagnostics)
     int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel

@@ -19,7 +19,6 @@
 //     super-tiles to the same XCD (blocks b, b+8, .. share an L2), so the row/column slabs
 //     of L21 a super-tile needs are fetched into that XCD's L2 once.
 #include "common.h"
-#include <map>
 
 namespace {
 
@@ -619,23 +618,9 @@ long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int ls, int lo, in
 // <= 100, +6-25 % on the row-sharded (lower == 2) grids of an 8-rank run.  The table keeps the same super-tile walk (the 64
 // tiles of a super-tile run together on one L2) but cuts the sequence of REAL tiles into eight equal contiguous runs, one per
 // XCD (block b -> XCD b % 8, entry b / 8 of its run).  Built on the host once per launch shape, kept on the device.
-struct TileTabKey {
-    int tm, tn, lower, ls, lo;
-    bool operator<(const TileTabKey &o) const {
-        if (tm != o.tm) return tm < o.tm;
-        if (tn != o.tn) return tn < o.tn;
-        if (lower != o.lower) return lower < o.lower;
-        if (ls != o.ls) return ls < o.ls;
-        return lo < o.lo;
-    }
-};
-struct TileTab { int *dev; long grid; };
-static std::map<std::pair<fvgp_handle *, TileTabKey>, TileTab> g_tabs;
-
 void gemm_release_tables(fvgp_handle *h) {
-    for (auto it = g_tabs.begin(); it != g_tabs.end();) {
-        if (it->first.first == h) { (void)hipFree(it->second.dev); it = g_tabs.erase(it); } else ++it;
-    }
+    for (auto &kv : h->tile_tabs) (void)hipFree(kv.second.dev);
+    h->tile_tabs.clear();
 }
 
 static std::vector<int> build_tile_table(int tm, int tn, int lower, int ls, int lo) {
@@ -670,16 +655,16 @@ long gemm_debug_tile_table(int tiles_m, int tiles_n, int lower, int ls, int lo, 
 }
 
 static int tile_table(fvgp_handle *h, int tm, int tn, int lower, int ls, int lo, const int **dev, long *grid) {
-    const std::pair<fvgp_handle *, TileTabKey> key{h, TileTabKey{tm, tn, lower, ls, lo}};
-    auto it = g_tabs.find(key);
-    if (it == g_tabs.end()) {
+    const TileTabKey key{tm, tn, lower, ls, lo};
+    auto it = h->tile_tabs.find(key);
+    if (it == h->tile_tabs.end()) {
         const std::vector<int> tab = build_tile_table(tm, tn, lower, ls, lo);
         TileTab tt{nullptr, (long)tab.size()};
         if (tt.grid > 0) {
             HIPCHK(hipMalloc((void **)&tt.dev, (size_t)tt.grid * sizeof(int)));
             HIPCHK(hipMemcpy(tt.dev, tab.data(), (size_t)tt.grid * sizeof(int), hipMemcpyHostToDevice));
         }
-        it = g_tabs.emplace(key, tt).first;
+        it = h->tile_tabs.emplace(key, tt).first;
     }
     *dev = it->second.dev; *grid = it->second.grid;
     return 0;
@@ -716,7 +701,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.tab = nullptr;
     const bool plain_k = d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && d.kei == 0 && d.kej == 0;
     if (h->tile_tables && plain_k && !d.rev_m && !d.probe && g.tiles_m < 32768 && g.tiles_n < 32768 &&
-        g.ntiles >= 1024 && !gemm_takes_small_tiles(h, d)) {
+        g.ntiles >= 64 && !gemm_takes_small_tiles(h, d)) {
         // equal work per tile: balance the XCDs by tile count (launches with per-tile K ranges keep the formula map)
         const int rc = tile_table(h, g.tiles_m, g.tiles_n, g.lower, g.ls, g.lo, &g.tab, &g.ntiles);
         if (rc) return rc;

@@ -200,7 +200,7 @@ int fvgp_hip_mfma_selftest(fvgp_handle *h, const double *A16x4, const double *B4
  * (no GPU needed); returns the grid size, fills min(grid, cap) entries; out-of-range tiles are
  * the ones the kernel exits on. */
 int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int scale, int off, int *out_ti, int *out_tj, int64_t cap);
-/* host-only: the XCD-balanced block -> tile table a plain launch of >= 1024 tiles uses instead of the formula map (block b runs
+/* host-only: the XCD-balanced block -> tile table the plain launches of the 128-tile kernels use instead of the formula map (block b runs
  * on XCD b % 8; each XCD gets a contiguous, equally long run of the REAL tiles in super-tile order).  Entries are
  * (tile row << 16) | tile col, or -1; returns the grid size, fills min(grid, cap) entries. */
 int64_t fvgp_hip_debug_tile_table(int tiles_m, int tiles_n, int lower, int scale, int off, int *out, int64_t cap);
