@@ -567,7 +567,7 @@ int fvgp_hip_panel_potrf_dev(fvgp_handle *h, double *T, int64_t w, int64_t rows,
     if (rc) return rc;
     h->linv_L = nullptr;
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
-    rc = panel_factor(h, T, n_valid, rows, ldt, 0, w);       // leaf / TRSM of every row below / in-panel update, per 128 columns
+    rc = panel_factor_nested(h, T, n_valid, rows, ldt, 0, w);   // leaf / TRSM of every row below / in-panel update per 128 columns, in sub-panels of `inner_block`
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     if (logdet_dev && n_valid > 0) return launch_diag_logsum(h, T, n_valid, ldt, logdet_dev);
