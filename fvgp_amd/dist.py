@@ -212,11 +212,15 @@ class ShardedGP:
         self.info_dev = o.zeros(self.npan, dtype=torch.int32)
         self.ld_dev = o.zeros(self.npan)
         if self.P > 1:
-            self._T = o.zeros((self.NB + self.nloc * TILE) * self.NB)   # tall panel: diagonal block + local rows
+            # tall panel: diagonal block + local rows; two of them, so that the trailing update of panel J can keep reading its
+            # rows from the compact panel while the chain of panel J + 1 fills the other one
+            self._T = [o.zeros((self.NB + self.nloc * TILE) * self.NB) for _ in range(2)]
+            self._low = [None, None]
             self._recv = [o.zeros(self.P * self.nb_max * TILE * self.NB) for _ in range(2)]
             # the factored NB x NB diagonal blocks, replicated: the panel-local part of every later solve
             # (N x NB doubles per rank, 0.4 GB at N = 50k)
             self._Dfac = o.zeros(self.npan, self.NB, self.NB)
+        self.keep_factor = True            # False: a likelihood-only evaluation leaves the factored panels out of A (no copy back)
         self.theta = None
         self.alpha = None                  # KVinvY, replicated, (np_, 128) with the first ncol columns in use
         self._into_tensor = self.P > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl"
@@ -286,7 +290,7 @@ class ShardedGP:
             lb = max(0, -(-(b1 - p) // P))
             L0 = b1 // P                                            # uniform first gathered local block (L0 <= lb)
             kt = (self.nloc - L0) * TILE                            # rows below: local blocks L0.. and the (y-m)^T block
-            T = self._T[:(w + kt) * w].view(w + kt, w)
+            T = self._T[J % 2][:(w + kt) * w].view(w + kt, w)
             D, low = T[:w], T[w:]
             D.zero_()
             mine = None
@@ -297,9 +301,13 @@ class ShardedGP:
             low.copy_(A[L0 * TILE:, J0:Jend])
             o.panel_potrf_dev(T, w, w + kt, n_valid, info, ld)
             self._Dfac[J, :w, :w].copy_(D)
-            if mine is not None:
-                A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)).copy_(mine)
-            A[lb * TILE:, J0:Jend].copy_(low[(lb - L0) * TILE:])
+            self._low[J % 2] = low[(lb - L0) * TILE:]                # this rank's rows below the panel, compact (ld = w)
+            if self.keep_factor:                                    # the solves that follow read the factor from A
+                if mine is not None:
+                    A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)).copy_(mine)
+                A[lb * TILE:, J0:Jend].copy_(self._low[J % 2])
+            else:                                                   # only the (y-m)^T rows are read back at the end
+                A[self.zrow:, J0:Jend].copy_(low[(self.nb_max - L0) * TILE:])
             if Jend < self.np_:
                 k = (self.nb_max - L0) * TILE
                 self._timed("all_gather", 8.0 * (P - 1) * k * w, self._all_gather,
@@ -323,7 +331,8 @@ class ShardedGP:
             b_blocks, b_off = self.nb_max - L0, cb - L0 * P
         else:
             B, b_blocks, b_off = A[c0:self.zrow, J0:Jend], 0, 0
-        o.syrk_rowshard(M, c1 - c0, w, A[l0 * TILE:, J0:Jend], B, A[l0 * TILE:, c0:], P, l0 * P + p - cb,
+        Arows = A[l0 * TILE:, J0:Jend] if P == 1 else self._low[J % 2]      # P > 1: the compact panel (same values, ld = w)
+        o.syrk_rowshard(M, c1 - c0, w, Arows, B, A[l0 * TILE:, c0:], P, l0 * P + p - cb,
                         P, b_blocks, b_off)
 
     def factor(self):
@@ -370,10 +379,13 @@ class ShardedGP:
         lb = max(la, max(0, -(-(b1 - self.p) // self.P)))
         return la, lb, la * self.P + self.p - b0, J0, Jend
 
-    def evaluate(self, theta, want_alpha=False):
+    def evaluate(self, theta, want_alpha=False, keep_factor=True):
         """One pass of the path on the sharded matrix: assemble, factor (the forward solve rides along), optionally
-        the backward solve.  Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated."""
+        the backward solve.  Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated.
+        keep_factor=False (likelihood only): the factored panels are not copied back into the matrix, so no solve,
+        gradient or posterior can follow this evaluation."""
         torch = self.torch
+        self.keep_factor = bool(keep_factor or want_alpha)
         with self.ops.stream():
             self.assemble(theta)
             self.factor()
@@ -384,7 +396,7 @@ class ShardedGP:
             J = int(bad[0])
             self.theta = None
             raise np.linalg.LinAlgError(f"{self.bnd[J] + int(out[2 + J])}-th leading minor of the array is not positive definite")
-        self.theta = np.array(theta, dtype=np.float64)
+        self.theta = np.array(theta, dtype=np.float64) if self.keep_factor else None
         self.alpha = None
         quad, logdet = float(out[0]) / self.ncol, float(out[1])
         if want_alpha:
@@ -394,7 +406,7 @@ class ShardedGP:
     def log_likelihood(self, theta):
         """GPMarginalLikelihood.log_likelihood(theta) (gp_marginal_likelihood.py:137-179) on the sharded matrix.
         Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated on every rank."""
-        return self.evaluate(theta)
+        return self.evaluate(theta, keep_factor=False)
 
     # -- solves with the distributed factor ---------------------------------------------------------
     def solve_backward(self):

@@ -202,7 +202,7 @@ class GP(ValidationMixin):
                          panel=int(self.args.get("shard_panel", 1024)), rank=self.args.get("shard_rank"),
                          world=self.args.get("shard_world"))
 
-    def _evaluate_sharded(self, hps, state):
+    def _evaluate_sharded(self, hps, state, keep_factor=True):
         """The same pass on the row-sharded matrix: `state` True evaluates into the object that holds the GP's state
         (KVinvY included), False into the scratch twin (gp_kv.py:574-578: an evaluation at another theta touches no state)."""
         hps = np.asarray(hps, dtype=np.float64)
@@ -217,7 +217,7 @@ class GP(ValidationMixin):
             raise NotImplementedError("the row-sharded mode takes a diagonal noise model")
         sh.set_targets(self.y_data - m[:, None], V)
         try:
-            ll, logdet, _ = sh.evaluate(hps, want_alpha=state)
+            ll, logdet, _ = sh.evaluate(hps, want_alpha=state, keep_factor=keep_factor)
         except np.linalg.LinAlgError as e:
             raise NonPositiveDefiniteError(_non_pd_message(self.point_number, str(e).split("-th")[0], float(np.min(V)), 0.0)) from e
         return ll, logdet, m, V, sh
@@ -442,7 +442,7 @@ class GP(ValidationMixin):
             return self._loglik
         try:
             if self._sharded:
-                ll = self._evaluate_sharded(hyperparameters, state=False)[0]
+                ll = self._evaluate_sharded(hyperparameters, state=False, keep_factor=False)[0]
             else:
                 KV, aw = self._scratch()
                 ll, _, _, _ = self._evaluate(hyperparameters, KV, aw, need_alpha=False)
