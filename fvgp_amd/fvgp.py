@@ -54,7 +54,17 @@ class fvGP(GP):
 
     def update_gp_data(self, x_new, y_new, noise_variances_new=None, append=True, rank_n_update=None):
         """fvgp/fvgp.py:575-623: transform the new block to the index set, then GP.update_gp_data."""
+        assert isinstance(x_new, np.ndarray), "Wrong format in x_new."
+        assert isinstance(y_new, np.ndarray), "Wrong format in y_new."
+        assert len(x_new) == len(y_new), "updated x and y do not have the same lengths."
         x, y, nv = transform_index_set(x_new, y_new, noise_variances_new, self.output_num)
         x_out, isd = self.x_out, self.input_set_dim
         super().update_gp_data(x, y, nv, append=append, rank_n_update=rank_n_update)
         self.x_out, self.input_set_dim = x_out, isd
+        if append:                                                # the (V, Di) / (V, No) view of the data, fvgp.py:598-616
+            self.fvgp_x_data = np.vstack([self.fvgp_x_data, x_new])
+            self.fvgp_y_data = np.vstack([self.fvgp_y_data, y_new])
+            self.fvgp_noise_variances = (None if noise_variances_new is None
+                                         else np.vstack([self.fvgp_noise_variances, noise_variances_new]))
+        else:
+            self.fvgp_x_data, self.fvgp_y_data, self.fvgp_noise_variances = x_new, y_new, noise_variances_new

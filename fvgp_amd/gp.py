@@ -313,24 +313,35 @@ class GP(ValidationMixin):
         extended by bordering on the device -- v = L^-1 k(x_old, x_new), L22 = chol(K22 + V22 - v^T v)
         (cholesky_update_rank_n, gp_lin_alg.py:1310-1477; GPkv.update_KV, gp_kv.py:462-476) -- O(n^2 m) instead of
         the O(n^3) refactorisation; KVinvY and log|KV| are then refreshed from the new factor (gp_kv.py:404-423)."""
-        assert isinstance(x_new, np.ndarray) and isinstance(y_new, np.ndarray), "wrong format in new data"
-        if np.ndim(y_new) == 1:
-            y_new = y_new.reshape(len(y_new), 1)
+        assert isinstance(x_new, np.ndarray) and np.ndim(x_new) == 2, \
+            "wrong format in x_new: a 2-d np.ndarray (non-Euclidean lists are not on the native path)"
+        assert isinstance(y_new, np.ndarray) and np.ndim(y_new) in (1, 2), "wrong format in y_new"
+        assert ((isinstance(noise_variances_new, np.ndarray) and np.ndim(noise_variances_new) == 1)
+                or noise_variances_new is None), "noise_variances_new must be a 1-d np.ndarray or None"
+        assert len(x_new) == len(y_new), "updated x and y do not have the same lengths."
         if rank_n_update is None:
             rank_n_update = append
+        if not append and rank_n_update:                              # gp.py:733-737
+            warnings.warn("`rank_n_update=True` is invalid when `append=False` (the previous factorization belongs "
+                          "to data that no longer exists). Forcing `rank_n_update=False`.")
+            rank_n_update = False
+        if self.noise_variances is not None and noise_variances_new is None:          # gp_data.py:84-89
+            raise Exception("Please provide noise_variances in the data update because you did at initialization "
+                            "or during a previous update.")
+        if self.noise_variances is None and noise_variances_new is not None:
+            raise Exception("You did not initialize noise and but included noise in the update."
+                            "Please reinitialize in this case.")
+        if np.ndim(y_new) == 1:
+            y_new = y_new.reshape(len(y_new), 1)
         if not append:
             self._set_data(x_new, y_new, noise_variances_new)
             self.set_hyperparameters(self._hps)
             return
-        assert len(x_new) == len(y_new), "x_new and y_new do not have the same lengths."
+        assert x_new.shape[1] == self.x_data.shape[1] and y_new.shape[1] == self.y_data.shape[1], \
+            "appended data must have the column counts of the existing data"
         x = np.vstack([self.x_data, x_new])
         y = np.vstack([self.y_data, y_new])
-        if self.noise_variances is not None:
-            if noise_variances_new is None:
-                raise Exception("Please provide noise_variances in the data update.")
-            nv = np.concatenate([self.noise_variances, noise_variances_new])
-        else:
-            nv = None
+        nv = None if self.noise_variances is None else np.concatenate([self.noise_variances, noise_variances_new])
         n_old = self.point_number
         if not (rank_n_update and self._native is not None and len(x_new) > 0) or self._sharded:
             self._set_data(x, y, nv)
@@ -841,20 +852,32 @@ class GP(ValidationMixin):
     # ------------------------------------------------------------------------------------------
     # training: the callers of the path -- device-resident objective, host optimiser
     # ------------------------------------------------------------------------------------------
-    def train(self, hyperparameter_bounds=None, init_hyperparameters=None, method="mcmc", pop_size=20,
-              tolerance=0.0001, max_iter=10000, local_optimizer="L-BFGS-B", constraints=(), info=False,
-              dask_client=None, seed=None, accept_only_if_improved=True):
+    def train(self, hyperparameter_bounds=None, objective_function=None, objective_function_gradient=None,
+              objective_function_hessian=None, init_hyperparameters=None, method="mcmc", pop_size=20, tolerance=0.0001,
+              max_iter=10000, mcmc_prior=None, mcmc_prop_distrs="normal", mcmc_args=None, bo_args=None,
+              local_optimizer="L-BFGS-B", global_optimizer="genetic", constraints=(), dask_client=None, info=False,
+              asynchronous=False, accept_only_if_improved=True, seed=None):
         """fvgp/gp.py:781-1141 for the methods that run without Dask/HGDL: 'mcmc' (default), 'adam',
-        'global' (differential evolution), 'local'.  Every objective call is one device evaluation;
-        x, y never leave HBM.  Returns the optimised hyperparameters and sets them (gp.py:1112).
-        'mcmc' draws from numpy's legacy global stream like the reference (seed: a RandomState(seed) instead);
-        'local' / 'adam' results that lower the log marginal likelihood are rejected unless
+        'global' (differential evolution), 'local', or a callable that gets the GP.  Every objective call is one
+        device evaluation; x, y never leave HBM.  Returns the optimised hyperparameters and sets them (gp.py:1112).
+        Argument checks follow gp.py:1007-1053: default bounds come with a warning, out-of-bounds starting points are
+        redrawn uniformly with a warning, 'mcmc' ignores a user objective, a user objective for 'local' needs its
+        gradient.  'mcmc' draws from numpy's legacy global stream like the reference (seed: a RandomState(seed)
+        instead); 'local' / 'adam' / callable results that lower the log marginal likelihood are rejected unless
         accept_only_if_improved=False (gp.py:1086-1168)."""
         from . import gp_training
+        if mcmc_prop_distrs not in ("normal", None):
+            raise NotImplementedError("the MCMC driver here has the reference's default proposal only: one adaptive "
+                                      "normal distribution over all hyperparameters (mcmc_prop_distrs='normal')")
+        if asynchronous:
+            if dask_client is None:
+                raise Exception("Please provide a dask_client for asynchronous training")
+            raise NotImplementedError("asynchronous (Dask actor) training is outside this engine's scope")
         if hyperparameter_bounds is None:
             hyperparameter_bounds = self._default_bounds()
-        if init_hyperparameters is None:
-            init_hyperparameters = self._hps.copy()
+            warnings.warn("Default hyperparameter_bounds initialized because none were provided. "
+                          "This will fail for custom kernel, mean, or noise functions")
+        hyperparameter_bounds = np.asarray(hyperparameter_bounds, dtype=np.float64)
         if self._sharded and seed is None:
             # every rank walks the same optimiser trajectory (each objective call is a collective): one seed for all
             import torch
@@ -866,13 +889,41 @@ class GP(ValidationMixin):
                 t = t.to(dev)
                 dist.broadcast(t, src=0, group=None if pg is True else pg)
             seed = int(t.item())
-        guarded = accept_only_if_improved and method in ("local", "adam")
+
+        def redraw():                                                   # gp.py:1026-1036
+            rng = np.random if seed is None else np.random.RandomState(seed)
+            return rng.uniform(low=hyperparameter_bounds[:, 0], high=hyperparameter_bounds[:, 1],
+                               size=len(hyperparameter_bounds))
+        if init_hyperparameters is None:
+            init_hyperparameters = self._hps.copy()
+            if len(init_hyperparameters) == len(hyperparameter_bounds) and \
+                    not gp_training._in_bounds(init_hyperparameters, hyperparameter_bounds):
+                init_hyperparameters = redraw()
+        else:
+            init_hyperparameters = np.asarray(init_hyperparameters, dtype=np.float64)
+            if len(init_hyperparameters) == len(hyperparameter_bounds) and \
+                    not gp_training._in_bounds(init_hyperparameters, hyperparameter_bounds):
+                warnings.warn("Your init_hyperparameters are out of bounds. They will be over-written")
+                init_hyperparameters = redraw()
+        user_objective = objective_function is not None
+        if method == "mcmc" and user_objective:
+            warnings.warn("MCMC always optimizes the log marginal likelihood; "
+                          "the user-defined objective_function is ignored.")
+            objective_function = None
+        if user_objective and objective_function_gradient is None and method in ("local", "hgdl"):
+            raise Exception("A gradient (and Hessian) of the objective function must be provided "
+                            "for method='local' or method='hgdl'.")
+        guarded = (accept_only_if_improved and not user_objective and
+                   (callable(method) or method in ("local", "hgdl", "adam")))
         incumbent = self._hps.copy() if guarded else None
         ll_incumbent = self.log_likelihood() if guarded else None
-        hps = gp_training.train(self, np.asarray(hyperparameter_bounds, dtype=np.float64),
-                                np.asarray(init_hyperparameters, dtype=np.float64), method=method,
+        hps = gp_training.train(self, hyperparameter_bounds, init_hyperparameters, method=method,
                                 pop_size=pop_size, tolerance=tolerance, max_iter=max_iter,
-                                local_optimizer=local_optimizer, constraints=constraints, info=info, seed=seed)
+                                local_optimizer=local_optimizer, constraints=constraints, info=info, seed=seed,
+                                objective_function=objective_function,
+                                objective_function_gradient=objective_function_gradient,
+                                objective_function_hessian=objective_function_hessian,
+                                mcmc_prior=mcmc_prior, mcmc_args={} if mcmc_args is None else mcmc_args)
         self.set_hyperparameters(np.asarray(hps, dtype=np.float64))
         if guarded and not self.log_likelihood() >= ll_incumbent:          # exact mode: strict comparison (gp.py:1158-1160)
             warnings.warn(f"Training with method=`{method}` returned hyperparameters with a lower log marginal likelihood "

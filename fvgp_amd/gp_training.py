@@ -12,15 +12,17 @@ def _in_bounds(theta, bounds):
     return bool(np.all((theta >= bounds[:, 0]) & (theta <= bounds[:, 1])))
 
 
-def run_mcmc(log_likelihood, bounds, x0, n_updates=10000, info=False, rng=None, break_default=True):
+def run_mcmc(log_likelihood, bounds, x0, n_updates=10000, info=False, rng=None, break_default=True, prior=None,
+             args=None):
     """Adaptive Metropolis-Hastings with one normal proposal over all hyperparameters.
 
     Follows gpMCMC.run_mcmc/_jump (gp_mcmc.py:96-224) and ProposalDistribution._adapt (:337-356):
     uniform prior on the bounds box, initial proposal covariance diag((0.2*range/sqrt(12))^2)
     (:84-87), covariance adapted every K=10 steps with gamma2 = 1/(i/K+3)^0.8, and the
     'default' break condition (|mean of last 100 f - mean of previous 100| < 1e-3 after 1000
-    iterations, :181-190).  One likelihood evaluation per proposal.  Returns the reference's
-    info dict; GP.train takes "median(x)" = median of the last 1 % of the trace.
+    iterations, :181-190).  One likelihood evaluation per proposal.  `prior(theta, bounds, args)` is a log prior
+    (-inf = reject without an evaluation, gp_mcmc.py:203-209); the default is the uniform box.  Returns the
+    reference's info dict; GP.train takes "median(x)" = median of the last 1 % of the trace.
     """
     # The reference draws from numpy's legacy global stream (np.random.multivariate_normal / np.random.uniform,
     # gp_mcmc.py:214,337-341): the default here is that same module, so `np.random.seed(s)` before train() walks the
@@ -32,22 +34,27 @@ def run_mcmc(log_likelihood, bounds, x0, n_updates=10000, info=False, rng=None, 
     std = (bounds[:, 1] - bounds[:, 0]) * 0.2 / np.sqrt(12)
     prop_Sigma = np.diag(std ** 2)
     K, c_1 = 10, 0.8
+    if prior is None:
+        def prior(theta, box, _args):
+            return 0.0 if _in_bounds(theta, box) else -np.inf
     x = np.array(x0, dtype=np.float64)
     f = log_likelihood(x)
+    p = prior(x, bounds, args)
     trace_x, trace_f, jumps = [x.copy()], [], []
     for i in range(1, n_updates):
         x_star = rng.multivariate_normal(mean=x, cov=prop_Sigma, size=1).reshape(len(x))
         jumped = 0.0
-        if _in_bounds(x_star, bounds):
+        p_star = prior(x_star, bounds, args)
+        if p_star != -np.inf:
             f_star = log_likelihood(x_star)
             if np.isnan(f_star):
                 raise Exception("Likelihood evaluation = NaN in gpMCMC")
-            expo = f_star - f
+            expo = p_star + f_star - p - f
             ratio = np.exp(expo) if expo < 50 else 1.1
             if np.isnan(ratio):
                 ratio = 0.0
             if ratio > rng.uniform(0, 1, 1):
-                x, f, jumped = x_star, f_star, 1.0
+                x, f, p, jumped = x_star, f_star, p_star, 1.0
         jumps.append(jumped)
         if i % K == 0:
             start = i - K + 1
@@ -101,40 +108,61 @@ def adam_optimize(nlml, grad_nlml, theta0, lr=1e-2, beta1=0.9, beta2=0.999, eps=
 
 
 def train(gp, bounds, init_hyperparameters, method="mcmc", pop_size=20, tolerance=1e-4, max_iter=10000,
-          local_optimizer="L-BFGS-B", constraints=(), info=False, seed=None):
-    """Dispatch on `method` (fvgp/gp_training.py:58-162).  Bounds / init checks: gp.py:1019-1036."""
+          local_optimizer="L-BFGS-B", constraints=(), info=False, seed=None, objective_function=None,
+          objective_function_gradient=None, objective_function_hessian=None, mcmc_prior=None, mcmc_args=None):
+    """Dispatch on `method` (GPtraining.train, fvgp/gp_training.py:28-196).  The objective is log_likelihood for
+    'mcmc' and neg_log_likelihood (+ gradient) otherwise unless the caller hands in their own (gp.py:1038-1053); a
+    callable `method` gets the GP and returns the hyperparameters (:194); the result must be a 1-d ndarray (:196)."""
     assert isinstance(bounds, np.ndarray) and bounds.ndim == 2 and bounds.shape[1] == 2, "wrong bounds format"
     if len(bounds) != len(init_hyperparameters):
         raise Exception("init_hyperparameters and hyperparameter_bounds have different lengths")
     if not _in_bounds(init_hyperparameters, bounds):
-        raise Exception("Starting hyperparameters out of bounds")
+        raise Exception("Starting positions outside of optimization bounds.", init_hyperparameters, bounds)
+    if objective_function is None and method in ("mcmc", "global", "local", "adam"):
+        objective_function = gp.log_likelihood if method == "mcmc" else gp.neg_log_likelihood
+    if objective_function_gradient is None and method in ("local", "adam"):
+        objective_function_gradient = gp.neg_log_likelihood_gradient
     if method == "mcmc":
-        res = run_mcmc(gp.log_likelihood, bounds, init_hyperparameters, n_updates=max_iter, info=info,
-                       rng=None if seed is None else np.random.RandomState(seed))
+        res = run_mcmc(objective_function, bounds, init_hyperparameters, n_updates=max_iter, info=info,
+                       rng=None if seed is None else np.random.RandomState(seed), prior=mcmc_prior, args=mcmc_args)
         gp.mcmc_info = res
-        return res["median(x)"]
-    if method == "global":
+        hps = res["median(x)"]
+    elif method == "global":
         from scipy.optimize import differential_evolution
-        res = differential_evolution(gp.neg_log_likelihood, bounds, maxiter=max_iter, popsize=pop_size, tol=tolerance,
+        res = differential_evolution(objective_function, bounds, maxiter=max_iter, popsize=pop_size, tol=tolerance,
                                      disp=info, polish=False, x0=init_hyperparameters.reshape(1, -1),
                                      constraints=constraints, workers=1, seed=seed)
-        return np.array(res["x"])
-    if method == "local":
+        hps = np.array(res["x"])
+    elif method == "local":
         from scipy.optimize import minimize
+        progress = None
+        if info:
+            state = {"i": 0}
+
+            def progress(intermediate_result):                               # gp_training.py:96-101
+                state["i"] += 1
+                print(f"fvGP local iteration {state['i']}: f(x)= {float(intermediate_result.fun)}")
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            res = minimize(gp.neg_log_likelihood, init_hyperparameters, method=local_optimizer,
-                           jac=gp.neg_log_likelihood_gradient, bounds=bounds, tol=tolerance,
-                           constraints=constraints, options={"maxiter": max_iter})
-        return res["x"]
-    if method == "adam":
+            res = minimize(objective_function, init_hyperparameters, method=local_optimizer,
+                           jac=objective_function_gradient, hess=objective_function_hessian, bounds=bounds,
+                           tol=tolerance, callback=progress, constraints=constraints, options={"maxiter": max_iter})
+        hps = res["x"]
+    elif method == "adam":
         progress = None
         if info:
             def progress(theta, fval, grad, iteration):                      # gp_training.py:163-177
                 if iteration % 10 == 0 or iteration == 1:
                     print(f"fvGP adam iteration {iteration} out of {max_iter}: f(x)= {float(fval)}, |grad|= {float(np.linalg.norm(grad))}")
-        hps, history = adam_optimize(gp.neg_log_likelihood, gp.neg_log_likelihood_gradient, init_hyperparameters,
+        hps, history = adam_optimize(objective_function, objective_function_gradient, init_hyperparameters,
                                      max_iter=max_iter, callback=progress)
         gp.adam_history = history
-        return hps
-    raise NotImplementedError(f"train(method={method!r}): only 'mcmc', 'adam', 'global' and 'local' run without Dask/HGDL")
+    elif method in ("hgdl", "bo"):
+        raise NotImplementedError(f"train(method={method!r}) needs HGDL / the BO surrogate loop, which are outside this "
+                                  "engine's scope: 'mcmc', 'adam', 'global', 'local' or a callable run here")
+    elif callable(method):
+        hps = method(gp)
+    else:
+        raise ValueError("No optimization mode specified in fvGP")
+    assert isinstance(hps, np.ndarray) and np.ndim(hps) == 1, "Optimizer returned invalid hyperparameters: " + str(hps)
+    return hps

@@ -63,3 +63,43 @@ def resolve(kernel_function):
             raise ValueError(f"unknown native kernel {kernel_function!r}; choose from {sorted(NATIVE)}")
         return NATIVE[kernel_function]
     return None
+
+
+# ---------------------------------------------------------------------------------------------
+# Building blocks for USER-WRITTEN host callables: code written against the reference's
+# `fvgp.kernels` helper names keeps working when its kernel is handed to fvgp_amd.GP as a Python callable (the host
+# slow path, N x N over PCIe).  The named kernels above never come through here -- they are assembled by fvgp_hip_kmat.
+# Formulas: fvgp/kernels.py:16-33 (squared exponential), :98-118 / :166-188 (Matern 3/2, 5/2), :440-481 (distances).
+# ---------------------------------------------------------------------------------------------
+def get_distance_matrix(x1, x2):
+    """Euclidean distances between the rows of x1 (U, D) and x2 (V, D) -> (U, V)."""
+    diff = np.asarray(x1, dtype=np.float64)[:, None, :] - np.asarray(x2, dtype=np.float64)[None, :, :]
+    return np.sqrt(np.einsum("uvd,uvd->uv", diff, diff))
+
+
+def get_anisotropic_distance_matrix(x1, x2, hps):
+    """Distances with one length scale per input dimension: sqrt(sum_k ((x1_k - x2_k) / hps_k)^2)."""
+    scale = np.asarray(hps, dtype=np.float64)[:np.shape(x1)[1]]
+    return get_distance_matrix(np.asarray(x1, dtype=np.float64) / scale, np.asarray(x2, dtype=np.float64) / scale)
+
+
+def squared_exponential_kernel(distance, length):
+    """exp(-distance^2 / (2 length^2))"""
+    return np.exp(-0.5 * (distance / length) ** 2)
+
+
+def exponential_kernel(distance, length):
+    """exp(-distance / length)"""
+    return np.exp(-distance / length)
+
+
+def matern_kernel_diff1(distance, length):
+    """Matern nu = 3/2: (1 + sqrt3 d/l) exp(-sqrt3 d/l)"""
+    s = np.sqrt(3.0) * distance / length
+    return (1.0 + s) * np.exp(-s)
+
+
+def matern_kernel_diff2(distance, length):
+    """Matern nu = 5/2: (1 + sqrt5 d/l + 5 d^2 / (3 l^2)) exp(-sqrt5 d/l)"""
+    s = np.sqrt(5.0) * distance / length
+    return (1.0 + s + s * s / 3.0) * np.exp(-s)

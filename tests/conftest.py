@@ -35,7 +35,7 @@ def synth(n, d, seed=20240501):
 # Parity evidence first, subprocess-spawning tests last: a failure (or a box limit) in the riskier files must
 # not keep the oracle / golden comparisons from running under `-x`.
 _ORDER = ["test_oracle_golden", "test_host_logic", "test_cpu_abi", "test_dist_cpu", "test_gpu_primitives", "test_gpu_facade",
-          "test_gpu_fullsize", "test_gpu_dist"]
+          "test_gpu_edge_cases", "test_gpu_fullsize", "test_gpu_dist"]
 
 
 def pytest_collection_modifyitems(config, items):

@@ -138,8 +138,35 @@ def test_mcmc_driver_on_a_toy_posterior():
     assert np.all(np.abs(res["median(x)"] - mu) < 0.1)
     assert res["max f(x)"] > -0.5
     assert np.all(res["x"] >= bounds[:, 0]) and np.all(res["x"] <= bounds[:, 1])
-    with pytest.raises(Exception, match="out of bounds"):
+    with pytest.raises(Exception, match="outside of optimization bounds"):            # gp_training.py:54-55
         gp_training.train(None, bounds, np.array([5.0, 1.0]))
+    with pytest.raises(ValueError, match="No optimization mode"):                      # gp_training.py:195
+        gp_training.train(None, bounds, np.array([1.0, 1.0]), method=42, objective_function=f)
+
+    class Holder:
+        pass
+    # a callable method gets the object and must hand back a 1-d ndarray (gp_training.py:194-196)
+    h = Holder()
+    np.testing.assert_array_equal(gp_training.train(h, bounds, np.array([1.0, 1.0]), method=lambda g: mu, objective_function=f), mu)
+    with pytest.raises(AssertionError, match="invalid hyperparameters"):
+        gp_training.train(h, bounds, np.array([1.0, 1.0]), method=lambda g: list(mu), objective_function=f)
+    # a log prior of -inf vetoes proposals without a likelihood call (gp_mcmc.py:203-209)
+    seen = []
+
+    def fcount(t):
+        seen.append(t.copy())
+        return f(t)
+    res = gp_training.run_mcmc(fcount, bounds, np.array([0.5, 2.0]), n_updates=400, rng=np.random.default_rng(4),
+                               prior=lambda t, box, args: 0.0 if (gp_training._in_bounds(t, box) and t[0] < 0.8) else -np.inf)
+    assert np.all(res["x"][:, 0] < 0.8) and all(t[0] < 0.8 for t in seen)
+    # a user objective with its gradient drives 'local' and 'adam'
+    g = lambda t: (t - mu) / 0.01
+    nf = lambda t: -f(t)
+    np.testing.assert_allclose(gp_training.train(h, bounds, np.array([3.0, 0.5]), method="local", objective_function=nf,
+                                                 objective_function_gradient=g, tolerance=1e-12), mu, atol=1e-6)
+    got = gp_training.train(h, bounds, np.array([1.2, 1.8]), method="adam", objective_function=nf,
+                            objective_function_gradient=g, max_iter=2000)
+    assert np.all(np.abs(got - mu) < 0.05) and len(h.adam_history["nlml"]) >= 1
 
 
 def test_training_drivers_walk_the_reference_traces():
@@ -186,3 +213,21 @@ def test_workspace_bytes_query(L):
     assert L.fvgp_hip_workspace_bytes(50000, 1000) > w50
     assert L.fvgp_hip_workspace_bytes(20000, 0) < w50
     assert L.fvgp_hip_workspace_bytes(0, 0) == -1 and L.fvgp_hip_workspace_bytes(10, -1) == -1
+
+
+def test_host_kernel_building_blocks_equal_the_oracles():
+    """fvgp_amd.kernels' helpers for user-written host callables against the oracle's restatement
+    of fvgp/kernels.py:16-33,98-118,166-188,440-481 -- same names, same values"""
+    from fvgp_amd import kernels
+    from oracle import fvgp_oracle as orc
+    rng = np.random.default_rng(5)
+    x1, x2 = rng.random((17, 3)), rng.random((9, 3))
+    ell = np.array([0.3, 1.7, 0.9])
+    np.testing.assert_allclose(kernels.get_distance_matrix(x1, x2), orc.get_distance_matrix(x1, x2), rtol=1e-14, atol=1e-15)
+    d = kernels.get_anisotropic_distance_matrix(x1, x2, ell)
+    np.testing.assert_allclose(d, orc.get_anisotropic_distance_matrix(x1, x2, ell), rtol=1e-14, atol=1e-15)
+    assert d.shape == (17, 9)
+    for name in ("squared_exponential_kernel", "matern_kernel_diff1", "matern_kernel_diff2"):
+        for length in (1.0, 0.37):
+            np.testing.assert_allclose(getattr(kernels, name)(d, length), getattr(orc, name)(d, length), rtol=1e-14)
+    np.testing.assert_allclose(kernels.exponential_kernel(d, 0.5), np.exp(-d / 0.5), rtol=1e-15)
