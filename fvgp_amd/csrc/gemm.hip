@@ -220,6 +220,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         fa[i] = AKM ? (q * LDM + wm * 64 + i * 16 + r) : ((wm * 64 + i * 16 + r) * LDK + q);
         fb[i] = BNM ? (q * LDM + wn * 64 + i * 16 + r) : ((wn * 64 + i * 16 + r) * LDK + q);
     }
+    // both operands k-minor: lane group q takes k = 4q .. 4q+3 of a K step instead of q, q+4, q+8, q+12 (the same
+    // permutation of the sum on both sides), so a pair of fragments is one 16-byte LDS read; probe 64 keeps the 8-byte reads
+    constexpr bool KPERM = !AKM && !BNM && !(DBG & 7) && DBG != 64;
+    if constexpr (KPERM) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[i] += 3 * q; fb[i] += 3 * q; }
+    }
     constexpr int SA = AKM ? 4 * LDM : 4;
     constexpr int SB = BNM ? 4 * LDM : 4;
 
@@ -260,6 +267,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         // the fragment reads and MFMAs of this wave go out at raised priority; the memory phase of the K step (global
         // loads above, LDS writes and barrier below) yields to the co-resident workgroup's MFMAs (+1.3 % on 8192^3)
         if (DBG != 8) __builtin_amdgcn_s_setprio(ROLE ? 1 : 2);
+        if constexpr (KPERM) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                double2_t a2[4], b2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a2[i] = *reinterpret_cast<const double2_t *>(pa + fa[i] + 2 * hf);
+                    b2[i] = *reinterpret_cast<const double2_t *>(pb + fb[i] + 2 * hf);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i][s], b2[j][s], acc[i][j], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             double a[4], bv[4];
@@ -273,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
+        }
         }
         if (DBG != 8) __builtin_amdgcn_s_setprio(ROLE ? 0 : 1);
         if (more && !(DBG & 1)) {
@@ -710,10 +736,10 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     dim3 grid((unsigned)g.ntiles), block(256);
     if (d.probe) {
         // timing probes of the K loop with parts of it removed (results are meaningless unless noted): 1 no global
-        // loads / LDS writes, 2 no barrier, 4 no LDS fragment reads, 8 the full loop without s_setprio (correct
-        // results) -- tools/gemm_probe.py
+        // loads / LDS writes, 2 no barrier, 4 no LDS fragment reads, 8 the full loop without s_setprio, 64 with 8-byte
+        // fragment reads in the plain k order (both with correct results) -- tools/gemm_probe.py
 #define PR(V) case V: hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 0, V>), grid, block, 0, h->stream, g); break
-        switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); PR(6); PR(7); PR(8); default: return -3; }
+        switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); PR(6); PR(7); PR(8); PR(64); default: return -3; }
 #undef PR
         HIPCHK(hipGetLastError());
         return 0;
