@@ -442,6 +442,50 @@ static int trsm_fwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl
     return 0;
 }
 
+// The same substitution on the TRANSPOSED right-hand sides: BT (rows x np, row-major, rows a multiple of 128) holds B^T and
+// leaves (L^-1 B)^T.  Every product is then the (M,K) x (N,K) layout of the factorisation's own panel TRSM and trailing
+// update -- X_k^T = B_k^T inv(L_kk)^T in place, BT[:, block] -= X^T L[block, k]^T -- i.e. the kernels with the 16-byte
+// fragment reads, and what follows (V^T V, row sums) reads contiguous rows.
+// LEFT-looking over the outer blocks: block J first receives everything to its left in one product,
+//     BT[:, J] -= BT[:, 0:J0] L[J, 0:J0]^T          (rows/128 x NB/128 output tiles, K = J0),
+// with K split over enough workgroups to fill the chip (deterministic two-pass reduction).  A right-looking sweep has
+// (rows/128) x (remaining blocks) tiles of K = NB per step instead: 1192, 1128, .. tiles on 512 slots lose a quarter of
+// the time to partly filled rounds (measured at N = 20k, P = 1000: 7.3 ms for 3.9e11 flops); here every launch is one round.
+static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt) {
+    const int64_t np = pad128(n), NB = h->outer_block;
+    int rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
+    for (int64_t J0 = 0; J0 < np; J0 += NB) {
+        const int64_t Jend = (J0 + NB < np) ? J0 + NB : np;
+        if (J0 > 0) {
+            GemmDesc u{};
+            u.a_kmajor = 0; u.b_nmajor = 0; u.lower = 0; u.M = rows; u.N = Jend - J0; u.K = J0; u.alpha = -1.0; u.beta = 1.0;
+            u.A = BT; u.lda = ldbt; u.B = L + J0 * ldl; u.ldb = ldl; u.C = BT + J0; u.ldc = ldbt;
+            const int64_t tiles = (u.M / TILE) * (u.N / TILE);
+            int64_t split = tiles >= 512 ? 1 : 512 / tiles;
+            const int64_t max_split = J0 / 512 > 0 ? J0 / 512 : 1;          // at least 512 of K per workgroup
+            if (split > max_split) split = max_split;
+            if (split > 1) {
+                rc = ensure_scratch(h, (split * u.M * u.N + 7) / 8); if (rc) return rc;
+                u.split = (int)split; u.split_ws = h->vec;
+            }
+            rc = launch_gemm(h, u); if (rc) return rc;
+        }
+        for (int64_t k0 = J0; k0 < Jend; k0 += TILE) {
+            GemmDesc d{};   // X_k^T = B_k^T inv(L_kk)^T, in place (a workgroup owns whole rows)
+            d.a_kmajor = 0; d.b_nmajor = 0; d.lower = 0; d.M = rows; d.N = TILE; d.K = TILE; d.alpha = 1.0; d.beta = 0.0;
+            d.A = BT + k0; d.lda = ldbt; d.B = h->linv + (k0 / TILE) * LEAF_DOUBLES; d.ldb = TILE; d.C = BT + k0; d.ldc = ldbt;
+            rc = launch_gemm(h, d); if (rc) return rc;
+            const int64_t r0 = k0 + TILE, R = Jend - r0;
+            if (R <= 0) continue;
+            GemmDesc u{};   // rest of the outer block: BT[:, r0:Jend] -= X_k^T L[r0:Jend, k]^T
+            u.a_kmajor = 0; u.b_nmajor = 0; u.lower = 0; u.M = rows; u.N = R; u.K = TILE; u.alpha = -1.0; u.beta = 1.0;
+            u.A = BT + k0; u.lda = ldbt; u.B = L + r0 * ldl + k0; u.ldb = ldl; u.C = BT + r0; u.ldc = ldbt;
+            rc = launch_gemm(h, u); if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
 // backward half, same two block sizes, from the last outer block to the first
 static int trsm_bwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t ncols, int64_t ldb) {
     const int64_t np = pad128(n), NB = h->outer_block;
@@ -813,7 +857,57 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
     HIPCHK(hipSetDevice(h->device));
     KmatDesc k{};
     rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &k); if (rc) return rc;
-    // cross covariance k(x_data, x_pred) (gp_prior.py:200-215), zero padding
+    const bool few = P <= 4;          // a handful of prediction points (acquisition-function optimisers ask for one at a
+                                      // time): vector sweeps instead of 128-wide GEMM tiles; measured break-even between 4 and 8
+    if (!few) {
+        // ---- the GEMM path works on the TRANSPOSED cross covariance k(x_pred, x_data), Pp x np with leading dimension np
+        //      in the caller's scratch: the substitution then runs on the factorisation's own (M,K) x (N,K) kernels
+        //      (trsm_fwd_gemm_t) and S -= V^T V is A A^T of contiguous rows
+        double *KT = kx;
+        k.x1 = xpred; k.n1 = P; k.x2 = x; k.n2 = n; k.vdiag = nullptr; k.K = KT; k.ldk = np; k.uplo = FVGP_FULL; k.pad = 2;
+        rc = launch_kmat(h, k); if (rc) return rc;
+        if (mean_out && ncol <= FVGP_MAX_RHS_VEC) {
+            rc = launch_rows_dot(h, KT, np, alpha, ncol, ncol, n, P, mean_out, ncol); if (rc) return rc;
+        } else if (mean_out) {
+            // many columns of y: GEMM with alpha widened to 128 columns in the handle scratch;
+            // the (Pp x 128) result goes to the tail of the same scratch
+            rc = ensure_scratch(h, np * 16 + Pp * 16); if (rc) return rc;
+            double *aw = h->vec;
+            rc = launch_copy_cols(h, alpha, ncol, aw, 128, np, ncol, np, 128); if (rc) return rc;
+            double *mw = h->vec + np * 128;
+            GemmDesc g{};
+            g.a_kmajor = 0; g.b_nmajor = 1; g.lower = 0; g.M = Pp; g.N = 128; g.K = np; g.alpha = 1.0; g.beta = 0.0;
+            g.A = KT; g.lda = np; g.B = aw; g.ldb = 128; g.C = mw; g.ldc = 128;
+            rc = launch_gemm(h, g); if (rc) return rc;
+            rc = launch_copy_cols(h, mw, 128, mean_out, ncol, P, ncol, P, ncol); if (rc) return rc;
+        }
+        if (var_out || S_out) {
+            rc = trsm_fwd_gemm_t(h, L, n, ldl, KT, Pp, np); if (rc) return rc;             // KT <- (L^-1 k)^T
+            if (S_out) {
+                KmatDesc kk = k;
+                kk.x1 = xpred; kk.n1 = P; kk.x2 = xpred; kk.n2 = P; kk.K = S_out; kk.ldk = lds; kk.uplo = FVGP_FULL; kk.pad = 2;
+                rc = launch_kmat(h, kk); if (rc) return rc;
+                GemmDesc g{};   // S -= V^T V = KT KT^T; few output tiles and K = np: split K so that the launch fills the chip
+                g.a_kmajor = 0; g.b_nmajor = 0; g.lower = 0; g.M = Pp; g.N = Pp; g.K = np; g.alpha = -1.0; g.beta = 1.0;
+                g.A = KT; g.lda = np; g.B = KT; g.ldb = np; g.C = S_out; g.ldc = lds;
+                const int64_t tiles = (Pp / TILE) * (Pp / TILE);
+                int64_t split = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
+                const int64_t max_split = np / 512 > 0 ? np / 512 : 1;       // at least 512 of K per workgroup
+                if (split > max_split) split = max_split;
+                if (split > 1) {
+                    rc = ensure_scratch(h, (split * Pp * Pp + 7) / 8); if (rc) return rc;
+                    g.split = (int)split; g.split_ws = h->vec;
+                }
+                rc = launch_gemm(h, g); if (rc) return rc;
+            }
+            if (var_out) {
+                // v_p = k(x_p,x_p) - |L^-1 k_p|^2 ; stationary kernels: k(x,x) = signal variance
+                rc = launch_rows_sumsq_base(h, KT, np, np, P, k.sig, var_out); if (rc) return rc;
+            }
+        }
+        return 0;
+    }
+    // ---- a few points: cross covariance k(x_data, x_pred) (gp_prior.py:200-215) in the (np x ldk) layout, zero padding
     k.x1 = x; k.n1 = n; k.x2 = xpred; k.n2 = P; k.vdiag = nullptr; k.K = kx; k.ldk = ldk; k.uplo = FVGP_FULL; k.pad = 2;
     rc = launch_kmat(h, k); if (rc) return rc;
     if (mean_out && ncol <= FVGP_MAX_RHS_VEC) {
@@ -821,8 +915,6 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
         rc = ensure_scratch(h, (kt_alpha_scratch_doubles(n, P, ncol) + 7) / 8); if (rc) return rc;
         rc = launch_kt_alpha(h, kx, ldk, alpha, ncol, ncol, n, P, h->vec, mean_out, ncol, 1.0, 0); if (rc) return rc;
     } else if (mean_out) {
-        // many columns of y: GEMM with alpha widened to 128 columns in the handle scratch;
-        // the (Pp x 128) result goes to the tail of the same scratch
         rc = ensure_scratch(h, np * 16 + Pp * 16); if (rc) return rc;
         double *aw = h->vec;
         rc = launch_copy_cols(h, alpha, ncol, aw, 128, np, ncol, np, 128); if (rc) return rc;
@@ -834,26 +926,16 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
         rc = launch_copy_cols(h, mw, 128, mean_out, ncol, P, ncol, P, ncol); if (rc) return rc;
     }
     if (var_out || S_out) {
-        const bool few = P <= 4;      // a handful of prediction points (acquisition-function optimisers ask for one at a
-                                      // time): vector sweeps instead of 128-wide GEMM tiles; measured break-even between 4 and 8
-        if (few) { rc = potrs_vec(h, L, n, ldl, kx, P, ldk, false); if (rc) return rc; }       // kx <- L^-1 k
-        else { rc = trsm_fwd_gemm(h, L, n, ldl, kx, Pp, ldk); if (rc) return rc; }
+        rc = potrs_vec(h, L, n, ldl, kx, P, ldk, false); if (rc) return rc;       // kx <- L^-1 k
         if (S_out) {
             KmatDesc kk = k;
             kk.x1 = xpred; kk.n1 = P; kk.x2 = xpred; kk.n2 = P; kk.K = S_out; kk.ldk = lds; kk.uplo = FVGP_FULL; kk.pad = 2;
             rc = launch_kmat(h, kk); if (rc) return rc;
-            if (few) {   // S -= V^T V as a streaming pass over V (P x P outputs)
-                rc = ensure_scratch(h, np + (kt_alpha_scratch_doubles(n, P, (int)P) + 7) / 8); if (rc) return rc;
-                rc = launch_kt_alpha(h, kx, ldk, kx, ldk, (int)P, n, P, h->vec + np * 8, S_out, lds, -1.0, 1); if (rc) return rc;
-            } else {
-                GemmDesc g{};
-                g.a_kmajor = 1; g.b_nmajor = 1; g.lower = 0; g.M = Pp; g.N = Pp; g.K = np; g.alpha = -1.0; g.beta = 1.0;
-                g.A = kx; g.lda = ldk; g.B = kx; g.ldb = ldk; g.C = S_out; g.ldc = lds;
-                rc = launch_gemm(h, g); if (rc) return rc;
-            }
+            // S -= V^T V as a streaming pass over V (P x P outputs)
+            rc = ensure_scratch(h, np + (kt_alpha_scratch_doubles(n, P, (int)P) + 7) / 8); if (rc) return rc;
+            rc = launch_kt_alpha(h, kx, ldk, kx, ldk, (int)P, n, P, h->vec + np * 8, S_out, lds, -1.0, 1); if (rc) return rc;
         }
         if (var_out) {
-            // v_p = k(x_p,x_p) - |L^-1 k_p|^2 ; stationary kernels: k(x,x) = signal variance
             rc = launch_colsumsq(h, kx, np, ldk, P, k.sig, var_out); if (rc) return rc;
         }
     }

@@ -101,6 +101,11 @@ struct GemmDesc {
     int probe = 0;                    // timing probe variant of the K loop (diagnostics only)
     int direct = 0;                   // (M,K) x (N,K) only: operands straight from global memory into MFMA registers (no LDS)
     int rev_m = 0;                    // walk the tile rows from the last to the first (per-tile K grows with ti: longest first)
+    // split-K for products with few output tiles and a long K (S -= V^T V of the posterior: 64 tiles, K = N): `split`
+    // workgroups per tile, each over K/split, partial tiles into split_ws (split x M x N doubles), then one fixed-order
+    // reduction into C -- the result does not depend on scheduling.  Plain K range only.
+    int split = 1;
+    double *split_ws = nullptr;
 };
 int launch_gemm(fvgp_handle *h, const GemmDesc &g);
 bool gemm_takes_small_tiles(const fvgp_handle *h, const GemmDesc &g);   // the launch runs gemm_f64_small_kernel, not gemm_f64_kernel
@@ -151,6 +156,12 @@ int launch_copy_cols(fvgp_handle *h, const double *src, int64_t lds, double *dst
                      int64_t rows_pad, int64_t cols_pad);
 int launch_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda);
 int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t P, double base, double *out);
+// row-wise twins for the transposed cross-covariance block KT (P x n, leading dimension ldk):
+// out[p][c] = sum_n KT[p][n] alpha[n][c]   and   out[p] = base - sum_n KT[p][n]^2
+int launch_rows_dot(fvgp_handle *h, const double *KT, int64_t ldk, const double *alpha, int64_t lda, int ncol, int64_t n, int64_t P,
+                    double *out, int64_t ldo);
+int launch_rows_sumsq_base(fvgp_handle *h, const double *KT, int64_t ldk, int64_t n, int64_t P, double base, double *out);
+int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M, int64_t N, int lower, double *C, int64_t ldc, double beta);
 int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D);
 int launch_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);
 int64_t kt_alpha_scratch_doubles(int64_t n, int64_t P, int ncol);

@@ -39,6 +39,7 @@ struct GemmArgs {
     long kb0, kbi, kbj, ke0, kei, kej;
     long ntiles;
     const int *tab;                   // balanced block -> tile table ((ti << 16) | tj, -1 = no tile), or nullptr: formula
+    long ksplit, csplit;              // split-K (gridDim.y > 1): block row y takes K elements [y ksplit, (y+1) ksplit), its tile goes to C + y csplit
 };
 
 // linear index -> (ti, tj).  Tiles are enumerated in super-tiles of 8 x SN (SN = min(8, tiles_n)),
@@ -179,6 +180,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     long kend = (g.ke0 < 0 ? g.K : g.ke0 + g.kei * ti + g.kej * tj);
     if (kbeg < 0) kbeg = 0;
     if (kend > g.K) kend = g.K;
+    if (g.ksplit) {
+        kbeg += (long)blockIdx.y * g.ksplit;
+        if (kbeg + g.ksplit < kend) kend = kbeg + g.ksplit;
+    }
     const int nk = kend > kbeg ? (int)((kend - kbeg) / BK) : 0;
 
     const long m0 = (long)ti * 128, n0 = (long)tj * 128;
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         if (!(DBG & 2)) __syncthreads();
     }
 
-    store_tile(acc, g.C + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
+    store_tile(acc, g.C + (long)blockIdx.y * g.csplit + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
 }
 
 // Small-tile variant for the latency-bound steps of the panel chain (TRSM by the inverted diagonal block, in-panel
@@ -724,7 +729,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     if ((d.bc_ranks > 1 || d.bc_off) && d.b_nmajor) { fvgp_set_error("gemm: block-cyclic B needs the (N, K) layout"); return -7; }
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
-    g.tab = nullptr;
+    g.tab = nullptr; g.ksplit = 0; g.csplit = 0;
     const bool plain_k = d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && d.kei == 0 && d.kej == 0;
     if (h->tile_tables && plain_k && !d.rev_m && !d.probe && g.tiles_m < 32768 && g.tiles_n < 32768 &&
         g.ntiles >= 64 && !gemm_takes_small_tiles(h, d)) {
@@ -734,6 +739,14 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     }
     if (g.ntiles == 0) return 0;
     dim3 grid((unsigned)g.ntiles), block(256);
+    const bool split = d.split > 1;
+    if (split) {
+        if (!plain_k || d.probe || d.rev_m || !d.split_ws) { fvgp_set_error("gemm: split-K needs a plain K range and a workspace"); return -3; }
+        const long steps = (d.K / BK + d.split - 1) / d.split;
+        g.ksplit = steps * BK; g.csplit = (long)d.M * d.N;
+        g.C = d.split_ws; g.ldc = d.N; g.beta = 0.0;
+        grid.y = (unsigned)d.split;
+    }
     if (d.probe) {
         // timing probes of the K loop with parts of it removed (results are meaningless unless noted): 1 no global
         // loads / LDS writes, 2 no barrier, 4 no LDS fragment reads, 8 the full loop without s_setprio, 64 with 8-byte
@@ -744,7 +757,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         HIPCHK(hipGetLastError());
         return 0;
     }
-    if (gemm_takes_small_tiles(h, d)) {             // too few 128-tiles to fill the chip (the panel chain's steps): 64-tiles
+    if (!split && gemm_takes_small_tiles(h, d)) {             // too few 128-tiles to fill the chip (the panel chain's steps): 64-tiles
         const long t128 = (long)g.tiles_m * g.tiles_n;
         const dim3 sg((unsigned)(t128 * 4));
         if (!d.b_nmajor) {
@@ -762,7 +775,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         return 0;
     }
     const bool direct_ = d.direct || h->gemm_direct >= 2 || (h->gemm_direct == 1 && d.role == 1);
-    if (direct_ && !d.probe && !d.a_kmajor && !d.b_nmajor && d.lda < (1L << 22) && d.ldb < (1L << 22)) {   // 64 rows of a wave within a 32-bit byte offset
+    if (direct_ && !split && !d.probe && !d.a_kmajor && !d.b_nmajor && d.lda < (1L << 22) && d.ldb < (1L << 22)) {   // 64 rows of a wave within a 32-bit byte offset
         if (d.role == 1) hipLaunchKernelGGL((gemm_f64_direct_kernel<1>), grid, block, 0, h->stream, g);
         else hipLaunchKernelGGL((gemm_f64_direct_kernel<0>), grid, block, 0, h->stream, g);
         HIPCHK(hipGetLastError());
@@ -776,5 +789,6 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     else GO(1, 1);
 #undef GO
     HIPCHK(hipGetLastError());
+    if (split) return launch_splitk_reduce(h, d.split_ws, d.split, d.M, d.N, d.lower, d.C, d.ldc, d.beta);
     return 0;
 }

@@ -214,6 +214,68 @@ __global__ void colsumsq_kernel(const double *V, long rows, long ldv, long P, do
     if (ty == 0 && p < P) { double t = 0.0; for (int k = 0; k < 8; ++k) t += sp[k][tx]; out[p] = base - t; }
 }
 
+// row-wise twins of the two kernels above for the transposed cross-covariance block KT (P x n): one workgroup per
+// prediction point streams its row (16-byte loads, coalesced), block sums in a fixed order
+template <int C>
+__global__ __launch_bounds__(256) void rows_dot_kernel(const double *KT, long ldk, const double *alpha, long lda, int ncol, long n,
+                                                       double *out, long ldo) {
+    __shared__ double sp[4][C];
+    const long p = blockIdx.x;
+    const double *row = KT + p * ldk;
+    double acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0;
+    for (long i = 2L * threadIdx.x; i < n; i += 512) {        // n is read up to the even index below it; the odd tail follows
+        if (i + 1 < n) {
+            const double2_t kv = *reinterpret_cast<const double2_t *>(row + i);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (c < ncol) acc[c] = fma(kv[1], alpha[(i + 1) * lda + c], fma(kv[0], alpha[i * lda + c], acc[c]));
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) if (c < ncol) acc[c] = fma(row[i], alpha[i * lda + c], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] += __shfl_down(acc[c], off, 64);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int c = 0; c < C; ++c) sp[threadIdx.x >> 6][c] = acc[c];
+    __syncthreads();
+    if (threadIdx.x < ncol) out[p * ldo + threadIdx.x] = (sp[0][threadIdx.x] + sp[1][threadIdx.x]) + (sp[2][threadIdx.x] + sp[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void rows_sumsq_base_kernel(const double *KT, long ldk, long n, double base, double *out) {
+    __shared__ double sp[4];
+    const long p = blockIdx.x;
+    const double *row = KT + p * ldk;
+    double s = 0.0;
+    for (long i = 2L * threadIdx.x; i < n; i += 512) {
+        if (i + 1 < n) { const double2_t v = *reinterpret_cast<const double2_t *>(row + i); s = fma(v[1], v[1], fma(v[0], v[0], s)); }
+        else s = fma(row[i], row[i], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sp[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[p] = base - ((sp[0] + sp[1]) + (sp[2] + sp[3]));
+}
+
+// C = beta C + sum over the splits of the partial products (alpha already applied), splits added in index order
+__global__ void splitk_reduce_kernel(const double *ws, int split, long M, long N, int lower, double *C, long ldc, double beta) {
+    const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (e >= M * N) return;
+    const long i = e / N, j = e - i * N;
+    if (lower && (j >> 7) > (i >> 7)) return;
+    double2_t s = *reinterpret_cast<const double2_t *>(ws + e);
+    for (int z = 1; z < split; ++z) { const double2_t t = *reinterpret_cast<const double2_t *>(ws + (long)z * M * N + e); s[0] += t[0]; s[1] += t[1]; }
+    double2_t *c = reinterpret_cast<double2_t *>(C + i * ldc + j);
+    if (beta != 0.0) { const double2_t o = *c; s[0] = fma(beta, o[0], s[0]); s[1] = fma(beta, o[1], s[1]); }
+    *c = s;
+}
+
 // posterior mean k^T alpha (gp_posterior.py:158) as a streaming pass over k: partial[chunk][p][c] = sum over the
 // chunk's rows n of K[n][p] * alpha[n][c]; a wave reads 512 contiguous bytes of a row per instruction.  Summed in a
 // fixed order by kt_alpha_reduce_kernel (no atomics: results do not depend on scheduling).
@@ -443,6 +505,34 @@ int launch_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda) {
 
 int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t P, double base, double *out) {
     hipLaunchKernelGGL(colsumsq_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, h->stream, V, (long)rows, (long)ldv, (long)P, base, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_dot(fvgp_handle *h, const double *KT, int64_t ldk, const double *alpha, int64_t lda, int ncol, int64_t n, int64_t P,
+                    double *out, int64_t ldo) {
+    if (ncol < 1 || ncol > 8) return -5;
+    if ((ldk & 1) || ((uintptr_t)KT & 15)) return -2;
+    const int C = ncol <= 1 ? 1 : ncol <= 2 ? 2 : ncol <= 4 ? 4 : 8;
+    dim3 grid((unsigned)P), block(256);
+#define GO(CC) hipLaunchKernelGGL((rows_dot_kernel<CC>), grid, block, 0, h->stream, KT, (long)ldk, alpha, (long)lda, ncol, (long)n, out, (long)ldo)
+    if (C == 1) GO(1); else if (C == 2) GO(2); else if (C == 4) GO(4); else GO(8);
+#undef GO
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_rows_sumsq_base(fvgp_handle *h, const double *KT, int64_t ldk, int64_t n, int64_t P, double base, double *out) {
+    if ((ldk & 1) || ((uintptr_t)KT & 15)) return -2;
+    hipLaunchKernelGGL(rows_sumsq_base_kernel, dim3((unsigned)P), dim3(256), 0, h->stream, KT, (long)ldk, (long)n, base, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M, int64_t N, int lower, double *C, int64_t ldc, double beta) {
+    const long pairs = (long)M * N / 2;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, ws, split, (long)M, (long)N, lower,
+                       C, (long)ldc, beta);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -177,7 +177,8 @@ int fvgp_hip_grad_trace(fvgp_handle *h, int kernel_id, const double *x, int64_t 
 
 /* posterior: GPposterior.posterior_mean / posterior_covariance  gp_posterior.py:139-182,229-288
  *   L: factor (padded), alpha: KVinvY (padded_dim(n), ncol)
- *   kx: scratch padded_dim(n) x ldk with ldk >= padded_dim(P); holds L^-1 k on return
+ *   kx: scratch of padded_dim(n) x ldk doubles with ldk >= padded_dim(P); contents unspecified on return (the cross
+ *       covariance and L^-1 k pass through it -- transposed, padded_dim(P) x padded_dim(n), when P > 4)
  *   mean_out (P, ncol) device  = k^T alpha          (prior mean added by the caller)
  *   S_out (padded_dim(P), lds) device or NULL  = kk - k^T KV^-1 k  (full, symmetric)
  *   var_out (P) device  = diag of the above (unclipped; clipping is gp_posterior.py:248-259, caller side) */
