@@ -22,8 +22,18 @@ int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred) {
     // inverted 128 x 128 diagonal blocks + per-leaf log-det partials + the solve / posterior scratch + reductions
     if (n <= 0 || npred < 0) return -1;
     const int64_t np = pad128(n), nblk = np / TILE, pp = pad128(npred);
-    const int64_t vec = np * 16 + pp * 16 > np * 8 ? np * 16 + pp * 16 : np * 8;      // posterior mean widening vs vector sweeps
-    return (nblk * LEAF_DOUBLES + nblk + (npred > 0 ? vec : np * 8) + RED_SLOTS) * (int64_t)sizeof(double) + (int64_t)sizeof(int);
+    int64_t vec = np * 16 + pp * 16 > np * 8 ? np * 16 + pp * 16 : np * 8;      // posterior mean widening vs vector sweeps
+    int64_t winv = 0;
+    if (npred > 4) {
+        // many-point posterior: inverted 1024-blocks (np x 1024), their doubling scratch (np x 256), one block of the
+        // transposed right-hand sides + its split-K partials, split-K partials of S -= V^T V
+        winv = np * 1024;
+        const int64_t tiles = (pp / TILE) * 8, want = tiles >= 512 ? 1 : 512 / tiles;
+        const int64_t stiles = (pp / TILE) * (pp / TILE), swant = stiles >= 512 ? 1 : (512 + stiles - 1) / stiles;
+        const int64_t cand[3] = {np * 256 + 1024, (1 + want) * pp * 1024 + 64, swant * pp * pp + 64};
+        for (int64_t c : cand) if (c > vec) vec = c;
+    }
+    return (nblk * LEAF_DOUBLES + nblk + (npred > 0 ? vec : np * 8) + winv + RED_SLOTS) * (int64_t)sizeof(double) + (int64_t)sizeof(int);
 }
 
 int64_t fvgp_hip_padded_dim(int64_t n) { return pad128(n); }
@@ -56,6 +66,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     gemm_release_tables(h);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->linv) (void)hipFree(h->linv);
+    if (h->winv) (void)hipFree(h->winv);
     if (h->logdet_parts) (void)hipFree(h->logdet_parts);
     if (h->red) (void)hipFree(h->red);
     if (h->dinfo) (void)hipFree(h->dinfo);
@@ -118,13 +129,14 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
         if (value != 0 && (value < 128 || value % 128)) { fvgp_set_error("inner_block must be 0 or a multiple of 128"); return -3; }
         h->inner_block = value; return 0;
     }
+    if (!strcmp(key, "block_inverses")) { h->block_inverses = value ? 1 : 0; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
     return -2;
 }
 
 int fvgp_hip_invalidate_factor(fvgp_handle *h) {
     if (!h) return -1;
-    h->linv_L = nullptr;
+    h->winv_ok = false; h->linv_L = nullptr;
     return 0;
 }
 
@@ -153,7 +165,7 @@ int fvgp_hip_get_profile(fvgp_handle *h, double *out) {
 static int ensure_blocks(fvgp_handle *h, int64_t nblk) {
     if ((size_t)nblk > h->linv_blocks) {
         if (h->linv) HIPCHK(hipFree(h->linv));
-        h->linv = nullptr; h->linv_blocks = 0; h->linv_L = nullptr;
+        h->linv = nullptr; h->linv_blocks = 0; h->winv_ok = false; h->linv_L = nullptr;
         HIPCHK(hipMalloc((void **)&h->linv, (size_t)nblk * LEAF_DOUBLES * sizeof(double)));
         h->linv_blocks = (size_t)nblk;
     }
@@ -185,7 +197,65 @@ int ensure_linv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl) {
     if (rc) return rc;
     rc = launch_leaf_inverse_batched(h, L, ldl, nblk, h->linv);
     if (rc) return rc;
-    h->linv_L = L; h->linv_n = n; h->linv_ld = ldl;
+    h->winv_ok = false; h->linv_L = L; h->linv_n = n; h->linv_ld = ldl;
+    return 0;
+}
+
+// inverses of the 1024 x 1024 diagonal blocks of L, from the 128-block inverses by doubling:
+//     inv [[A, 0], [C, B]] = [[inv A, 0], [-inv(B) C inv(A), inv B]]      at block sizes 128 -> 256 -> 512 -> 1024,
+// every level two strided-batch GEMM launches over all full 1024-blocks (T = C inv(A) into the handle scratch, then
+// -inv(B) T into place) plus single launches for the pairs of a narrower last block.  O(N 1024^2) flops, a few hundred
+// microseconds; kept until the factor changes.
+static int ensure_winv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl) {
+    int rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
+    if (h->winv_ok) return 0;
+    const int64_t np = pad128(n), nblk = np / TILE, WB = 1024;
+    const size_t need = (size_t)np * WB;
+    if (need > h->winv_cap) {
+        if (h->winv) HIPCHK(hipFree(h->winv));
+        h->winv = nullptr; h->winv_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->winv, need * sizeof(double)));
+        h->winv_cap = need;
+    }
+    double *W = h->winv;
+    rc = launch_winv_seed(h, h->linv, nblk, W); if (rc) return rc;
+    rc = ensure_scratch(h, np * 32 + 128); if (rc) return rc;          // T: at most np/2 x 512 doubles
+    double *T = h->vec;
+    const int64_t nfull = np / WB, t0 = nfull * WB, wt = np - t0;
+    for (int64_t hs = TILE; hs < WB; hs *= 2) {
+        const int64_t ny = WB / (2 * hs);
+        if (nfull > 0) {
+            GemmDesc a{};   // T[y, z] = C inv(A)
+            a.a_kmajor = 0; a.b_nmajor = 1; a.lower = 0; a.M = hs; a.N = hs; a.K = hs; a.alpha = 1.0; a.beta = 0.0;
+            a.A = L + hs * ldl; a.lda = ldl; a.B = W; a.ldb = WB; a.C = T; a.ldc = hs;
+            a.batch_y = (int)ny; a.batch_z = (int)nfull;
+            a.a_by = 2 * hs * ldl + 2 * hs; a.a_bz = WB * ldl + WB;
+            a.b_by = 2 * hs * WB + 2 * hs; a.b_bz = WB * WB;
+            a.c_by = hs * hs; a.c_bz = ny * hs * hs;
+            rc = launch_gemm(h, a); if (rc) return rc;
+            GemmDesc b{};   // W21[y, z] = -inv(B) T
+            b.a_kmajor = 0; b.b_nmajor = 1; b.lower = 0; b.M = hs; b.N = hs; b.K = hs; b.alpha = -1.0; b.beta = 0.0;
+            b.A = W + hs * WB + hs; b.lda = WB; b.B = T; b.ldb = hs; b.C = W + hs * WB; b.ldc = WB;
+            b.batch_y = (int)ny; b.batch_z = (int)nfull;
+            b.a_by = 2 * hs * WB + 2 * hs; b.a_bz = WB * WB;
+            b.b_by = hs * hs; b.b_bz = ny * hs * hs;
+            b.c_by = 2 * hs * WB + 2 * hs; b.c_bz = WB * WB;
+            rc = launch_gemm(h, b); if (rc) return rc;
+        }
+        double *Tt = T + nfull * ny * hs * hs;                           // the last, narrower block: its pairs one by one
+        for (int64_t s = 0; s + hs < wt; s += 2 * hs) {
+            const int64_t wb = (wt - s - hs < hs) ? wt - s - hs : hs;
+            GemmDesc a{};
+            a.a_kmajor = 0; a.b_nmajor = 1; a.lower = 0; a.M = wb; a.N = hs; a.K = hs; a.alpha = 1.0; a.beta = 0.0;
+            a.A = L + (t0 + s + hs) * ldl + t0 + s; a.lda = ldl; a.B = W + (t0 + s) * WB + s; a.ldb = WB; a.C = Tt; a.ldc = hs;
+            rc = launch_gemm(h, a); if (rc) return rc;
+            GemmDesc b{};
+            b.a_kmajor = 0; b.b_nmajor = 1; b.lower = 0; b.M = wb; b.N = hs; b.K = wb; b.alpha = -1.0; b.beta = 0.0;
+            b.A = W + (t0 + s + hs) * WB + s + hs; b.lda = WB; b.B = Tt; b.ldb = hs; b.C = W + (t0 + s + hs) * WB + s; b.ldc = WB;
+            rc = launch_gemm(h, b); if (rc) return rc;
+        }
+    }
+    h->winv_ok = true;
     return 0;
 }
 
@@ -286,7 +356,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     const int64_t np = pad128(n), nblk = np / TILE;
     int rc = ensure_blocks(h, nblk);
     if (rc) return rc;
-    h->linv_L = nullptr;
+    h->winv_ok = false; h->linv_L = nullptr;
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
     const int64_t NB = h->outer_block;
     size_t nev = 0;
@@ -360,7 +430,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     }
     if (enqueue_only) {          // no host round trip: info stays on the device, nothing is timed
         if (info_dev) HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-        h->linv_L = A; h->linv_n = n; h->linv_ld = lda;
+        h->winv_ok = false; h->linv_L = A; h->linv_n = n; h->linv_ld = lda;
         return 0;
     }
     if (h->profile) { rc = get_event(&e_end); if (rc) return rc; HIPCHK(hipEventRecord(e_end, h->stream)); }
@@ -370,7 +440,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     int info = *hinfo;
     if (info > n) info = 0;   // cannot happen: the padding is an identity block
     if (info_host) *info_host = info;
-    h->linv_L = A; h->linv_n = n; h->linv_ld = lda;
+    h->winv_ok = false; h->linv_L = A; h->linv_n = n; h->linv_ld = lda;
     if (h->profile) {
         h->prof_launches = 0; h->prof_ms = 0; h->prof_flops = 0;
         for (size_t i = 0; i < h->ev_flops.size(); ++i) {
@@ -446,29 +516,49 @@ static int trsm_fwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl
 // leaves (L^-1 B)^T.  Every product is then the (M,K) x (N,K) layout of the factorisation's own panel TRSM and trailing
 // update -- X_k^T = B_k^T inv(L_kk)^T in place, BT[:, block] -= X^T L[block, k]^T -- i.e. the kernels with the 16-byte
 // fragment reads, and what follows (V^T V, row sums) reads contiguous rows.
+// The block itself is then ONE product with the inverse of its 1024 x 1024 diagonal block (ensure_winv) instead of eight
+// 128-steps of two latency-bound launches each.
 // LEFT-looking over the outer blocks: block J first receives everything to its left in one product,
 //     BT[:, J] -= BT[:, 0:J0] L[J, 0:J0]^T          (rows/128 x NB/128 output tiles, K = J0),
 // with K split over enough workgroups to fill the chip (deterministic two-pass reduction).  A right-looking sweep has
 // (rows/128) x (remaining blocks) tiles of K = NB per step instead: 1192, 1128, .. tiles on 512 slots lose a quarter of
 // the time to partly filled rounds (measured at N = 20k, P = 1000: 7.3 ms for 3.9e11 flops); here every launch is one round.
 static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt) {
-    const int64_t np = pad128(n), NB = h->outer_block;
-    int rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
+    const int64_t np = pad128(n), NB = 1024;
+    const bool winv = h->block_inverses != 0;
+    int rc = winv ? ensure_winv(h, L, n, ldl) : ensure_linv(h, L, n, ldl); if (rc) return rc;
+    // scratch: tmp (rows x NB: block J with everything to its left applied) and the split-K partials behind it
+    const int64_t tiles = (rows / TILE) * (NB / TILE);
+    const int64_t want = tiles >= 512 ? 1 : 512 / tiles;                  // workgroups per output tile that fill the chip
+    const int64_t tmp_d = rows * NB, ws_d = want * rows * NB;
+    rc = ensure_scratch(h, (tmp_d + ws_d + 7) / 8); if (rc) return rc;
+    double *tmp = h->vec, *ws = h->vec + tmp_d;
     for (int64_t J0 = 0; J0 < np; J0 += NB) {
-        const int64_t Jend = (J0 + NB < np) ? J0 + NB : np;
+        const int64_t Jend = (J0 + NB < np) ? J0 + NB : np, w = Jend - J0;
+        bool in_tmp = false;
         if (J0 > 0) {
             GemmDesc u{};
-            u.a_kmajor = 0; u.b_nmajor = 0; u.lower = 0; u.M = rows; u.N = Jend - J0; u.K = J0; u.alpha = -1.0; u.beta = 1.0;
+            u.a_kmajor = 0; u.b_nmajor = 0; u.lower = 0; u.M = rows; u.N = w; u.K = J0; u.alpha = -1.0; u.beta = 1.0;
             u.A = BT; u.lda = ldbt; u.B = L + J0 * ldl; u.ldb = ldl; u.C = BT + J0; u.ldc = ldbt;
-            const int64_t tiles = (u.M / TILE) * (u.N / TILE);
-            int64_t split = tiles >= 512 ? 1 : 512 / tiles;
+            int64_t split = want;
             const int64_t max_split = J0 / 512 > 0 ? J0 / 512 : 1;          // at least 512 of K per workgroup
             if (split > max_split) split = max_split;
             if (split > 1) {
-                rc = ensure_scratch(h, (split * u.M * u.N + 7) / 8); if (rc) return rc;
-                u.split = (int)split; u.split_ws = h->vec;
+                u.split = (int)split; u.split_ws = ws;
+                if (winv) { u.split_out = tmp; u.split_ldo = w; in_tmp = true; }   // the reduction drops the block where the next product reads it
             }
             rc = launch_gemm(h, u); if (rc) return rc;
+        }
+        if (winv) {
+            if (!in_tmp) { rc = launch_copy_cols(h, BT + J0, ldbt, tmp, w, rows, w, rows, w); if (rc) return rc; }
+            GemmDesc d{};   // X_J^T = B_J^T inv(L_JJ)^T
+            d.a_kmajor = 0; d.b_nmajor = 0; d.lower = 0; d.M = rows; d.N = w; d.K = w; d.alpha = 1.0; d.beta = 0.0;
+            d.A = tmp; d.lda = w; d.B = h->winv + J0 * 1024; d.ldb = 1024; d.C = BT + J0; d.ldc = ldbt;
+            int64_t split = want;
+            if (split > w / TILE) split = w / TILE;
+            if (split > 1) { d.split = (int)split; d.split_ws = ws; }
+            rc = launch_gemm(h, d); if (rc) return rc;
+            continue;
         }
         for (int64_t k0 = J0; k0 < Jend; k0 += TILE) {
             GemmDesc d{};   // X_k^T = B_k^T inv(L_kk)^T, in place (a workgroup owns whole rows)
@@ -609,7 +699,7 @@ int fvgp_hip_panel_potrf_dev(fvgp_handle *h, double *T, int64_t w, int64_t rows,
     HIPCHK(hipSetDevice(h->device));
     int rc = ensure_blocks(h, w / TILE);
     if (rc) return rc;
-    h->linv_L = nullptr;
+    h->winv_ok = false; h->linv_L = nullptr;
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
     rc = panel_factor_nested(h, T, n_valid, rows, ldt, 0, w);   // leaf / TRSM of every row below / in-panel update per 128 columns, in sub-panels of `inner_block`
     if (rc) return rc;
@@ -719,7 +809,7 @@ int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *wo
     s.kb0 = 0; s.kbi = TILE; s.kbj = 0; s.ke0 = -1;
     rc = launch_gemm(h, s); if (rc) return rc;
     rc = launch_copy_lower_tiles(h, work, ldw, L, ldl, np); if (rc) return rc;
-    h->linv_L = nullptr;   // L is gone
+    h->winv_ok = false; h->linv_L = nullptr;   // L is gone
     return 0;
 }
 

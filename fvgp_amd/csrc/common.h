@@ -34,6 +34,13 @@ struct fvgp_handle {
     size_t linv_blocks = 0;
     const double *linv_L = nullptr;   // which factor they belong to
     int64_t linv_n = 0, linv_ld = 0;
+    // inverses of the 1024 x 1024 diagonal blocks of the same factor (block J in rows [1024 J, ..) of an np x 1024 array),
+    // built on demand from the 128-block inverses by doubling (ensure_winv) for the many-right-hand-side forward
+    // substitution of the posterior; dropped whenever the 128-block inverses change owner
+    double *winv = nullptr;
+    size_t winv_cap = 0;
+    bool winv_ok = false;
+    int block_inverses = 1;           // option: 0 = the posterior substitution walks the 128-blocks instead
     // per-leaf sum(log L_ii), device
     double *logdet_parts = nullptr;
     size_t logdet_cap = 0;
@@ -106,6 +113,11 @@ struct GemmDesc {
     // reduction into C -- the result does not depend on scheduling.  Plain K range only.
     int split = 1;
     double *split_ws = nullptr;
+    double *split_out = nullptr; int64_t split_ldo = 0;   // the reduced result beta C + sum goes here instead of over C
+    // strided batch of equal problems: problem (y, z), y < batch_y, z < batch_z, takes A + y a_by + z a_bz, B + .., C + ..
+    // (elements).  Excludes split-K.
+    int batch_y = 1, batch_z = 1;
+    int64_t a_by = 0, a_bz = 0, b_by = 0, b_bz = 0, c_by = 0, c_bz = 0;
 };
 int launch_gemm(fvgp_handle *h, const GemmDesc &g);
 bool gemm_takes_small_tiles(const fvgp_handle *h, const GemmDesc &g);   // the launch runs gemm_f64_small_kernel, not gemm_f64_kernel
@@ -161,7 +173,9 @@ int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, 
 int launch_rows_dot(fvgp_handle *h, const double *KT, int64_t ldk, const double *alpha, int64_t lda, int ncol, int64_t n, int64_t P,
                     double *out, int64_t ldo);
 int launch_rows_sumsq_base(fvgp_handle *h, const double *KT, int64_t ldk, int64_t n, int64_t P, double base, double *out);
-int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M, int64_t N, int lower, double *C, int64_t ldc, double beta);
+int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M, int64_t N, int lower, const double *C, int64_t ldc, double beta,
+                         double *out, int64_t ldo);
+int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W);
 int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D);
 int launch_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);
 int64_t kt_alpha_scratch_doubles(int64_t n, int64_t P, int ncol);

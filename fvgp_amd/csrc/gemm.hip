@@ -40,6 +40,8 @@ struct GemmArgs {
     long ntiles;
     const int *tab;                   // balanced block -> tile table ((ti << 16) | tj, -1 = no tile), or nullptr: formula
     long ksplit, csplit;              // split-K (gridDim.y > 1): block row y takes K elements [y ksplit, (y+1) ksplit), its tile goes to C + y csplit
+    int ny;                           // strided batch (ksplit == 0, gridDim.y > 1): problem (y, z) = (blockIdx.y % ny, blockIdx.y / ny)
+    long ab1, ab2, bb1, bb2, cb1, cb2;   // takes its operands at A + y ab1 + z ab2, B + .., C + ..
 };
 
 // linear index -> (ti, tj).  Tiles are enumerated in super-tiles of 8 x SN (SN = min(8, tiles_n)),
@@ -180,9 +182,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     long kend = (g.ke0 < 0 ? g.K : g.ke0 + g.kei * ti + g.kej * tj);
     if (kbeg < 0) kbeg = 0;
     if (kend > g.K) kend = g.K;
+    long coff = 0;
+    const double *gA = g.A, *gB = g.B;
     if (g.ksplit) {
         kbeg += (long)blockIdx.y * g.ksplit;
         if (kbeg + g.ksplit < kend) kend = kbeg + g.ksplit;
+        coff = (long)blockIdx.y * g.csplit;
+    } else if (g.ny) {
+        const long y = blockIdx.y % g.ny, z = blockIdx.y / g.ny;
+        gA += y * g.ab1 + z * g.ab2; gB += y * g.bb1 + z * g.bb2; coff = y * g.cb1 + z * g.cb2;
     }
     const int nk = kend > kbeg ? (int)((kend - kbeg) / BK) : 0;
 
@@ -198,20 +206,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     for (int p = 0; p < 4; ++p) {
         if (AKM) {           // A stored (K, M): rows of 128 contiguous m
             int kr = p * 4 + (tid >> 6), mc = (tid & 63) * 2;
-            ga[p] = g.A + (kbeg + kr) * g.lda + m0 + mc;
+            ga[p] = gA + (kbeg + kr) * g.lda + m0 + mc;
             sa[p] = kr * LDM + mc;
         } else {             // A stored (M, K): rows of 16 contiguous k
             int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
-            ga[p] = g.A + (m0 + row) * g.lda + kbeg + kc;
+            ga[p] = gA + (m0 + row) * g.lda + kbeg + kc;
             sa[p] = row * LDK + kc;
         }
         if (BNM) {           // B stored (K, N)
             int kr = p * 4 + (tid >> 6), nc = (tid & 63) * 2;
-            gb[p] = g.B + (kbeg + kr) * g.ldb + n0 + nc;
+            gb[p] = gB + (kbeg + kr) * g.ldb + n0 + nc;
             sb[p] = kr * LDM + nc;
         } else {             // B stored (N, K)
             int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
-            gb[p] = g.B + (nb0 + row) * g.ldb + kbeg + kc;
+            gb[p] = gB + (nb0 + row) * g.ldb + kbeg + kc;
             sb[p] = row * LDK + kc;
         }
     }
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         if (!(DBG & 2)) __syncthreads();
     }
 
-    store_tile(acc, g.C + (long)blockIdx.y * g.csplit + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
+    store_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
 }
 
 // Small-tile variant for the latency-bound steps of the panel chain (TRSM by the inverted diagonal block, in-panel
@@ -730,6 +738,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
     g.tab = nullptr; g.ksplit = 0; g.csplit = 0;
+    g.ny = 0; g.ab1 = g.ab2 = g.bb1 = g.bb2 = g.cb1 = g.cb2 = 0;
     const bool plain_k = d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && d.kei == 0 && d.kej == 0;
     if (h->tile_tables && plain_k && !d.rev_m && !d.probe && g.tiles_m < 32768 && g.tiles_n < 32768 &&
         g.ntiles >= 64 && !gemm_takes_small_tiles(h, d)) {
@@ -747,6 +756,12 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         g.C = d.split_ws; g.ldc = d.N; g.beta = 0.0;
         grid.y = (unsigned)d.split;
     }
+    const bool batched = (long)d.batch_y * d.batch_z > 1;
+    if (batched) {
+        if (split || d.probe || d.batch_y < 1 || d.batch_z < 1) { fvgp_set_error("gemm: a strided batch excludes split-K and probes"); return -3; }
+        g.ny = d.batch_y; g.ab1 = d.a_by; g.ab2 = d.a_bz; g.bb1 = d.b_by; g.bb2 = d.b_bz; g.cb1 = d.c_by; g.cb2 = d.c_bz;
+        grid.y = (unsigned)(d.batch_y * d.batch_z);
+    }
     if (d.probe) {
         // timing probes of the K loop with parts of it removed (results are meaningless unless noted): 1 no global
         // loads / LDS writes, 2 no barrier, 4 no LDS fragment reads, 8 the full loop without s_setprio, 64 with 8-byte
@@ -757,7 +772,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         HIPCHK(hipGetLastError());
         return 0;
     }
-    if (!split && gemm_takes_small_tiles(h, d)) {             // too few 128-tiles to fill the chip (the panel chain's steps): 64-tiles
+    if (!split && !batched && gemm_takes_small_tiles(h, d)) {             // too few 128-tiles to fill the chip (the panel chain's steps): 64-tiles
         const long t128 = (long)g.tiles_m * g.tiles_n;
         const dim3 sg((unsigned)(t128 * 4));
         if (!d.b_nmajor) {
@@ -775,7 +790,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         return 0;
     }
     const bool direct_ = d.direct || h->gemm_direct >= 2 || (h->gemm_direct == 1 && d.role == 1);
-    if (direct_ && !split && !d.probe && !d.a_kmajor && !d.b_nmajor && d.lda < (1L << 22) && d.ldb < (1L << 22)) {   // 64 rows of a wave within a 32-bit byte offset
+    if (direct_ && !split && !batched && !d.probe && !d.a_kmajor && !d.b_nmajor && d.lda < (1L << 22) && d.ldb < (1L << 22)) {   // 64 rows of a wave within a 32-bit byte offset
         if (d.role == 1) hipLaunchKernelGGL((gemm_f64_direct_kernel<1>), grid, block, 0, h->stream, g);
         else hipLaunchKernelGGL((gemm_f64_direct_kernel<0>), grid, block, 0, h->stream, g);
         HIPCHK(hipGetLastError());
@@ -789,6 +804,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     else GO(1, 1);
 #undef GO
     HIPCHK(hipGetLastError());
-    if (split) return launch_splitk_reduce(h, d.split_ws, d.split, d.M, d.N, d.lower, d.C, d.ldc, d.beta);
+    if (split) return launch_splitk_reduce(h, d.split_ws, d.split, d.M, d.N, d.lower, d.C, d.ldc, d.beta,
+                                           d.split_out ? d.split_out : d.C, d.split_out ? d.split_ldo : d.ldc);
     return 0;
 }

@@ -264,16 +264,34 @@ __global__ __launch_bounds__(256) void rows_sumsq_base_kernel(const double *KT, 
 }
 
 // C = beta C + sum over the splits of the partial products (alpha already applied), splits added in index order
-__global__ void splitk_reduce_kernel(const double *ws, int split, long M, long N, int lower, double *C, long ldc, double beta) {
+__global__ void splitk_reduce_kernel(const double *ws, int split, long M, long N, int lower, const double *C, long ldc, double beta,
+                                     double *out, long ldo) {
     const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (e >= M * N) return;
     const long i = e / N, j = e - i * N;
     if (lower && (j >> 7) > (i >> 7)) return;
     double2_t s = *reinterpret_cast<const double2_t *>(ws + e);
     for (int z = 1; z < split; ++z) { const double2_t t = *reinterpret_cast<const double2_t *>(ws + (long)z * M * N + e); s[0] += t[0]; s[1] += t[1]; }
-    double2_t *c = reinterpret_cast<double2_t *>(C + i * ldc + j);
-    if (beta != 0.0) { const double2_t o = *c; s[0] = fma(beta, o[0], s[0]); s[1] = fma(beta, o[1], s[1]); }
-    *c = s;
+    if (beta != 0.0) {
+        const double2_t o = *reinterpret_cast<const double2_t *>(C + i * ldc + j);
+        s[0] = fma(beta, o[0], s[0]); s[1] = fma(beta, o[1], s[1]);
+    }
+    *reinterpret_cast<double2_t *>(out + i * ldo + j) = s;
+}
+
+// seed of the 1024-block inverses: block row b (128 x 1024) of W <- zeros, with inv(L_bb) at its place on the diagonal of
+// the 1024-block the row belongs to
+__global__ __launch_bounds__(256) void winv_seed_kernel(const double *linv, double *W) {
+    const long b = blockIdx.x;
+    const int c0 = (int)(b & 7) * 128;
+    const double *src = linv + b * 128 * 128;
+    double *dst = W + b * 128 * 1024;
+    for (int e = threadIdx.x * 2; e < 128 * 1024; e += 512) {
+        const int i = e >> 10, j = e & 1023;
+        double2_t v = {0.0, 0.0};
+        if (j >= c0 && j < c0 + 128) v = *reinterpret_cast<const double2_t *>(src + i * 128 + (j - c0));
+        *reinterpret_cast<double2_t *>(dst + e) = v;
+    }
 }
 
 // posterior mean k^T alpha (gp_posterior.py:158) as a streaming pass over k: partial[chunk][p][c] = sum over the
@@ -529,10 +547,18 @@ int launch_rows_sumsq_base(fvgp_handle *h, const double *KT, int64_t ldk, int64_
     return 0;
 }
 
-int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M, int64_t N, int lower, double *C, int64_t ldc, double beta) {
+int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M, int64_t N, int lower, const double *C, int64_t ldc, double beta,
+                         double *out, int64_t ldo) {
     const long pairs = (long)M * N / 2;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, ws, split, (long)M, (long)N, lower,
-                       C, (long)ldc, beta);
+                       C, (long)ldc, beta, out, (long)ldo);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W) {
+    if (nblk <= 0) return 0;
+    hipLaunchKernelGGL(winv_seed_kernel, dim3((unsigned)nblk), dim3(256), 0, h->stream, linv, W);
     HIPCHK(hipGetLastError());
     return 0;
 }

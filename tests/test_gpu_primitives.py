@@ -426,3 +426,37 @@ def test_panel_potrf_dev_tall_panel(H, w, extra, n_valid):
     np.testing.assert_allclose(float(ld.item()), 2 * np.log(np.diag(L)[:n_valid]).sum(), rtol=1e-12)
     if extra:
         np.testing.assert_allclose(got[w:], sla.solve_triangular(L, Pm.T, lower=True).T, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("n,P", [(2700, 300), (1024, 130), (3200, 5)])
+def test_posterior_block_inverse_substitution(H, n, P):
+    """The many-point posterior substitutes with the inverted 1024 x 1024 diagonal blocks (doubling from the 128-block
+    inverses; n = 2700 leaves a last block of 5 x 128, n = 1024 a single full one): against the oracle's cho_solve
+    (gp_posterior.py:120-136,229-288) and against the 128-step substitution (option block_inverses = 0)."""
+    from fvgp_amd import _lib
+    x, y = synth(n, 3)
+    nv = np.full(n, 0.01)
+    theta = np.array([1.3, 0.35, 0.3, 0.4])
+    ref = orc.OracleGP(x, y, theta, noise_variances=nv, kernel="rbf_ard")
+    xp = np.random.default_rng(5).random((P, 3))
+    want_m = ref.posterior_mean(xp)["m(x)"]
+    want_S = ref.posterior_covariance(xp)["S"]
+    npad, Pp = _lib.pad128(n), _lib.pad128(P)
+    xd, vd = H.to_device(x), H.to_device(nv)
+    ymd = H.to_device((y - np.mean(y)).reshape(n, 1))
+    KV = H.empty(npad, npad); alpha = H.empty(npad, 1)
+    H.loglik(0, xd, theta, vd, ymd, KV, alpha)
+    got = {}
+    for mode in (1, 0):
+        H.set_option("block_inverses", mode)
+        kx = H.empty(npad, Pp); mean = H.empty(P, 1); var = H.empty(P); S = H.empty(Pp, Pp)
+        H.posterior(0, xd, theta, KV, alpha, 1, H.to_device(xp), kx, mean, var, S)
+        H.sync()
+        got[mode] = (mean.cpu().numpy()[:, 0] + np.mean(y), S.cpu().numpy()[:P, :P], var.cpu().numpy())
+    H.set_option("block_inverses", 1)
+    for mode in (1, 0):
+        m, S, v = got[mode]
+        np.testing.assert_allclose(m, want_m, rtol=1e-8, atol=1e-9)
+        assert np.max(np.abs(S - want_S)) < 1e-10 * theta[0] + 1e-12
+        assert np.max(np.abs(v - np.diag(want_S))) < 1e-10 * theta[0] + 1e-12
+    assert np.max(np.abs(got[1][1] - got[0][1])) < 1e-11 * theta[0]
