@@ -129,6 +129,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
         if (value != 0 && (value < 128 || value % 128)) { fvgp_set_error("inner_block must be 0 or a multiple of 128"); return -3; }
         h->inner_block = value; return 0;
     }
+    if (!strcmp(key, "k128_kernels")) { h->k128_kernels = value ? 1 : 0; return 0; }
     if (!strcmp(key, "block_inverses")) { h->block_inverses = value ? 1 : 0; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
     return -2;

@@ -40,6 +40,7 @@ struct fvgp_handle {
     double *winv = nullptr;
     size_t winv_cap = 0;
     bool winv_ok = false;
+    int k128_kernels = 1;             // option: K = 128 products of the panel chain fetch their operands in one stage
     int block_inverses = 1;           // option: 0 = the posterior substitution walks the 128-blocks instead
     // per-leaf sum(log L_ii), device
     double *logdet_parts = nullptr;

@@ -453,6 +453,86 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
                 cbase[(i * 16 + 4 * v) * g.ldc + j * 16] = alpha * acc[i][j][v] + (beta != 0.0 ? beta * old[i][v][j] : 0.0);
 }
 
+// K = 128 in ONE stage, for the two products every 128-column step of the panel chain waits for (TRSM by the inverted
+// diagonal block, update of the next block column): the whole k range of both operands is fetched at once -- every load
+// of the workgroup in flight together -- instead of eight double-buffered steps of one memory round trip each (the
+// steps are latency, not bandwidth: these launches have a few hundred workgroups).  (M,K) x (N,K) layout, k-minor images
+// with a row stride of 130 doubles (16-byte fragment reads of the permuted k order, conflict-free).  A workgroup owns 32
+// rows: its A image stays, the B rows pass through in TN / 32 phases of 32 (the next phase's loads fly during the MFMAs),
+// a wave computes one 16 x 16 tile per phase.  67 KB of LDS -- like the leaf, it must fit into what one retiring
+// trailing-update workgroup frees.  <64>: results that alias no operand; <128>: the in-place TRSM (the workgroup has read
+// all of its rows before it writes them).
+template <int TN>
+__global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
+    constexpr int LDS_ = 130, NPH = TN / 32, TM = 32;
+    __shared__ double sA[TM * LDS_];
+    __shared__ double sB[32 * LDS_];
+    const int tn = (g.tiles_n * 128) / TN;
+    const int ti = blockIdx.x / tn, tj = blockIdx.x % tn;
+    const long m0 = (long)ti * TM, n0 = (long)tj * TN;
+    if (g.lower == 1 && n0 / 128 > m0 / 128) return;
+    if (g.lower == 2 && n0 / 128 > (m0 / 128) * g.ls + g.lo) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+    const int idx = (int)(n0 / 128) + g.bco;                            // B rows in all-gather (block-cyclic) order
+    const long nb0 = ((long)(idx % g.bcr) * g.bcb + idx / g.bcr) * 128 + n0 % 128;
+
+    // one wave reads one row of 128 doubles per pass
+    constexpr int PP = 8;
+    double2_t ra[PP], rb[PP];
+    const int lrow = wave, kc = lane * 2;
+#pragma unroll
+    for (int p = 0; p < PP; ++p) ra[p] = *reinterpret_cast<const double2_t *>(g.A + (m0 + p * 4 + lrow) * g.lda + kc);
+#pragma unroll
+    for (int p = 0; p < PP; ++p) rb[p] = *reinterpret_cast<const double2_t *>(g.B + (nb0 + p * 4 + lrow) * g.ldb + kc);
+    double *cbase = g.C + (m0 + wm * 16 + q) * g.ldc + n0 + wn * 16 + r;
+    double old[NPH][4];
+    if (g.beta != 0.0) {
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) old[ph][v] = cbase[(4 * v) * g.ldc + ph * 32];
+    }
+#pragma unroll
+    for (int p = 0; p < PP; ++p) *reinterpret_cast<double2_t *>(&sA[(p * 4 + lrow) * LDS_ + kc]) = ra[p];
+    double4_t acc[NPH];
+    const double *pa = &sA[(wm * 16 + r) * LDS_ + 4 * q];
+    const double *pb = &sB[(wn * 16 + r) * LDS_ + 4 * q];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+#pragma unroll
+        for (int p = 0; p < PP; ++p) *reinterpret_cast<double2_t *>(&sB[(p * 4 + lrow) * LDS_ + kc]) = rb[p];
+        __syncthreads();
+        if (ph + 1 < NPH) {                                             // the next 32 rows of B are on their way during the MFMAs
+#pragma unroll
+            for (int p = 0; p < PP; ++p)
+                rb[p] = *reinterpret_cast<const double2_t *>(g.B + (nb0 + (ph + 1) * 32 + p * 4 + lrow) * g.ldb + kc);
+        }
+        // two accumulators per tile (even / odd halves of the k range): the MFMAs of a tile do not wait for each other
+        double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const double2_t a0 = *reinterpret_cast<const double2_t *>(pa + kb * 16);
+            const double2_t a1 = *reinterpret_cast<const double2_t *>(pa + kb * 16 + 2);
+            const double2_t b0 = *reinterpret_cast<const double2_t *>(pb + kb * 16);
+            const double2_t b1 = *reinterpret_cast<const double2_t *>(pb + kb * 16 + 2);
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[1], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[1], c1, 0, 0, 0);
+        }
+        acc[ph] = c0 + c1;
+        if (ph + 1 < NPH) __syncthreads();                              // everybody is done with this B image
+    }
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            cbase[(4 * v) * g.ldc + ph * 32] = alpha * acc[ph][v] + (beta != 0.0 ? beta * old[ph][v] : 0.0);
+}
+
 // a wave-uniform pointer moved into SGPRs (readfirstlane returns int: widen each half as UNSIGNED)
 __device__ __forceinline__ const double *uniform_ptr(const double *p) {
     const uintptr_t v = (uintptr_t)p;
@@ -776,10 +856,14 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         const long t128 = (long)g.tiles_m * g.tiles_n;
         const dim3 sg((unsigned)(t128 * 4));
         if (!d.b_nmajor) {
-            if ((const double *)d.C == d.A || (const double *)d.C == d.B)         // in place: a workgroup owns whole rows
-                hipLaunchKernelGGL((gemm_f64_small_kernel<32, 128, 0>), sg, block, 0, h->stream, g);
-            else
-                hipLaunchKernelGGL((gemm_f64_small_kernel<64, 64, 0>), sg, block, 0, h->stream, g);
+            const bool one_stage = d.K == 128 && h->k128_kernels;
+            if ((const double *)d.C == d.A || (const double *)d.C == d.B) {       // in place: a workgroup owns whole rows
+                if (one_stage) hipLaunchKernelGGL((gemm_f64_k128_kernel<128>), sg, block, 0, h->stream, g);
+                else hipLaunchKernelGGL((gemm_f64_small_kernel<32, 128, 0>), sg, block, 0, h->stream, g);
+            } else {
+                if (one_stage) hipLaunchKernelGGL((gemm_f64_k128_kernel<64>), dim3((unsigned)(t128 * 8)), block, 0, h->stream, g);
+                else hipLaunchKernelGGL((gemm_f64_small_kernel<64, 64, 0>), sg, block, 0, h->stream, g);
+            }
         } else {
             if ((const double *)d.C == d.B)                                        // in place of B (K, N), K == M: whole columns
                 hipLaunchKernelGGL((gemm_f64_small_kernel<128, 32, 1>), sg, block, 0, h->stream, g);

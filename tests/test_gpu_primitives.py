@@ -72,6 +72,40 @@ def test_gemm_layouts(H, akm, bnm, lower):
         assert np.max(np.abs(got - ref) / scale) < 8 * EPS
 
 
+@pytest.mark.parametrize("one_stage", [1, 0])
+@pytest.mark.parametrize("lower", [0, 1])
+def test_gemm_k128_chain_products(H, lower, one_stage):
+    """The two K = 128 products of a panel-chain step on the small-tile kernels (one-stage fetch or eight double-buffered
+    steps): the block-column update C -= A B^T, and the TRSM X = A inv(L)^T written over A."""
+    rng = np.random.default_rng(20 + lower)
+    H.set_option("k128_kernels", one_stage)
+    try:
+        M, N, K = 640, 384 if not lower else 640, 128
+        a = rng.standard_normal((M, K)); b = rng.standard_normal((N, K)); C0 = rng.standard_normal((M, N))
+        C = H.to_device(C0)
+        H.gemm(0, 0, lower, M, N, K, -1.0, H.to_device(a), H.to_device(b), 1.0, C)
+        H.sync()
+        got, ref, scale = C.cpu().numpy(), C0 - a @ b.T, np.abs(a) @ np.abs(b.T) + np.abs(C0)
+        for ti in range(M // 128):
+            for tj in range(N // 128):
+                sl = (slice(ti * 128, ti * 128 + 128), slice(tj * 128, tj * 128 + 128))
+                if not lower or tj <= ti:
+                    assert np.max(np.abs(got[sl] - ref[sl]) / scale[sl]) < 8 * EPS
+                else:
+                    assert np.array_equal(got[sl], C0[sl]), "tile above the diagonal must be untouched"
+        # in place: A (M x 128 inside a wider buffer) <- A inv^T
+        wide = rng.standard_normal((M, 512)); inv = np.tril(rng.standard_normal((128, 128)))
+        W = H.to_device(wide)
+        H.gemm(0, 0, 0, M, 128, 128, 1.0, W[:, 128:256], H.to_device(inv), 0.0, W[:, 128:256])
+        H.sync()
+        out = W.cpu().numpy()
+        want = wide[:, 128:256] @ inv.T
+        assert np.max(np.abs(out[:, 128:256] - want) / (np.abs(wide[:, 128:256]) @ np.abs(inv.T))) < 8 * EPS
+        assert np.array_equal(out[:, :128], wide[:, :128]) and np.array_equal(out[:, 256:], wide[:, 256:])
+    finally:
+        H.set_option("k128_kernels", 1)
+
+
 def test_gemm_beta_zero_and_big_k(H):
     rng = np.random.default_rng(3)
     M, N, K = 128, 128, 2048
