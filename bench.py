@@ -217,6 +217,16 @@ def sharded_main(args, x, y, world, rank, local, dist):
             os._exit(3)                # a hung collective is a failed run: the launcher must see it
 
     threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        return _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d)
+    finally:
+        done.set()
+
+
+def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d):
+    import torch
+    from fvgp_amd import _lib
+    from fvgp_amd.dist import ShardedGP
     gp = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=args.outer_block or 1024,
                    rank=rank if dist is not None else 0, world=world if dist is not None else 1)
     for t in range(args.warmup):
@@ -286,7 +296,6 @@ def sharded_main(args, x, y, world, rank, local, dist):
                                  f"{len(thetas)} per GPU, outside the timed region"},
         }
         print(json.dumps(out), flush=True)
-    done.set()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -337,8 +346,20 @@ def main():
 
     n, d = args.n, args.d
     x, y = synth(n, d)
+    sharded_error = None
     if args.mode == "sharded" or (args.mode == "auto" and world > 1):
-        return sharded_main(args, x, y, world, rank, local, dist)
+        try:
+            return sharded_main(args, x, y, world, rank, local, dist)
+        except Exception as e:              # noqa: BLE001 -- an exception (not a hang: the watchdog owns those) on the sharded path
+            if args.mode == "sharded" or dist is None:
+                raise
+            # the same code runs on every rank, so every rank lands here: the run still reports the replicas record
+            # (independent evaluations, no data-path collective) and says what happened to the sharded one
+            import traceback
+            traceback.print_exc()
+            sharded_error = f"{type(e).__name__}: {e}"
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
     H = _lib.Handle(local)
     if args.outer_block:
         H.set_option("outer_block", args.outer_block)
@@ -435,6 +456,9 @@ def main():
         if not args.no_cpu_baseline:                                # the CPU leg is timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_sample_n)
     if rank == 0:
+        if sharded_error is not None:
+            out["sharded_error"] = ("the row-sharded evaluation raised on this node, the line reports the replicas instead: "
+                                    + sharded_error)[:600]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

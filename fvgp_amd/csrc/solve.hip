@@ -87,29 +87,40 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const double *L, long ldl
     }
 }
 
+// One block step of the backward sweep.  A step is a chain of dependent memory round trips (y_k, the diagonal inverse, the
+// row panel), not bandwidth, so each phase has ALL its loads in flight at once: the 128 x 128 inverse as 64 loads per thread,
+// the row panel with the 128 rows split over the four waves (32 loads per thread, two columns each) and the four partial
+// sums combined through LDS -- three round trips per step instead of thirteen.  Workgroup b owns columns [128 b, 128 b + 128).
 template <int C>
 __global__ __launch_bounds__(256) void bwd_step_kernel(const double *L, long ldl, long np, long k0, const double *linv,
                                                        double *Yres, double *X, long ldx, int c_used) {
     __shared__ double sy[128 * C];
     __shared__ double sxv[2][128 * C];
-    const int tid = threadIdx.x;
+    __shared__ double sp[4][128 * C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the row panel does not depend on x: its loads go out first and fly during the x phase
+    const long c2 = (long)blockIdx.x * 128 + 2 * lane;
+    const bool have = c2 < k0;
+    double2_t l2[32];
+    if (have) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) l2[u] = *reinterpret_cast<const double2_t *>(L + (k0 + wave * 32 + u) * ldl + c2);
+    }
     for (int e = tid; e < 128 * C; e += 256) sy[e] = Yres[k0 * C + e];
-    __syncthreads();
-    // x = Linv^T y : thread (i, half) walks half of column i of Linv (coalesced across i), 16 loads in flight
+    // x = Linv^T y : thread (i, half) walks half of column i of Linv (coalesced across i)
     {
         const int i = tid & 127, half = tid >> 7;
+        double l[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) l[u] = linv[(half * 64 + u) * 128 + i];      // Linv[j][i] = 0 for j < i
+        __syncthreads();
         double acc[C];
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) acc[cc] = 0.0;
-        for (int j0 = half * 64; j0 < half * 64 + 64; j0 += 16) {
-            double l[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) l[u] = linv[(j0 + u) * 128 + i];      // Linv[j][i] = 0 for j < i
+        for (int u = 0; u < 64; ++u)
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-#pragma unroll
-                for (int cc = 0; cc < C; ++cc) acc[cc] = fma(l[u], sy[(j0 + u) * C + cc], acc[cc]);
-        }
+            for (int cc = 0; cc < C; ++cc) acc[cc] = fma(l[u], sy[(half * 64 + u) * C + cc], acc[cc]);
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) sxv[half][i * C + cc] = acc[cc];
     }
@@ -122,25 +133,26 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const double *L, long ldl
             if (cc < c_used) X[(k0 + i) * ldx + cc] = sxv[0][e];
         }
     }
-    // columns to the left: thread owns 2 adjacent columns and walks the 128 rows, 16 loads in flight
-    for (long c2 = ((long)blockIdx.x * 256 + tid) * 2; c2 < k0; c2 += (long)gridDim.x * 512) {
-        double a0[C], a1[C];
+    // columns to the left: this wave's 32 rows of the panel times x, two adjacent columns per lane
+    double a0[C], a1[C];
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) { a0[cc] = 0.0; a1[cc] = 0.0; }
-        for (int r0 = 0; r0 < 128; r0 += 16) {
-            double2_t l2[16];
+    for (int cc = 0; cc < C; ++cc) { a0[cc] = 0.0; a1[cc] = 0.0; }
+    if (have) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) l2[u] = *reinterpret_cast<const double2_t *>(L + (k0 + r0 + u) * ldl + c2);
+        for (int u = 0; u < 32; ++u)
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+            for (int cc = 0; cc < C; ++cc) {
+                const double xv = sxv[0][(wave * 32 + u) * C + cc];
+                a0[cc] = fma(l2[u][0], xv, a0[cc]);
+                a1[cc] = fma(l2[u][1], xv, a1[cc]);
+            }
+    }
 #pragma unroll
-                for (int cc = 0; cc < C; ++cc) {
-                    a0[cc] = fma(l2[u][0], sxv[0][(r0 + u) * C + cc], a0[cc]);
-                    a1[cc] = fma(l2[u][1], sxv[0][(r0 + u) * C + cc], a1[cc]);
-                }
-        }
-#pragma unroll
-        for (int cc = 0; cc < C; ++cc) { Yres[c2 * C + cc] -= a0[cc]; Yres[(c2 + 1) * C + cc] -= a1[cc]; }
+    for (int cc = 0; cc < C; ++cc) { sp[wave][(2 * lane) * C + cc] = a0[cc]; sp[wave][(2 * lane + 1) * C + cc] = a1[cc]; }
+    __syncthreads();
+    for (int e = tid; e < 128 * C; e += 256) {
+        const long col = (long)blockIdx.x * 128 + e / C;
+        if (col < k0) Yres[(long)blockIdx.x * 128 * C + e] -= (sp[0][e] + sp[1][e]) + (sp[2][e] + sp[3][e]);
     }
 }
 
@@ -471,7 +483,7 @@ int launch_fwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, in
 
 template <int C>
 static int bwd_go(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv, double *Yres, double *X, int64_t ldx, int c) {
-    long blocks = k0 > 0 ? (k0 + 511) / 512 : 1;     // 2 columns per thread
+    long blocks = k0 > 0 ? k0 / 128 : 1;             // one workgroup per 128 columns to the left (k0 is a multiple of 128)
     hipLaunchKernelGGL((bwd_step_kernel<C>), dim3((unsigned)blocks), dim3(256), 0, h->stream, L, (long)ldl, (long)np, (long)k0, linv, Yres, X, (long)ldx, c);
     return 0;
 }
