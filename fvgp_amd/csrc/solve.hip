@@ -27,31 +27,42 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const double *L, long ldl
                                                        double *B, long ldb, double *Y, int c_used) {
     __shared__ double sb[128 * C];
     __shared__ double sy[128 * C];
-    constexpr int R = 8;                       // rows in flight per wave
+    constexpr int R = 8;                       // rows below in flight per wave and pass
+    constexpr int RY = 16;                     // rows of the diagonal inverse in flight per wave and pass
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // like the backward step, a chain of memory round trips: the first pass over the rows below does not depend on y, so
+    // its loads go out before anything else
+    const long r0 = k0 + 128;
+    const long stride = (long)gridDim.x * 4 * R;
+    const long rb0 = r0 + ((long)blockIdx.x * 4 + wave) * R;
+    double2_t lf[R];
+    if (rb0 < np) {
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) lf[rr] = *reinterpret_cast<const double2_t *>(L + (rb0 + rr) * ldl + k0 + 2 * lane);
+    }
     for (int e = tid; e < 128 * C; e += 256) {
         const int i = e / C, cc = e - i * C;
         sb[e] = cc < c_used ? B[(k0 + i) * ldb + cc] : 0.0;
     }
     __syncthreads();
-    // y = Linv * b : wave handles 32 rows, 8 at a time; lanes hold 2 columns each
+    // y = Linv * b : wave handles 32 rows, 16 at a time; lanes hold 2 columns each
     {
         double b0[C], b1[C];
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) { b0[cc] = sb[(2 * lane) * C + cc]; b1[cc] = sb[(2 * lane + 1) * C + cc]; }
-        for (int i0 = wave * 32; i0 < wave * 32 + 32; i0 += R) {
-            double2_t l2[R];
+        for (int i0 = wave * 32; i0 < wave * 32 + 32; i0 += RY) {
+            double2_t l2[RY];
 #pragma unroll
-            for (int rr = 0; rr < R; ++rr) l2[rr] = *reinterpret_cast<const double2_t *>(linv + (i0 + rr) * 128 + 2 * lane);
-            double acc[R][C];
+            for (int rr = 0; rr < RY; ++rr) l2[rr] = *reinterpret_cast<const double2_t *>(linv + (i0 + rr) * 128 + 2 * lane);
+            double acc[RY][C];
 #pragma unroll
-            for (int rr = 0; rr < R; ++rr)
+            for (int rr = 0; rr < RY; ++rr)
 #pragma unroll
                 for (int cc = 0; cc < C; ++cc) acc[rr][cc] = l2[rr][0] * b0[cc] + l2[rr][1] * b1[cc];
-            wave_reduce<C, R>(acc);
+            wave_reduce<C, RY>(acc);
             if (lane == 0)
 #pragma unroll
-                for (int rr = 0; rr < R; ++rr)
+                for (int rr = 0; rr < RY; ++rr)
 #pragma unroll
                     for (int cc = 0; cc < C; ++cc) sy[(i0 + rr) * C + cc] = acc[rr][cc];
         }
@@ -67,12 +78,11 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const double *L, long ldl
     double y0[C], y1[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) { y0[cc] = sy[(2 * lane) * C + cc]; y1[cc] = sy[(2 * lane + 1) * C + cc]; }
-    const long r0 = k0 + 128;
-    const long stride = (long)gridDim.x * 4 * R;
-    for (long rb = r0 + ((long)blockIdx.x * 4 + wave) * R; rb < np; rb += stride) {   // np - r0 is a multiple of 128
+    for (long rb = rb0; rb < np; rb += stride) {   // np - r0 is a multiple of 128
         double2_t l2[R];
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) l2[rr] = *reinterpret_cast<const double2_t *>(L + (rb + rr) * ldl + k0 + 2 * lane);
+        for (int rr = 0; rr < R; ++rr)
+            l2[rr] = rb == rb0 ? lf[rr] : *reinterpret_cast<const double2_t *>(L + (rb + rr) * ldl + k0 + 2 * lane);
         double acc[R][C];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr)
