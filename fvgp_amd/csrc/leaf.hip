@@ -18,8 +18,10 @@
 // Algorithm (16-wide blocks):
 //   for p = 0..7:  TRSM of the rows below by per-row forward substitution against L_pp;
 //                  trailing tiles C_ij -= X_i X_j^T on fp64 MFMA 16x16x4; wave 0 takes tile
-//                  (p+1,p+1) first and factors it (lane-broadcast left-looking Cholesky, Newton
-//                  reciprocal square roots) while the other waves finish the update.
+//                  (p+1,p+1) first and factors it while the other waves finish the update: four-column
+//                  panels whose 4x4 diagonal block is factored as wave-uniform scalars (Newton reciprocal
+//                  square roots), the rows under it solved per lane group, and ONE rank-4 MFMA update of the
+//                  rest of the tile per panel (PanelBlock).
 //   inverse:       wave j owns block column j of inv(L):  X_jj = inv(L_jj),
 //                  X_ij = -inv(L_ii) * sum_{k=j..i-1} L_ik X_kj.  The f64 MFMA accumulator layout
 //                  (row = q+4v) is exactly the next MFMA's B-operand layout, so the whole column
@@ -71,33 +73,6 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return y;
 }
 
-template <int J>
-struct Col {
-    // column J of the factorisation, lane `row` holds row `row` of the tile in a[]; right-looking: a[c], c > J, already carries A[row][c] - sum_{k<J} L[row][k] L[c][k]; once column J is final it
-    // is applied to the later columns at once (independent FMAs)
-    static __device__ __forceinline__ void step(double (&a)[16], double (&rd)[16], int row, int &bad) {
-        const double dj = bcast<J>(a[J]);
-        if (!(dj > 0.0) && bad < 0) bad = J;
-        const double y = rsqrt_nr(dj);
-        double piv = dj * y;
-        piv = fma(fma(-piv, piv, dj), 0.5 * y, piv);
-        rd[J] = y;
-        const double lj = (row == J) ? piv : (row > J ? a[J] * y : 0.0);
-        a[J] = lj;
-        Later<J + 1>::apply(a, lj);
-        if constexpr (J < 15) Col<J + 1>::step(a, rd, row, bad);
-    }
-    template <int C>
-    struct Later {
-        static __device__ __forceinline__ void apply(double (&a)[16], double lj) {
-            if constexpr (C < 16) {
-                a[C] = fma(-lj, bcast<C>(lj), a[C]);
-                Later<C + 1>::apply(a, lj);
-            }
-        }
-    };
-};
-
 template <int I>
 struct InvRow {
     // row I of inv(tile): lane c holds column c of the inverse in x[]
@@ -110,21 +85,91 @@ struct InvRow {
     }
 };
 
+// the 16-lane block BLK of v in all four blocks of the wave (two gfx950 row swaps per 32-bit half)
+template <int BLK>
+__device__ __forceinline__ double bcast_block(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto l1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // [0] = blocks (0,0,2,2), [1] = (1,1,3,3)
+    const auto h1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const unsigned l = (BLK & 1) ? l1[1] : l1[0], h = (BLK & 1) ? h1[1] : h1[0];
+    const auto l2 = __builtin_amdgcn_permlane32_swap(l, l, false, false);        // [0] = lower half twice, [1] = upper half twice
+    const auto h2 = __builtin_amdgcn_permlane32_swap(h, h, false, false);
+    return __hiloint2double((BLK & 2) ? h2[1] : h2[0], (BLK & 2) ? l2[1] : l2[0]);
+}
+
+// sqrt(d) from d and y ~ 1/sqrt(d): one correction step on top of d y
+__device__ __forceinline__ double sqrt_from(double d, double y) {
+    const double p = d * y;
+    return fma(fma(-p, p, d), 0.5 * y, p);
+}
+
+// Four-column block B of a 16x16 tile.  The tile is kept as the full symmetric matrix in the MFMA accumulator layout, lane
+// (r, q) holds D[q + 4v][r] = D[r][q + 4v], so accumulator slot B of lane (r, q) IS the panel entry (row r, panel column q).
+//   1. the 4x4 diagonal block is factored as wave-uniform scalars (its ten entries by readlane): the pivot chain -- four
+//      reciprocal square roots in sequence -- waits for nothing else;
+//   2. every row of the panel is solved against it, column c in lane group c; a finished column reaches the other lane
+//      groups by two gfx950 row swaps per 32-bit half (bcast_block);
+//   3. the factored panel is both operands of ONE rank-4 MFMA update of the rest of the tile.
+// (The first version swept 16 columns with 15 - J broadcast-and-FMA updates behind each pivot: 7.4k cycles per tile.)
+template <int B>
+struct PanelBlock {
+    static __device__ __forceinline__ void step(double4_t &acc, double *sT, double &ykeep, int r, int q, int lane, int &bad) {
+        constexpr int R0 = 4 * B;
+        const bool above = r < R0 + q;                        // finished rows, and the 4x4 block above its diagonal
+        const double x = above ? 0.0 : acc[B];
+        const double d00 = bcast<R0>(x), d10 = bcast<R0 + 1>(x), d20 = bcast<R0 + 2>(x), d30 = bcast<R0 + 3>(x);
+        const double d11 = bcast<16 + R0 + 1>(x), d21 = bcast<16 + R0 + 2>(x), d31 = bcast<16 + R0 + 3>(x);
+        const double d22 = bcast<32 + R0 + 2>(x), d32 = bcast<32 + R0 + 3>(x);
+        const double d33 = bcast<48 + R0 + 3>(x);
+        if (!(d00 > 0.0) && bad < 0) bad = R0;
+        const double y0 = rsqrt_nr(d00);
+        const double l10 = d10 * y0, l20 = d20 * y0, l30 = d30 * y0;
+        const double e11 = fma(-l10, l10, d11);
+        if (!(e11 > 0.0) && bad < 0) bad = R0 + 1;
+        const double y1 = rsqrt_nr(e11);
+        const double l21 = fma(-l20, l10, d21) * y1, l31 = fma(-l30, l10, d31) * y1;
+        const double e22 = fma(-l21, l21, fma(-l20, l20, d22));
+        if (!(e22 > 0.0) && bad < 0) bad = R0 + 2;
+        const double y2 = rsqrt_nr(e22);
+        const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * y2;
+        const double e33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
+        if (!(e33 > 0.0) && bad < 0) bad = R0 + 3;
+        const double y3 = rsqrt_nr(e33);
+        // rows of the panel: x_c = (raw_c - sum_{k<c} x_k L[c][k]) y_c, valid in lane group c
+        const double x0 = x * y0;
+        const double X0 = bcast_block<0>(x0);
+        const double x1 = fma(-X0, l10, x) * y1;
+        const double X1 = bcast_block<1>(x1);
+        const double x2 = fma(-X1, l21, fma(-X0, l20, x)) * y2;
+        const double X2 = bcast_block<2>(x2);
+        const double x3 = fma(-X2, l32, fma(-X1, l31, fma(-X0, l30, x))) * y3;
+        const bool g0 = q == 0, g1 = q == 1, g2 = q == 2;
+        double xf = g0 ? x0 : (g1 ? x1 : (g2 ? x2 : x3));
+        // the diagonal entries with one correction step (on this lane group's pivot), zeros above them
+        const double eq = g0 ? d00 : (g1 ? e11 : (g2 ? e22 : e33));
+        const double yq = g0 ? y0 : (g1 ? y1 : (g2 ? y2 : y3));
+        const double pd = sqrt_from(eq, yq);
+        if (r == R0 + q) { xf = pd; ykeep = yq; }            // lane (r, q = r mod 4) keeps 1 / L_rr
+        if (above) xf = 0.0;
+        if (r >= R0 + q) sT[el(r, R0 + q)] = xf;
+        if constexpr (B < 3) {
+            acc = mfma(-xf, xf, acc);
+            PanelBlock<B + 1>::step(acc, sT, ykeep, r, q, lane, bad);
+        }
+    }
+};
+
 // one wave: Cholesky of the 16x16 tile at sT (lower part), in place; 1/diag -> srd[0..15]
 // returns the first bad pivot column or -1
 __device__ __forceinline__ int diag_factor(double *sT, double *srd, int lane) {
-    const int row = lane & 15;
-    double a[16], rd[16];
+    const int r = lane & 15, q = lane >> 4;
+    double4_t acc;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = (k <= row) ? sT[el(row, k)] : 0.0;
+    for (int v = 0; v < 4; ++v) { const int i = q + 4 * v; acc[v] = (i >= r) ? sT[el(i, r)] : sT[el(r, i)]; }
     int bad = -1;
-    Col<0>::step(a, rd, row, bad);
-    if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) if (k <= row) sT[el(row, k)] = a[k];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) if (k == row) srd[k] = rd[k];
-    }
+    double ykeep = 0.0;
+    PanelBlock<0>::step(acc, sT, ykeep, r, q, lane, bad);
+    if (q == (r & 3)) srd[r] = ykeep;
     return bad;
 }
 
