@@ -272,11 +272,19 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
             __syncthreads();
             FVGP_STAMP();
         }
-        // ---- L back to global (lower triangle only) and the log-diagonal sum ---------------------------
-        for (int e = tid; e < 128 * 128; e += 512) {
-            const int row = e >> 7, col = e & 127;
-            if (col <= row) A[(long)row * g.lda + col] = sT[tix(row >> 4, col >> 4) + el(row & 15, col & 15)];
+        // ---- L back to global (lower triangle only), tile by tile: a wave's store covers four 128-byte row segments ----
+        for (int t = wave; t < NT; t += 8) {
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            const int tj = t - ti * (ti + 1) / 2;
+            const double *T = &sT[t * TSZ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int a = 4 * u + q;
+                if (ti != tj || r <= a) A[(long)(16 * ti + a) * g.lda + 16 * tj + r] = T[el(a, r)];
+            }
         }
+        // ---- the log-diagonal sum ------------------------------------------------------------------------------------
         if (g.logdet_part != nullptr) {
             double s = 0.0;
             if (tid < g.nvalid) s = -log(srd[tid]);
@@ -325,24 +333,33 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
         for (int m = 1; m < 8; ++m) {
             const int i = j + m;
             if (i < 8) {
-                double4_t t4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < m; ++kk) {
-                    const double *Lik = &sT[tix(i, j + kk)];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) t4 = mfma(Lik[el(r, 4 * s + q)], xb[kk][s], t4);
-                }
+                // two accumulators per product: consecutive MFMAs never wait for each other's result
                 const double *Dii = &sT[tix(i, i)];
-                double4_t x4 = {0.0, 0.0, 0.0, 0.0};
+                double dd[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int cc = 4 * s + q;                       // inv(L_ii)[r][cc]
                     double d = 0.0;
                     if (r > cc) d = Dii[el(cc, r)];
                     else if (r == cc) d = srd[16 * i + r];
-                    x4 = mfma(-d, t4[s], x4);
+                    dd[s] = -d;
                 }
-                xb[m] = x4;
+                double4_t ta = {0.0, 0.0, 0.0, 0.0}, tb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < m; ++kk) {
+                    const double *Lik = &sT[tix(i, j + kk)];
+                    ta = mfma(Lik[el(r, q)], xb[kk][0], ta);
+                    tb = mfma(Lik[el(r, 4 + q)], xb[kk][1], tb);
+                    ta = mfma(Lik[el(r, 8 + q)], xb[kk][2], ta);
+                    tb = mfma(Lik[el(r, 12 + q)], xb[kk][3], tb);
+                }
+                const double4_t t4 = ta + tb;
+                double4_t xa = {0.0, 0.0, 0.0, 0.0}, xc = {0.0, 0.0, 0.0, 0.0};
+                xa = mfma(dd[0], t4[0], xa);
+                xc = mfma(dd[1], t4[1], xc);
+                xa = mfma(dd[2], t4[2], xa);
+                xc = mfma(dd[3], t4[3], xc);
+                xb[m] = xa + xc;
             } else {
                 xb[m] = (double4_t){0.0, 0.0, 0.0, 0.0};
             }
