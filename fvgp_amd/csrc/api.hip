@@ -129,6 +129,8 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
         if (value != 0 && (value < 128 || value % 128)) { fvgp_set_error("inner_block must be 0 or a multiple of 128"); return -3; }
         h->inner_block = value; return 0;
     }
+    if (!strcmp(key, "leaf_tiles")) { h->leaf_tiles = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "leaf_tiles_rows")) { h->leaf_tiles_rows = value; return 0; }
     if (!strcmp(key, "k128_kernels")) { h->k128_kernels = value ? 1 : 0; return 0; }
     if (!strcmp(key, "block_inverses")) { h->block_inverses = value ? 1 : 0; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
@@ -276,20 +278,29 @@ static int panel_factor(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_
     for (int64_t k0 = J0; k0 < Jend; k0 += TILE) {
         const int64_t kb = k0 / TILE;
         const int64_t nv = n - k0;
-        rc = launch_leaf(h, A + k0 * lda + k0, lda, h->linv + kb * LEAF_DOUBLES, h->logdet_parts + kb, (int)k0, 1,
-                         nv >= TILE ? TILE : (nv > 0 ? (int)nv : 0));
-        if (rc) return rc;
         const int64_t r0 = k0 + TILE, R = np - r0;
+        // few rows below = the chain is what the factorisation waits for: the leaf then skips the triangular inverse of its
+        // block (19 of 103 thousand cycles) and the TRSM substitutes with the 16 x 16 tile inverses; with many rows the
+        // product with the full inverse is the cheaper TRSM and the leaf is hidden under the trailing update anyway
+        const int tiles = (h->leaf_tiles && R <= h->leaf_tiles_rows) ? 1 : 0;
+        rc = launch_leaf(h, A + k0 * lda + k0, lda, h->linv + kb * LEAF_DOUBLES, h->logdet_parts + kb, (int)k0, 1,
+                         nv >= TILE ? TILE : (nv > 0 ? (int)nv : 0), tiles);
+        if (rc) return rc;
         if (R <= 0) continue;
         // panel TRSM in place: A[r0:, k0:k0+128] <- A[r0:, k0:k0+128] * inv(L_kk)^T
-        GemmDesc t{};
-        t.a_kmajor = 0; t.b_nmajor = 0; t.lower = 0; t.M = R; t.N = TILE; t.K = TILE;
-        t.alpha = 1.0; t.beta = 0.0;
-        t.A = A + r0 * lda + k0; t.lda = lda;
-        t.B = h->linv + kb * LEAF_DOUBLES; t.ldb = TILE;
-        t.C = A + r0 * lda + k0; t.ldc = lda;
-        rc = launch_gemm(h, t);
-        if (rc) return rc;
+        if (tiles) {        // by substitution with the inverses of the diagonal block's 16 x 16 tiles (all the leaf left)
+            rc = launch_trsm_tiles(h, A + r0 * lda + k0, lda, R, A + k0 * lda + k0, lda, h->linv + kb * LEAF_DOUBLES);
+            if (rc) return rc;
+        } else {
+            GemmDesc t{};
+            t.a_kmajor = 0; t.b_nmajor = 0; t.lower = 0; t.M = R; t.N = TILE; t.K = TILE;
+            t.alpha = 1.0; t.beta = 0.0;
+            t.A = A + r0 * lda + k0; t.lda = lda;
+            t.B = h->linv + kb * LEAF_DOUBLES; t.ldb = TILE;
+            t.C = A + r0 * lda + k0; t.ldc = lda;
+            rc = launch_gemm(h, t);
+            if (rc) return rc;
+        }
         // update of the rest of the outer panel: A[r0:, r0:Jend] -= P P[0:Jend-r0]^T (lower tiles)
         const int64_t W = Jend - r0;
         if (W > 0) {
@@ -428,6 +439,12 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             // the next iteration's updates use panel J+1: wait for its factorisation
             HIPCHK(hipStreamWaitEvent(mainS, h->ev_panel, 0));
         }
+    }
+    if (h->leaf_tiles) {
+        // the chain only needed the inverses of the 16 x 16 diagonal tiles; the 128 x 128 block inverses the sweeps, the
+        // posterior and POTRI use come from one launch over all blocks (a few tens of microseconds on the whole chip
+        // instead of 8 us per block on the chain's critical path)
+        rc = launch_leaf_inverse_batched(h, A, lda, nblk, h->linv); if (rc) return rc;
     }
     if (enqueue_only) {          // no host round trip: info stays on the device, nothing is timed
         if (info_dev) HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));

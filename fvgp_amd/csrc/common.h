@@ -40,6 +40,8 @@ struct fvgp_handle {
     double *winv = nullptr;
     size_t winv_cap = 0;
     bool winv_ok = false;
+    int64_t leaf_tiles_rows = 8192;   //   ... while at most this many rows lie below the block
+    int leaf_tiles = 1;               // option: the leaf leaves the inverses of its 16x16 diagonal tiles only, the chain's TRSM substitutes
     int k128_kernels = 1;             // option: K = 128 products of the panel chain fetch their operands in one stage
     int block_inverses = 1;           // option: 0 = the posterior substitution walks the 128-blocks instead
     // per-leaf sum(log L_ii), device
@@ -150,7 +152,11 @@ struct GradDesc {
 };
 int launch_grad_trace(fvgp_handle *h, const GradDesc &g, int *nblocks_out);
 
-int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid);
+int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid,
+                int tiles_only = 0);
+// X = A inv(L)^T in place for `rows` (a multiple of 32) rows of 128 columns, by substitution over the eight 16-column tiles of
+// the 128 x 128 lower block L with the inverses of its diagonal tiles (`dinv`, as launch_leaf(tiles_only) leaves them)
+int launch_trsm_tiles(fvgp_handle *h, double *A, int64_t lda, int64_t rows, const double *L, int64_t ldl, const double *dinv);
 int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, int64_t nblk, double *linv);
 
 int launch_fwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,

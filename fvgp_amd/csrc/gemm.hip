@@ -533,6 +533,87 @@ __global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
             cbase[(4 * v) * g.ldc + ph * 32] = alpha * acc[ph][v] + (beta != 0.0 ? beta * old[ph][v] : 0.0);
 }
 
+// The chain's panel TRSM without the inverse of the 128 x 128 diagonal block: X = A inv(L)^T by substitution over the eight
+// 16-column tiles,  X_t = (A_t - sum_{s<t} X_s L[t,s]^T) inv(L_tt)^T,  with the inverses of the 16 x 16 diagonal tiles only
+// (what the leaf computes anyway; its triangular inverse of the whole block was 19 of its 103 thousand cycles, on ONE
+// workgroup, in every step of the chain -- here the same number of MFMAs is spread over rows/32 workgroups).  A workgroup
+// owns 32 rows, a wave 16 of them; everything is computed transposed so that a finished tile is already the next
+// product's B operand: R^T = A_t^T - sum L[t,s] X_s^T accumulates in the MFMA D layout, X_t^T = inv(L_tt) R^T takes it as
+// it is.  L passes through in four phases of 32 rows (next phase in flight during the MFMAs); 67 KB of LDS.
+struct TrsmTilesArgs { double *A; long lda; const double *L; long ldl; const double *dinv; };
+
+__global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
+    constexpr int LDS_ = 130;
+    __shared__ double sX[32 * LDS_];
+    __shared__ double sL[32 * LDS_];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    double *Arows = g.A + (long)blockIdx.x * 32 * g.lda;
+    double2_t ra[16], rl[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) ra[p] = *reinterpret_cast<const double2_t *>(Arows + (long)(2 * p + wave) * g.lda + 2 * lane);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) rl[p] = *reinterpret_cast<const double2_t *>(g.L + (long)(2 * p + wave) * g.ldl + 2 * lane);
+    double2_t rd0 = *reinterpret_cast<const double2_t *>(g.dinv + 2 * tid), rd1 = *reinterpret_cast<const double2_t *>(g.dinv + 256 + 2 * tid);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) *reinterpret_cast<double2_t *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]) = ra[p];
+    double *xrow = &sX[(16 * wave + r) * LDS_];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) *reinterpret_cast<double2_t *>(&sL[(2 * p + wave) * LDS_ + 2 * lane]) = rl[p];
+        __syncthreads();
+        {   // the two diagonal tiles of these rows <- their inverses (thread -> two adjacent entries of each tile)
+            const int a = tid >> 3, b = (tid & 7) * 2;
+            *reinterpret_cast<double2_t *>(&sL[a * LDS_ + 32 * ph + b]) = rd0;
+            *reinterpret_cast<double2_t *>(&sL[(16 + a) * LDS_ + 32 * ph + 16 + b]) = rd1;
+        }
+        __syncthreads();
+        if (ph + 1 < 4) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+                rl[p] = *reinterpret_cast<const double2_t *>(g.L + (long)(32 * (ph + 1) + 2 * p + wave) * g.ldl + 2 * lane);
+            rd0 = *reinterpret_cast<const double2_t *>(g.dinv + (2 * ph + 2) * 256 + 2 * tid);
+            rd1 = *reinterpret_cast<const double2_t *>(g.dinv + (2 * ph + 3) * 256 + 2 * tid);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = 2 * ph + h;
+            const double *lrow = &sL[(16 * h + r) * LDS_];
+            double4_t acc, acc2 = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0}, acc4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = xrow[16 * t + q + 4 * v];
+            // sum over the finished tiles: lane group q takes k = 4q .. 4q+3 of a tile (same permutation on both operands: two
+            // 16-byte reads per operand and tile), four accumulators so that no MFMA waits for the one before it
+#pragma unroll
+            for (int s = 0; s < t; ++s) {
+                const double2_t l01 = *reinterpret_cast<const double2_t *>(lrow + 16 * s + 4 * q);
+                const double2_t l23 = *reinterpret_cast<const double2_t *>(lrow + 16 * s + 4 * q + 2);
+                const double2_t x01 = *reinterpret_cast<const double2_t *>(xrow + 16 * s + 4 * q);
+                const double2_t x23 = *reinterpret_cast<const double2_t *>(xrow + 16 * s + 4 * q + 2);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-l01[0], x01[0], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l01[1], x01[1], acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l23[0], x23[0], acc3, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l23[1], x23[1], acc4, 0, 0, 0);
+            }
+            acc += (acc2 + acc3) + acc4;
+            double4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[16 * t + q], acc[0], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[16 * t + 4 + q], acc[1], x1, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[16 * t + 8 + q], acc[2], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[16 * t + 12 + q], acc[3], x1, 0, 0, 0);
+            x0 += x1;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xrow[16 * t + q + 4 * v] = x0[v];
+        }
+        if (ph + 1 < 4) __syncthreads();          // both waves are done with these rows of L
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+        *reinterpret_cast<double2_t *>(Arows + (long)(2 * p + wave) * g.lda + 2 * lane) = *reinterpret_cast<const double2_t *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]);
+}
+
 // a wave-uniform pointer moved into SGPRs (readfirstlane returns int: widen each half as UNSIGNED)
 __device__ __forceinline__ const double *uniform_ptr(const double *p) {
     const uintptr_t v = (uintptr_t)p;
@@ -890,5 +971,14 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     HIPCHK(hipGetLastError());
     if (split) return launch_splitk_reduce(h, d.split_ws, d.split, d.M, d.N, d.lower, d.C, d.ldc, d.beta,
                                            d.split_out ? d.split_out : d.C, d.split_out ? d.split_ldo : d.ldc);
+    return 0;
+}
+
+int launch_trsm_tiles(fvgp_handle *h, double *A, int64_t lda, int64_t rows, const double *L, int64_t ldl, const double *dinv) {
+    if (rows <= 0) return 0;
+    if (rows % 32 || (lda & 1) || (ldl & 1) || ((uintptr_t)A & 15) || ((uintptr_t)L & 15)) { fvgp_set_error("trsm_tiles: rows % 32, even leading dimensions, 16-byte alignment"); return -2; }
+    TrsmTilesArgs g{A, (long)lda, L, (long)ldl, dinv};
+    hipLaunchKernelGGL(trsm_tiles_kernel, dim3((unsigned)(rows / 32)), dim3(128), 0, h->stream, g);
+    HIPCHK(hipGetLastError());
     return 0;
 }

@@ -46,6 +46,7 @@ struct LeafArgs {
     int nvalid;                   // rows of this block that count for log-det and info (rest is padding)
     long a_stride, linv_stride;   // batched mode: block b at A + b*a_stride
     unsigned long *stamps;        // diagnostics: s_memtime at the phase boundaries (nullptr in the product path)
+    int tiles_only;               // linv <- the inverses of the eight 16x16 diagonal tiles only (8 x 256 doubles, lower, zeros above)
 };
 
 __device__ __forceinline__ double4_t mfma(double a, double b, double4_t c) {
@@ -319,6 +320,21 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
     __syncthreads();
     FVGP_STAMP();
 
+    if (g.tiles_only) {
+        // the chain's TRSM substitutes tile column by tile column (trsm_tiles_kernel) and needs these only; the full
+        // 128 x 128 inverses come from one batched launch after the factorisation (launch_leaf_inverse_batched)
+        const double *Tw = &sT[tix(wave, wave)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = 4 * u + q;
+            double d = 0.0;
+            if (a > r) d = Tw[el(r, a)];
+            else if (a == r) d = srd[16 * wave + a];
+            linv[wave * 256 + a * 16 + r] = d;
+        }
+        FVGP_STAMP();
+        return;
+    }
     // ---- block column `wave` of inv(L), kept in registers in MFMA B-operand layout -----------------------
     {
         const int j = wave;
@@ -383,8 +399,10 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
 
 }  // namespace
 
-int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid) {
+int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid,
+                int tiles_only) {
     LeafArgs g;
+    g.tiles_only = tiles_only;
     g.A = A; g.lda = lda; g.linv = linv; g.logdet_part = logdet_part; g.info = h->dinfo; g.info_base = info_base;
     g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid; g.stamps = h->leaf_stamps;
     hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(512), 0, h->stream, g);
@@ -396,7 +414,7 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
     if (nblk <= 0) return 0;
     LeafArgs g;
     g.A = const_cast<double *>(L); g.lda = ldl; g.linv = linv; g.logdet_part = nullptr; g.info = h->dinfo; g.info_base = 0;
-    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr;
+    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr; g.tiles_only = 0;
     hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)nblk), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;

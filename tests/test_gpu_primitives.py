@@ -218,10 +218,13 @@ def test_potrf_solve_logdet(H, n, outer):
                                    dict(outer_block=256, outer_block_big=1024, big_threshold=1500, inner_block=128, lookahead=1),
                                    dict(outer_block=256, outer_block_big=768, big_threshold=0, inner_block=512, lookahead=1),
                                    dict(outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0),
-                                   dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1)])
+                                   dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1),
+                                   dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=0),
+                                   dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles_rows=1024)])
 def test_potrf_panel_schedules_agree(H, sched):
-    """Every panel schedule (regular / wide panels, sub-panels of a third block size, with and without look-ahead)
-    is the same factorisation: compare with LAPACK on one matrix.  The last entry is the library default."""
+    """Every panel schedule (regular / wide panels, sub-panels of a third block size, with and without look-ahead; the
+    chain's TRSM by the inverted 128-block, by substitution with the 16 x 16 tile inverses, or switching between the two
+    on the way down) is the same factorisation: compare with LAPACK on one matrix.  The third from last is the default."""
     from fvgp_amd._lib import pad128
     n = 3000
     M = _spd(n, 17)
@@ -237,8 +240,16 @@ def test_potrf_panel_schedules_agree(H, sched):
         L = np.tril(A.cpu().numpy()[:n, :n])
         assert np.max(np.abs(L - Lref)) / np.max(np.abs(Lref)) < 1e-13
         np.testing.assert_allclose(H.logdet(A, n), 2 * np.sum(np.log(np.diag(Lref))), rtol=1e-13)
+        # the 128-block inverses a solve takes after the factorisation belong to this factor whichever way the chain went
+        b = np.random.default_rng(3).standard_normal((npad, 1)); b[n:] = 0.0
+        B = H.to_device(b)
+        H.potrs(A, n, B, 1)
+        H.sync()
+        want = sla.cho_solve((Lref, True), b[:n, 0])
+        assert np.max(np.abs(B.cpu().numpy()[:n, 0] - want)) / np.max(np.abs(want)) < 1e-9
     finally:
-        for k, v in dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1).items():
+        for k, v in dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=1,
+                         leaf_tiles_rows=8192).items():
             H.set_option(k, v)
 
 
