@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
 // workgroup, in every step of the chain -- here the same number of MFMAs is spread over rows/32 workgroups).  A workgroup
 // owns 32 rows, a wave 16 of them; everything is computed transposed so that a finished tile is already the next
 // product's B operand: R^T = A_t^T - sum L[t,s] X_s^T accumulates in the MFMA D layout, X_t^T = inv(L_tt) R^T takes it as
-// it is.  L passes through in four phases of 32 rows (next phase in flight during the MFMAs); 67 KB of LDS.
+// it is.  L passes through LDS in four phases of 32 rows (all of it is fetched into registers up front); 67 KB of LDS.
 struct TrsmTilesArgs { double *A; long lda; const double *L; long ldl; const double *dinv; };
 
 __global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
@@ -549,33 +549,32 @@ __global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     double *Arows = g.A + (long)blockIdx.x * 32 * g.lda;
-    double2_t ra[16], rl[16];
+    // every global load of the kernel goes out at once (the phases would otherwise each wait a memory round trip):
+    // the workgroup's 32 rows of A, all 128 rows of L (four phases of 32), the eight tile inverses
+    double2_t ra[16], rl[4][16], rd[8];
 #pragma unroll
     for (int p = 0; p < 16; ++p) ra[p] = *reinterpret_cast<const double2_t *>(Arows + (long)(2 * p + wave) * g.lda + 2 * lane);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) rl[p] = *reinterpret_cast<const double2_t *>(g.L + (long)(2 * p + wave) * g.ldl + 2 * lane);
-    double2_t rd0 = *reinterpret_cast<const double2_t *>(g.dinv + 2 * tid), rd1 = *reinterpret_cast<const double2_t *>(g.dinv + 256 + 2 * tid);
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            rl[ph][p] = *reinterpret_cast<const double2_t *>(g.L + (long)(32 * ph + 2 * p + wave) * g.ldl + 2 * lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) rd[t] = *reinterpret_cast<const double2_t *>(g.dinv + t * 256 + 2 * tid);
 #pragma unroll
     for (int p = 0; p < 16; ++p) *reinterpret_cast<double2_t *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]) = ra[p];
     double *xrow = &sX[(16 * wave + r) * LDS_];
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
 #pragma unroll
-        for (int p = 0; p < 16; ++p) *reinterpret_cast<double2_t *>(&sL[(2 * p + wave) * LDS_ + 2 * lane]) = rl[p];
+        for (int p = 0; p < 16; ++p) *reinterpret_cast<double2_t *>(&sL[(2 * p + wave) * LDS_ + 2 * lane]) = rl[ph][p];
         __syncthreads();
         {   // the two diagonal tiles of these rows <- their inverses (thread -> two adjacent entries of each tile)
             const int a = tid >> 3, b = (tid & 7) * 2;
-            *reinterpret_cast<double2_t *>(&sL[a * LDS_ + 32 * ph + b]) = rd0;
-            *reinterpret_cast<double2_t *>(&sL[(16 + a) * LDS_ + 32 * ph + 16 + b]) = rd1;
+            *reinterpret_cast<double2_t *>(&sL[a * LDS_ + 32 * ph + b]) = rd[2 * ph];
+            *reinterpret_cast<double2_t *>(&sL[(16 + a) * LDS_ + 32 * ph + 16 + b]) = rd[2 * ph + 1];
         }
         __syncthreads();
-        if (ph + 1 < 4) {
-#pragma unroll
-            for (int p = 0; p < 16; ++p)
-                rl[p] = *reinterpret_cast<const double2_t *>(g.L + (long)(32 * (ph + 1) + 2 * p + wave) * g.ldl + 2 * lane);
-            rd0 = *reinterpret_cast<const double2_t *>(g.dinv + (2 * ph + 2) * 256 + 2 * tid);
-            rd1 = *reinterpret_cast<const double2_t *>(g.dinv + (2 * ph + 3) * 256 + 2 * tid);
-        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int t = 2 * ph + h;
