@@ -129,6 +129,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
         if (value != 0 && (value < 128 || value % 128)) { fvgp_set_error("inner_block must be 0 or a multiple of 128"); return -3; }
         h->inner_block = value; return 0;
     }
+    if (!strcmp(key, "panel_recursive")) { h->panel_recursive = value ? 1 : 0; return 0; }
     if (!strcmp(key, "leaf_tiles")) { h->leaf_tiles = value ? 1 : 0; return 0; }
     if (!strcmp(key, "leaf_tiles_rows")) { h->leaf_tiles_rows = value; return 0; }
     if (!strcmp(key, "k128_kernels")) { h->k128_kernels = value ? 1 : 0; return 0; }
@@ -336,7 +337,26 @@ static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, i
 // a panel wider than `inner_block` is factored in sub-panels of that width: 128-column steps inside a sub-panel,
 // then one update of the remaining columns of the panel with K = inner_block -- a third block size between the
 // leaf (128) and the trailing update (panel width), so that wide panels do not pay for their width in K = 128 work
+// One 128-column step of the chain without the in-panel update: leaf, then the TRSM of every row below.
+static int panel_step(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t k0) {
+    return panel_factor(h, A, n, np, lda, k0, k0 + TILE);
+}
+
+// Recursive panel: left half, ONE update of the right half's columns with K = width of the left half, right half.  Against
+// the right-looking loop of panel_factor (after every 128 columns an update of ALL remaining columns of the panel with
+// K = 128) the same flops make 2/3 of the read-modify-write passes over the panel's columns at the 512 level and run at
+// K = 256 / 512 / 1024 where they can; the update right before a leaf only touches the columns that leaf needs.
+static int panel_factor_recursive(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+    const int64_t blocks = (Jend - J0) / TILE;
+    if (blocks <= 1) return panel_step(h, A, n, np, lda, J0);
+    const int64_t mid = J0 + (blocks / 2) * TILE;
+    int rc = panel_factor_recursive(h, A, n, np, lda, J0, mid); if (rc) return rc;
+    rc = trailing_update(h, A, np, lda, J0, mid, mid, Jend, 0); if (rc) return rc;
+    return panel_factor_recursive(h, A, n, np, lda, mid, Jend);
+}
+
 static int panel_factor_nested(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+    if (h->panel_recursive) return panel_factor_recursive(h, A, n, np, lda, J0, Jend);
     const int64_t inner = h->inner_block;
     if (inner <= 0 || Jend - J0 <= inner) return panel_factor(h, A, n, np, lda, J0, Jend);
     for (int64_t s0 = J0; s0 < Jend; s0 += inner) {

@@ -220,11 +220,13 @@ def test_potrf_solve_logdet(H, n, outer):
                                    dict(outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0),
                                    dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1),
                                    dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=0),
-                                   dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles_rows=1024)])
+                                   dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles_rows=1024),
+                                   dict(outer_block=256, outer_block_big=768, big_threshold=0, inner_block=256, lookahead=1, panel_recursive=0),
+                                   dict(outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0, panel_recursive=0)])
 def test_potrf_panel_schedules_agree(H, sched):
     """Every panel schedule (regular / wide panels, sub-panels of a third block size, with and without look-ahead; the
     chain's TRSM by the inverted 128-block, by substitution with the 16 x 16 tile inverses, or switching between the two
-    on the way down) is the same factorisation: compare with LAPACK on one matrix.  The third from last is the default."""
+    on the way down; panels by recursive halving (the default) or by 128-column steps inside sub-panels) is the same factorisation: compare with LAPACK on one matrix.  The third from last is the default."""
     from fvgp_amd._lib import pad128
     n = 3000
     M = _spd(n, 17)
@@ -249,7 +251,7 @@ def test_potrf_panel_schedules_agree(H, sched):
         assert np.max(np.abs(B.cpu().numpy()[:n, 0] - want)) / np.max(np.abs(want)) < 1e-9
     finally:
         for k, v in dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=1,
-                         leaf_tiles_rows=8192).items():
+                         leaf_tiles_rows=8192, panel_recursive=1).items():
             H.set_option(k, v)
 
 
