@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
     constexpr int LDN = TN + 16;                       // row stride of the n-minor B image (16 mod 32 doubles: conflict-free reads)
     constexpr int IMA = TM * LDK, IMB = BNM ? 16 * LDN : TN * LDK;
     __shared__ double smem[2][IMA + IMB];
+    __builtin_amdgcn_s_setprio(2);                     // chain steps and sub-round updates: ahead of the trailing update's waves
     const int tn = (g.tiles_n * 128) / TN;             // tiles per row of the tile grid
     const int ti = blockIdx.x / tn, tj = blockIdx.x % tn;
     const long m0 = (long)ti * TM, n0 = (long)tj * TN;
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
     constexpr int LDS_ = 130, NPH = TN / 32, TM = 32;
     __shared__ double sA[TM * LDS_];
     __shared__ double sB[32 * LDS_];
+    __builtin_amdgcn_s_setprio(3);        // a step of the chain: ahead of the trailing-update waves it shares its SIMDs with
     const int tn = (g.tiles_n * 128) / TN;
     const int ti = blockIdx.x / tn, tj = blockIdx.x % tn;
     const long m0 = (long)ti * TM, n0 = (long)tj * TN;
@@ -546,6 +548,7 @@ __global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
     constexpr int LDS_ = 130;
     __shared__ double sX[32 * LDS_];
     __shared__ double sL[32 * LDS_];
+    __builtin_amdgcn_s_setprio(3);        // a step of the chain: ahead of the trailing-update waves it shares its SIMDs with
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     double *Arows = g.A + (long)blockIdx.x * 32 * g.lda;
