@@ -19,9 +19,19 @@
 //     super-tiles to the same XCD (blocks b, b+8, .. share an L2), so the row/column slabs
 //     of L21 a super-tile needs are fetched into that XCD's L2 once.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
+#ifndef FVGP_GEMM_LEAN_DEFAULT
+#define FVGP_GEMM_LEAN_DEFAULT 1
+#endif
+#ifndef FVGP_GEMM_SWZ_DEFAULT
+#define FVGP_GEMM_SWZ_DEFAULT 1
+#endif
+#ifndef FVGP_GEMM_PIPE_DEFAULT
+#define FVGP_GEMM_PIPE_DEFAULT 0
+#endif
 constexpr int BK = 16;
 constexpr int LDK = 18;            // doubles per row of a k-minor LDS image  [128][18]
 constexpr int LDM = 144;           // doubles per row of an m-minor LDS image [16][144]
@@ -112,6 +122,14 @@ __host__ __device__ inline long xcd_remap(long b, long nwg, int tiles_n) {
     return full * per + (k >= 0 ? k : 0);
 }
 
+// a wave-uniform pointer moved into SGPRs (readfirstlane returns int: widen each half as UNSIGNED)
+__device__ __forceinline__ const double *uniform_ptr(const double *p) {
+    const uintptr_t v = (uintptr_t)p;
+    const uintptr_t lo = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffu));
+    const uintptr_t hi = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<const double *>(lo | (hi << 32));
+}
+
 // epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile.  The read-modify-write of C
 // is done in two batches of 32 loads per lane, all issued before the first use, so a tile pays two
 // memory round trips instead of sixteen.
@@ -154,7 +172,7 @@ template <int AKM, int BNM, int ROLE, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // 76 KB, a little more than the 72 KB of operand images: the look-ahead leaf kernel (73 KB) must fit
     // into the LDS range one retiring workgroup of this kernel frees
-    __shared__ double smem[2][2][IMG + 128];
+    __shared__ double smem[2][2][IMG + 128 + ((DBG & 1024) ? 640 : 0)];
 
     // XCD-aware remap: hardware deals block b to XCD b%8.  Blocks b, b+8, b+16, .. (one XCD) walk whole
     // super-tiles: the 8*SN tiles of a super-tile run together on one L2, and super-tiles are dealt
@@ -198,6 +216,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     long nb0 = n0;                    // first row of this tile's B block
     if (!BNM) { const int idx = tj + g.bco; nb0 = ((long)(idx % g.bcr) * g.bcb + idx / g.bcr) * 128; }
 
+    // both operands k-minor (the trailing update, every panel product): unpadded [128][16] images whose 16-byte chunks are
+    // XOR-swizzled within their row by s(row) = bit1(row) | bit2(row) << 2.  ds_read_b128 serves a wave in four groups of
+    // sixteen lanes, {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32: every group holds each r = lane & 15 once,
+    // with lane group q = lane >> 4 alternating between two values, and with this swizzle the sixteen chunks of a group fall
+    // on sixteen different 16-byte bank groups (the padded [128][18] image left a third of the LDS cycles to 2-way
+    // conflicts: SQ_LDS_BANK_CONFLICT = 4 cycles per read); a row is still 128 contiguous bytes for the ds_write_b128 side.
+    constexpr bool SWZ = !AKM && !BNM && DBG != 64 && ((DBG & 256) || (DBG == 0 && FVGP_GEMM_SWZ_DEFAULT));
+    auto swz = [](int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); };
     // global -> register staging maps (4 x 16 B per operand per thread)
     const double *ga[4]; const double *gb[4];
     int sa[4], sb[4];
@@ -211,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         } else {             // A stored (M, K): rows of 16 contiguous k
             int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
             ga[p] = gA + (m0 + row) * g.lda + kbeg + kc;
-            sa[p] = row * LDK + kc;
+            sa[p] = SWZ ? row * 16 + (((tid & 7) ^ swz(row)) << 1) : row * LDK + kc;
         }
         if (BNM) {           // B stored (K, N)
             int kr = p * 4 + (tid >> 6), nc = (tid & 63) * 2;
@@ -220,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         } else {             // B stored (N, K)
             int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
             gb[p] = gB + (nb0 + row) * g.ldb + kbeg + kc;
-            sb[p] = row * LDK + kc;
+            sb[p] = SWZ ? row * 16 + (((tid & 7) ^ swz(row)) << 1) : row * LDK + kc;
         }
     }
     astep = AKM ? (long)BK * g.lda : BK;
@@ -235,10 +261,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     // both operands k-minor: lane group q takes k = 4q .. 4q+3 of a K step instead of q, q+4, q+8, q+12 (the same
     // permutation of the sum on both sides), so a pair of fragments is one 16-byte LDS read; probe 64 keeps the 8-byte reads
-    constexpr bool KPERM = !AKM && !BNM && !(DBG & 7) && DBG != 64;
+    constexpr bool KPERM = !AKM && !BNM && (!(DBG & 7) || (DBG & 512)) && DBG != 64;
     if constexpr (KPERM) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { fa[i] += 3 * q; fb[i] += 3 * q; }
+    }
+    int fa1[4], fb1[4];               // SWZ: second half of a K step = the neighbouring chunk (chunk ^ 1)
+    if constexpr (SWZ) {
+        const int c0 = (2 * q) ^ swz(r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = (wm * 64 + i * 16 + r) * 16 + 2 * c0; fa1[i] = (wm * 64 + i * 16 + r) * 16 + 2 * (c0 ^ 1);
+            fb[i] = (wn * 64 + i * 16 + r) * 16 + 2 * c0; fb1[i] = (wn * 64 + i * 16 + r) * 16 + 2 * (c0 ^ 1);
+        }
     }
     constexpr int SA = AKM ? 4 * LDM : 4;
     constexpr int SB = BNM ? 4 * LDM : 4;
@@ -264,6 +299,164 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     __syncthreads();
 
+    // K loop without vector-ALU work (both operands k-minor).  fp64 MFMA and the vector ALU do not execute side by side on a
+    // SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in this kernel): every v_lshl_add_u64 of a pointer bump, every LDS base that is
+    // recomputed per step comes straight out of the MFMA stream (12 such instructions per K step and wave cost ~4 %).
+    // Here the global loads go through buffer descriptors -- a constant 32-bit offset per lane, the K position in an SGPR
+    // bumped by the scalar ALU -- and the loop is unrolled over the two LDS buffers so that every LDS address is one
+    // loop-invariant register plus an immediate.
+    constexpr bool PIPE = KPERM && !SWZ && (DBG == 128 || (DBG == 0 && FVGP_GEMM_PIPE_DEFAULT));
+    constexpr bool LEAN = KPERM && ((DBG & 512) || (DBG == 0 && FVGP_GEMM_LEAN_DEFAULT));
+    constexpr int PB = (DBG & 512) ? (DBG & 31) : 0;      // timing probes of this loop: 1 no global loads / LDS writes, 2 no barrier, 4 no LDS reads
+    if constexpr (LEAN) {
+        const double *abase = uniform_ptr(gA + m0 * g.lda + kbeg);
+        const double *bbase = uniform_ptr(gB + nb0 * g.ldb + kbeg);
+        const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(abase), 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(bbase), 0, 0xffffffff, 0x00020000);
+        int voa[4], vob[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
+            voa[p] = (int)(((long)row * g.lda + kc) * 8);
+            vob[p] = (int)(((long)row * g.ldb + kc) * 8);
+        }
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 la[4] = {}, lb[4] = {};
+        u32x4 sink = {};
+        int soff = 0;                                   // byte offset of the K step being fetched
+        auto kstep = [&](auto curc, const bool more) {
+            constexpr int CUR = decltype(curc)::value;
+            if (more && !(PB & 1) && !(PB & 8)) {
+                soff += BK * 8;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    la[p] = __builtin_amdgcn_raw_buffer_load_b128(ra_src, voa[p], soff, 0);
+                    lb[p] = __builtin_amdgcn_raw_buffer_load_b128(rb_src, vob[p], soff, 0);
+                }
+            }
+            const double *pa = &smem[CUR][0][0];
+            const double *pb = &smem[CUR][1][0];
+            __builtin_amdgcn_s_setprio(ROLE ? 1 : 2);
+            // all sixteen fragment reads of the step go out before its first MFMA
+            double2_t a2[2][4], b2[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (PB & 4) { a2[hf][i] = ra[i] + (double)(hf + CUR); b2[hf][i] = rb[i] + (double)(hf + CUR); }
+                    else if constexpr (SWZ) {
+                        a2[hf][i] = *reinterpret_cast<const double2_t *>(pa + (hf ? fa1[i] : fa[i]));
+                        b2[hf][i] = *reinterpret_cast<const double2_t *>(pb + (hf ? fb1[i] : fb[i]));
+                    } else {
+                        a2[hf][i] = *reinterpret_cast<const double2_t *>(pa + fa[i] + 2 * hf);
+                        b2[hf][i] = *reinterpret_cast<const double2_t *>(pb + fb[i] + 2 * hf);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[hf][i][s], b2[hf][j][s], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(ROLE ? 0 : 1);
+            if (more && !(PB & 1) && !(PB & 16)) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    *reinterpret_cast<u32x4 *>(&smem[CUR ^ 1][0][sa[p]]) = la[p];
+                    *reinterpret_cast<u32x4 *>(&smem[CUR ^ 1][1][sb[p]]) = lb[p];
+                }
+            }
+            if ((PB & 16) && more) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) sink ^= la[p] ^ lb[p];
+            }
+            if (!(PB & 2)) __syncthreads();
+        };
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            kstep(std::integral_constant<int, 0>{}, true);
+            kstep(std::integral_constant<int, 1>{}, kt + 2 < nk);
+        }
+        if (kt < nk) kstep(std::integral_constant<int, 0>{}, false);
+        if ((PB & 16) && sink[0] == 0x12345u) smem[0][0][tid] = 1.0;
+    } else
+    // Software-pipelined K loop (both operands k-minor): a K step's MFMAs are split around its barrier.  The fragments of
+    // the step's second half are read before the first half's MFMAs, the next step's first-half fragments right after the
+    // barrier and before the second half's MFMAs -- every LDS read has 32 MFMAs (2048 pipe cycles) of the wave's own work
+    // between issue and use, and the wave arrives at the barrier with half a step of MFMAs still to issue behind it, so
+    // the LDS round trip no longer sits between the barrier and the first MFMA of the next step.
+    if constexpr (PIPE) {
+        double2_t f0a[4], f0b[4], f1a[4], f1b[4];
+        if (nk > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f0a[i] = *reinterpret_cast<const double2_t *>(&smem[0][0][fa[i]]);
+                f0b[i] = *reinterpret_cast<const double2_t *>(&smem[0][1][fb[i]]);
+            }
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = (kt + 1 < nk);
+            if (more) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    ga[p] += astep; gb[p] += bstep;
+                    ra[p] = *reinterpret_cast<const double2_t *>(ga[p]);
+                    rb[p] = *reinterpret_cast<const double2_t *>(gb[p]);
+                }
+            }
+            const double *pa = &smem[cur][0][0];
+            const double *pb = &smem[cur][1][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f1a[i] = *reinterpret_cast<const double2_t *>(pa + fa[i] + 2);
+                f1b[i] = *reinterpret_cast<const double2_t *>(pb + fb[i] + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(ROLE ? 1 : 2);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0a[i][s], f0b[j][s], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(ROLE ? 0 : 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    *reinterpret_cast<double2_t *>(&smem[cur ^ 1][0][sa[p]]) = ra[p];
+                    *reinterpret_cast<double2_t *>(&smem[cur ^ 1][1][sb[p]]) = rb[p];
+                }
+            }
+            __syncthreads();
+            if (more) {
+                const double *na = &smem[cur ^ 1][0][0];
+                const double *nb = &smem[cur ^ 1][1][0];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f0a[i] = *reinterpret_cast<const double2_t *>(na + fa[i]);
+                    f0b[i] = *reinterpret_cast<const double2_t *>(nb + fb[i]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(ROLE ? 1 : 2);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1a[i][s], f1b[j][s], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(ROLE ? 0 : 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
@@ -286,8 +479,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 double2_t a2[4], b2[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    a2[i] = *reinterpret_cast<const double2_t *>(pa + fa[i] + 2 * hf);
-                    b2[i] = *reinterpret_cast<const double2_t *>(pb + fb[i] + 2 * hf);
+                    if constexpr (SWZ) {
+                        a2[i] = *reinterpret_cast<const double2_t *>(pa + (hf ? fa1[i] : fa[i]));
+                        b2[i] = *reinterpret_cast<const double2_t *>(pb + (hf ? fb1[i] : fb[i]));
+                    } else {
+                        a2[i] = *reinterpret_cast<const double2_t *>(pa + fa[i] + 2 * hf);
+                        b2[i] = *reinterpret_cast<const double2_t *>(pb + fb[i] + 2 * hf);
+                    }
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -616,14 +814,6 @@ __global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
         *reinterpret_cast<double2_t *>(Arows + (long)(2 * p + wave) * g.lda + 2 * lane) = *reinterpret_cast<const double2_t *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]);
 }
 
-// a wave-uniform pointer moved into SGPRs (readfirstlane returns int: widen each half as UNSIGNED)
-__device__ __forceinline__ const double *uniform_ptr(const double *p) {
-    const uintptr_t v = (uintptr_t)p;
-    const uintptr_t lo = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffu));
-    const uintptr_t hi = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return reinterpret_cast<const double *>(lo | (hi << 32));
-}
-
 // LDS-free variant for the (M,K) x (N,K) layout (the trailing update): every wave loads its own MFMA operands straight
 // from global memory into registers.  v_mfma_f64_16x16x4 wants lane (r, q) to hold A[row r][k_q]; WHICH four k a step
 // contracts is free as long as A and B agree, so lane (r, q) takes the two consecutive doubles k0 + 2q, k0 + 2q + 1 of
@@ -889,6 +1079,9 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     if ((d.lda & 1) || (d.ldb & 1) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) {
         fvgp_set_error("gemm: operands must be 16-byte aligned with even leading dimensions"); return -9;
     }
+    if (d.lda >= (1L << 21) || d.ldb >= (1L << 21)) {     // a tile's 128 rows are addressed by 32-bit byte offsets from its first row
+        fvgp_set_error("gemm: leading dimensions must be below 2^21 doubles"); return -9;
+    }
     GemmArgs g;
     g.A = d.A; g.B = d.B; g.C = d.C; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
     g.alpha = d.alpha; g.beta = d.beta; g.K = d.K;
@@ -930,7 +1123,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         // loads / LDS writes, 2 no barrier, 4 no LDS fragment reads, 8 the full loop without s_setprio, 64 with 8-byte
         // fragment reads in the plain k order (both with correct results) -- tools/gemm_probe.py
 #define PR(V) case V: hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 0, V>), grid, block, 0, h->stream, g); break
-        switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); PR(6); PR(7); PR(8); PR(64); default: return -3; }
+        switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); PR(6); PR(7); PR(8); PR(64); PR(128); PR(256); PR(512); PR(513); PR(514); PR(515); PR(516); PR(517); PR(518); PR(519); PR(520); PR(522); PR(528); PR(530); PR(768); PR(1536); default: return -3; }
 #undef PR
         HIPCHK(hipGetLastError());
         return 0;
