@@ -23,6 +23,12 @@
 
 namespace {
 
+#ifndef FVGP_GEMM_ATOMIC_DEFAULT
+#define FVGP_GEMM_ATOMIC_DEFAULT 0
+#endif
+#ifndef FVGP_GEMM_DMA_DEFAULT
+#define FVGP_GEMM_DMA_DEFAULT 1
+#endif
 #ifndef FVGP_GEMM_LEAN_DEFAULT
 #define FVGP_GEMM_LEAN_DEFAULT 1
 #endif
@@ -168,6 +174,19 @@ __device__ __forceinline__ void store_tile(double4_t (&acc)[4][4], double *cbase
 
 // ROLE only names the instantiation (0 generic, 1 trailing update of the Cholesky) so that profilers list
 // the kernel the metric lives in under its own symbol
+// epilogue of C += alpha * D without reading C: one fire-and-forget global_atomic_add_f64 per element (every element of C
+// gets exactly one add per launch, so the result is the same single rounding as the read-modify-write and does not depend
+// on the order) -- no load round trips between the last MFMA and the end of the workgroup
+__device__ __forceinline__ void atomic_tile(double4_t (&acc)[4][4], double *cbase, long ldc, double alpha) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                unsafeAtomicAdd(&cbase[(i * 16 + 4 * v) * ldc + j * 16], alpha * acc[i][j][v]);
+}
+
 template <int AKM, int BNM, int ROLE, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // 76 KB, a little more than the 72 KB of operand images: the look-ahead leaf kernel (73 KB) must fit
@@ -320,6 +339,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             voa[p] = (int)(((long)row * g.lda + kc) * 8);
             vob[p] = (int)(((long)row * g.ldb + kc) * 8);
         }
+        // LDS-DMA staging (DMA): the loads write the swizzled image directly -- a wave instruction fills eight whole rows (lane l
+        // lands at 16 l bytes behind the wave's base, so lane l fetches chunk (l & 7) ^ s(row) of row l >> 3 of its rows) -- no
+        // staging registers, no ds_write instructions
+        constexpr bool DMA = SWZ && ((DBG & 2048) || (DBG == 0 && FVGP_GEMM_DMA_DEFAULT));
+        typedef __attribute__((address_space(3))) void lds_void;
+        if constexpr (DMA) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = p * 32 + (tid >> 3), kc = ((tid & 7) ^ swz(row)) * 2;
+                voa[p] = (int)(((long)row * g.lda + kc) * 8);
+                vob[p] = (int)(((long)row * g.ldb + kc) * 8);
+            }
+        }
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // the LDS destination of a wave's DMA is a scalar (M0)
+        auto dma_step = [&](auto bufc, int so) {
+            constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                lds_void *da = (lds_void *)&smem[BUF][0][(p * 32 + wave_u * 8) * 16];
+                lds_void *db = (lds_void *)&smem[BUF][1][(p * 32 + wave_u * 8) * 16];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_src, da, 16, voa[p], so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_src, db, 16, vob[p], so, 0, 0);
+            }
+        };
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         u32x4 la[4] = {}, lb[4] = {};
         u32x4 sink = {};
@@ -328,10 +371,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             constexpr int CUR = decltype(curc)::value;
             if (more && !(PB & 1) && !(PB & 8)) {
                 soff += BK * 8;
+                if constexpr (DMA) dma_step(std::integral_constant<int, CUR ^ 1>{}, soff);
+                else {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    la[p] = __builtin_amdgcn_raw_buffer_load_b128(ra_src, voa[p], soff, 0);
-                    lb[p] = __builtin_amdgcn_raw_buffer_load_b128(rb_src, vob[p], soff, 0);
+                    for (int p = 0; p < 4; ++p) {
+                        la[p] = __builtin_amdgcn_raw_buffer_load_b128(ra_src, voa[p], soff, 0);
+                        lb[p] = __builtin_amdgcn_raw_buffer_load_b128(rb_src, vob[p], soff, 0);
+                    }
                 }
             }
             const double *pa = &smem[CUR][0][0];
@@ -363,7 +409,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                         for (int j = 0; j < 4; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[hf][i][s], b2[hf][j][s], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(ROLE ? 0 : 1);
-            if (more && !(PB & 1) && !(PB & 16)) {
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next step's image has landed
+            if (!DMA && more && !(PB & 1) && !(PB & 16)) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     *reinterpret_cast<u32x4 *>(&smem[CUR ^ 1][0][sa[p]]) = la[p];
@@ -522,7 +569,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         if (!(DBG & 2)) __syncthreads();
     }
 
-    store_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
+    constexpr bool ATOM = (DBG & 4096) || (DBG == 0 && FVGP_GEMM_ATOMIC_DEFAULT);
+    if (ATOM && g.beta == 1.0) atomic_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha);
+    else store_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
 }
 
 // Small-tile variant for the latency-bound steps of the panel chain (TRSM by the inverted diagonal block, in-panel
@@ -1123,7 +1172,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         // loads / LDS writes, 2 no barrier, 4 no LDS fragment reads, 8 the full loop without s_setprio, 64 with 8-byte
         // fragment reads in the plain k order (both with correct results) -- tools/gemm_probe.py
 #define PR(V) case V: hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 0, V>), grid, block, 0, h->stream, g); break
-        switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); PR(6); PR(7); PR(8); PR(64); PR(128); PR(256); PR(512); PR(513); PR(514); PR(515); PR(516); PR(517); PR(518); PR(519); PR(520); PR(522); PR(528); PR(530); PR(768); PR(1536); default: return -3; }
+        switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); PR(6); PR(7); PR(8); PR(64); PR(128); PR(256); PR(512); PR(513); PR(514); PR(515); PR(516); PR(517); PR(518); PR(519); PR(520); PR(522); PR(528); PR(530); PR(768); PR(2816); PR(6912); PR(1536); default: return -3; }
 #undef PR
         HIPCHK(hipGetLastError());
         return 0;
