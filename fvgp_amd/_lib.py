@@ -26,7 +26,7 @@ SYMBOLS = [
     "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_stream_create", "fvgp_hip_stream_destroy", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_grad_trace", "fvgp_hip_posterior", "fvgp_hip_gemm",
-    "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower",
+    "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower", "fvgp_hip_trace_dot",
     "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
 ]
 
@@ -101,6 +101,7 @@ def lib():
     L.fvgp_hip_mfma_selftest.argtypes = [c_p, c_p, c_p, c_p]
     L.fvgp_hip_symmetrize.argtypes = [c_p, c_p, c_l, c_l]
     L.fvgp_hip_add_lower.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_d]
+    L.fvgp_hip_trace_dot.argtypes = [c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_l, P_d]
     L.fvgp_hip_mfma_peak.argtypes = [c_p, c_p, c_i, c_i]
     L.fvgp_hip_trsm_lower_t.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
     L.fvgp_hip_panel_trsm.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
@@ -167,7 +168,7 @@ class Handle:
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(lib().fvgp_hip_create(ctypes.byref(self._h), self.device, ctypes.c_void_p(stream)), "fvgp_hip_create")
-        for key in ("lookahead", "outer_block", "outer_block_big", "big_threshold", "inner_block", "gemm_direct", "small_tile_max", "small_tile_max_update", "tile_tables", "block_inverses", "k128_kernels", "leaf_tiles", "leaf_tiles_rows", "panel_recursive"):        # tuning overrides, e.g. FVGP_OUTER_BLOCK=512
+        for key in ("lookahead", "outer_block", "outer_block_big", "big_threshold", "inner_block", "gemm_direct", "small_tile_max", "small_tile_max_update", "tile_tables", "block_inverses", "k128_kernels", "leaf_tiles", "leaf_tiles_rows", "panel_recursive", "potri_kminor"):        # tuning overrides, e.g. FVGP_OUTER_BLOCK=512
             val = os.environ.get("FVGP_" + key.upper())
             if val is not None:
                 self.set_option(key, int(val))
@@ -310,6 +311,13 @@ class Handle:
     def add_lower(self, A, n, B, alpha=1.0):
         """A[:n, :n] += alpha * B[:n, :n] on the lower triangle (K + V with a matrix-valued noise model)."""
         _check(lib().fvgp_hip_add_lower(self._h, _ptr(A), int(n), A.stride(0), _ptr(B), B.stride(0), float(alpha)), "fvgp_hip_add_lower")
+
+    def trace_dot(self, W, D, b, n):
+        """sum_ij (W_ij - b_i b_j) D_ij over the full n x n arrays (W symmetric, both triangles valid); b a 1-d view or None."""
+        out = ctypes.c_double(0.0)
+        _check(lib().fvgp_hip_trace_dot(self._h, _ptr(W), W.stride(0), _ptr(D), D.stride(0), _ptr(b),
+                                        1 if b is None else b.stride(0), int(n), ctypes.byref(out)), "fvgp_hip_trace_dot")
+        return out.value
 
     def symmetrize(self, A, n):
         _check(lib().fvgp_hip_symmetrize(self._h, _ptr(A), int(n), A.stride(0)), "fvgp_hip_symmetrize")

@@ -134,6 +134,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "leaf_tiles_rows")) { h->leaf_tiles_rows = value; return 0; }
     if (!strcmp(key, "k128_kernels")) { h->k128_kernels = value ? 1 : 0; return 0; }
     if (!strcmp(key, "block_inverses")) { h->block_inverses = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "potri_kminor")) { h->potri_kminor = value ? 1 : 0; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
     return -2;
 }
@@ -792,6 +793,51 @@ int fvgp_hip_logdet(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, dou
     return read_back(h, h->red, out_host, 1);
 }
 
+// POTRI on the factorisation's own product layout.  Every product of dtrtri and of W^T W is arranged as (M,K) x (N,K) --
+// both operands k-minor, the layout of the trailing update and of its K loop (16-byte swizzled fragment reads, LDS-DMA
+// staging, no vector-ALU work) -- by keeping transposes where the textbook schedule reads an operand k-major:
+//   dtrtri, 1024-wide panels from the bottom-right corner, W_JJ from the doubled block inverses (ensure_winv):
+//        X^T  = W_JJ^T L_2J^T            A = W_JJ^T (transposed copy of the block), B = L_2J          -> work[J, 2]
+//        W_2J = -W_22 X                  A = W_22 (k <= row), B = X^T                                 -> over L_2J
+//   W^T W = (W^T)(W^T)^T with W^T written into `work` (upper tiles, diagonal tiles transposed), the result straight into L.
+// Against the round-2 schedule ((K,N) and (K,M) operands on the 8-byte fragment reads, 14 latency-bound launches per panel
+// for W_JJ, ragged K in 438 launches): the same N^3 2/3 flops on the faster kernel in 3 launches per panel.
+static int potri_kminor(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *work, int64_t ldw) {
+    const int64_t np = pad128(n), WB = 1024;
+    int rc = ensure_winv(h, L, n, ldl); if (rc) return rc;
+    rc = ensure_scratch(h, (WB * WB + 7) / 8); if (rc) return rc;
+    double *Ujj = h->vec;                                   // W_JJ^T of the panel at hand
+    const int64_t npan = (np + WB - 1) / WB;
+    for (int64_t J = npan - 1; J >= 0; --J) {
+        const int64_t J0 = J * WB, Jend = (J0 + WB < np) ? J0 + WB : np, w = Jend - J0, R = np - Jend;
+        const double *Wjj = h->winv + J0 * WB;
+        if (R > 0) {
+            rc = launch_transpose_lower_tiles(h, Wjj, WB, Ujj, WB, w); if (rc) return rc;
+            double *XT = work + J0 * ldw + Jend;            // w x R, in the (free) upper part of work
+            GemmDesc t{};   // X^T = W_JJ^T L_2J^T   (W_JJ^T upper: k >= row tile)
+            t.a_kmajor = 0; t.b_nmajor = 0; t.lower = 0; t.M = w; t.N = R; t.K = w; t.alpha = 1.0; t.beta = 0.0;
+            t.A = Ujj; t.lda = WB; t.B = L + Jend * ldl + J0; t.ldb = ldl; t.C = XT; t.ldc = ldw;
+            t.kb0 = 0; t.kbi = TILE; t.kbj = 0; t.ke0 = -1;
+            rc = launch_gemm(h, t); if (rc) return rc;
+            GemmDesc u{};   // W_2J = -W_22 X   (W_22 lower: k <= row tile), over L_2J
+            u.a_kmajor = 0; u.b_nmajor = 0; u.lower = 0; u.M = R; u.N = w; u.K = R; u.alpha = -1.0; u.beta = 0.0;
+            u.A = L + Jend * ldl + Jend; u.lda = ldl; u.B = XT; u.ldb = ldw; u.C = L + Jend * ldl + J0; u.ldc = ldl;
+            u.kb0 = 0; u.ke0 = TILE; u.kei = TILE; u.kej = 0;
+            u.rev_m = 1;    // K grows with the row tile: the long rows start first
+            rc = launch_gemm(h, u); if (rc) return rc;
+        }
+        rc = launch_copy_lower_tiles(h, Wjj, WB, L + J0 * ldl + J0, ldl, w); if (rc) return rc;
+    }
+    rc = launch_transpose_lower_tiles(h, L, ldl, work, ldw, np); if (rc) return rc;
+    GemmDesc s{};   // KV^-1 = W^T W = (W^T)(W^T)^T, lower tiles, k >= row tile
+    s.a_kmajor = 0; s.b_nmajor = 0; s.lower = 1; s.M = np; s.N = np; s.K = np; s.alpha = 1.0; s.beta = 0.0;
+    s.A = work; s.lda = ldw; s.B = work; s.ldb = ldw; s.C = L; s.ldc = ldl;
+    s.kb0 = 0; s.kbi = TILE; s.kbj = 0; s.ke0 = -1;
+    rc = launch_gemm(h, s); if (rc) return rc;
+    h->winv_ok = false; h->linv_L = nullptr;   // L is gone
+    return 0;
+}
+
 int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *work, int64_t ldw) {
     if (!h) return -1;
     int rc = check_square(L, n, ldl, 2, 3, 4);
@@ -799,6 +845,7 @@ int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *wo
     rc = check_square(work, n, ldw, 5, 3, 6);
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
+    if (h->potri_kminor) return potri_kminor(h, L, n, ldl, work, ldw);
     const int64_t np = pad128(n);
     const int64_t NB = h->outer_block;
     rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
@@ -1200,6 +1247,23 @@ int fvgp_hip_add_lower(fvgp_handle *h, double *A, int64_t n, int64_t lda, const 
     if (ldb < n) return -6;
     HIPCHK(hipSetDevice(h->device));
     return launch_add_lower(h, A, lda, B, ldb, n, alpha);
+}
+
+int fvgp_hip_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const double *D, int64_t ldd, const double *b, int64_t ldb,
+                       int64_t n, double *out_host) {
+    if (!h) return -1;
+    if (!W) return -2;
+    if (n <= 0) return -8;
+    if (ldw < n) return -3;
+    if (!D) return -4;
+    if (ldd < n) return -5;
+    if (b && ldb < 1) return -7;
+    if (!out_host) return -9;
+    HIPCHK(hipSetDevice(h->device));
+    int nblocks = 0;
+    int rc = launch_trace_dot(h, W, ldw, D, ldd, b, ldb, n, h->red + 8, &nblocks); if (rc) return rc;      // <= 2048 partial sums
+    rc = launch_sum(h, h->red + 8, nblocks, h->red); if (rc) return rc;
+    return read_back(h, h->red, out_host, 1);
 }
 
 int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda) {

@@ -45,6 +45,7 @@ struct fvgp_handle {
     int leaf_tiles = 1;               // option: the leaf leaves the inverses of its 16x16 diagonal tiles only, the chain's TRSM substitutes
     int k128_kernels = 1;             // option: K = 128 products of the panel chain fetch their operands in one stage
     int block_inverses = 1;           // option: 0 = the posterior substitution walks the 128-blocks instead
+    int potri_kminor = 1;             // option: POTRI on the (M,K) x (N,K) products only (0: the round-2 schedule with (K,N) / (K,M) operands)
     // per-leaf sum(log L_ii), device
     double *logdet_parts = nullptr;
     size_t logdet_cap = 0;
@@ -190,6 +191,9 @@ int64_t kt_alpha_scratch_doubles(int64_t n, int64_t P, int ncol);
 int launch_kt_alpha(fvgp_handle *h, const double *K, int64_t ldk, const double *alpha, int64_t lda, int ncol, int64_t n, int64_t P,
                     double *scratch, double *out, int64_t ldo, double scale, int accumulate);
 int launch_copy_lower_tiles(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t np);
+int launch_transpose_lower_tiles(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t np);
+int launch_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const double *D, int64_t ldd, const double *b, int64_t ldb, int64_t n,
+                     double *partial, int *nblocks);
 
 int ensure_linv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl);
 int ensure_scratch(fvgp_handle *h, int64_t np);

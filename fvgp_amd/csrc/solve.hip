@@ -370,11 +370,44 @@ __global__ void copy_lower_tiles_kernel(const double *src, long lds, double *dst
     }
 }
 
+// dst tile (tj, ti) <- transpose of src tile (ti, tj) for the 128 x 128 tiles on and below the block diagonal, in 32 x 32
+// pieces through LDS (the upper part of src's diagonal tiles is explicit zeros, so dst's diagonal tiles come out with a zero
+// lower part): W = inv(L) (lower, k-major for W^T W) becomes W^T (upper, k-minor: the (M,K) x (N,K) layout of the fast GEMM)
+__global__ void transpose_lower_tiles_kernel(const double *src, long lds, double *dst, long ldd) {
+    __shared__ double t[32][33];
+    const int bj = blockIdx.x, bi = blockIdx.y;           // 32-granular block coordinates in src
+    if ((bj >> 2) > (bi >> 2)) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int rr = ty; rr < 32; rr += 8) t[rr][tx] = src[((long)bi * 32 + rr) * lds + (long)bj * 32 + tx];
+    __syncthreads();
+    for (int rr = ty; rr < 32; rr += 8) dst[((long)bj * 32 + rr) * ldd + (long)bi * 32 + tx] = t[tx][rr];
+}
+
+// partial[block] = sum over the block's rows i and all j < n of (W[i][j] - b_i b_j) D[i][j]: the trace term of the gradient
+// for a derivative matrix D that exists as numbers (host kernel callables, matrix-valued noise derivatives),
+// tr(KV^-1 dK) - b^T dK b with W = KV^-1 symmetric and full (gp_marginal_likelihood.py:301-306); b may be null
+__global__ __launch_bounds__(256) void trace_dot_kernel(const double *W, long ldw, const double *D, long ldd, const double *b, long ldb,
+                                                        long n, double *partial) {
+    __shared__ double sw[4];
+    double s = 0.0;
+    for (long i = blockIdx.x; i < n; i += gridDim.x) {
+        const double bi = b ? b[i * ldb] : 0.0;
+        for (long j = threadIdx.x; j < n; j += 256) {
+            const double bj = b ? b[j * ldb] : 0.0;
+            s = fma(W[i * ldw + j] - bi * bj, D[i * ldd + j], s);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
 // A[i][j] += alpha * B[i][j] on the lower triangle (j <= i < n): K + V for a matrix-valued noise model (gp_kv.py:654-657)
 __global__ void add_lower_kernel(double *A, long lda, const double *B, long ldb, long n, double alpha) {
-    const long i = blockIdx.y;
-    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j <= i; j += (long)gridDim.x * blockDim.x)
-        A[i * lda + j] = fma(alpha, B[i * ldb + j], A[i * lda + j]);
+    for (long i = blockIdx.y; i < n; i += gridDim.y)
+        for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j <= i; j += (long)gridDim.x * blockDim.x)
+            A[i * lda + j] = fma(alpha, B[i * ldb + j], A[i * lda + j]);
 }
 
 // rows n..np-1 of a padded square matrix <- identity rows (lower part; the strict upper is never read)
@@ -458,7 +491,8 @@ int launch_rows_to_vec(fvgp_handle *h, const double *A, int64_t lda, int64_t row
 
 int launch_add_lower(fvgp_handle *h, double *A, int64_t lda, const double *B, int64_t ldb, int64_t n, double alpha) {
     long bx = (n + 255) / 256; if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(add_lower_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, h->stream, A, (long)lda, B, (long)ldb, (long)n, alpha);
+    const long by = n < 65535 ? n : 65535;                 // gridDim.y is limited to 65535: the rows are walked with that stride
+    hipLaunchKernelGGL(add_lower_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, h->stream, A, (long)lda, B, (long)ldb, (long)n, alpha);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -607,6 +641,23 @@ int launch_kt_alpha(fvgp_handle *h, const double *K, int64_t ldk, const double *
     hipLaunchKernelGGL(kt_alpha_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
                        scratch, (int)nchunks, (long)P, C, ncol, out, (long)ldo, scale, accumulate);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_transpose_lower_tiles(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t np) {
+    unsigned nb = (unsigned)(np / 32);
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL(transpose_lower_tiles_kernel, dim3(nb, nb), dim3(256), 0, h->stream, src, (long)lds, dst, (long)ldd);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const double *D, int64_t ldd, const double *b, int64_t ldb, int64_t n,
+                     double *partial, int *nblocks) {
+    const long blocks = n < 2048 ? n : 2048;
+    hipLaunchKernelGGL(trace_dot_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, W, (long)ldw, D, (long)ldd, b, (long)ldb, (long)n, partial);
+    HIPCHK(hipGetLastError());
+    *nblocks = (int)blocks;
     return 0;
 }
 

@@ -211,6 +211,13 @@ int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);
 /* A[i][j] += alpha * B[i][j] for j <= i < n: GPkv.addKV with a matrix-valued (2-d) noise model, KV = K + V
  * (gp_kv.py:654-657); only the lower triangle, like every other symmetric buffer of this ABI */
 int fvgp_hip_add_lower(fvgp_handle *h, double *A, int64_t n, int64_t lda, const double *B, int64_t ldb, double alpha);
+/* out = sum_{i,j<n} (W[i][j] - b_i b_j) D[i][j]  =  tr(W D) - b^T D b for symmetric W: the kernel term of the gradient,
+ * dL/dtheta_i = -1/2 (b^T dK_i b - tr(KV^-1 dK_i)) (gp_marginal_likelihood.py:301-306), for a derivative matrix that exists as
+ * numbers -- kernel callables (user gradient or the central differences of gp_prior.py:438-447) and matrix-valued noise
+ * derivatives (gp_marginal_likelihood.py:262-267).  W, D full n x n device arrays (W symmetric: both triangles valid), b a
+ * device vector with stride ldb or NULL.  Fixed-order reduction. */
+int fvgp_hip_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const double *D, int64_t ldd, const double *b, int64_t ldb,
+                       int64_t n, double *out_host);
 /* mirror the lower triangle into the upper (for exporting K / KV^-1 to numpy) */
 int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda);
 

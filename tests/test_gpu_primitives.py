@@ -287,7 +287,7 @@ def test_golden_lin_alg_block(H):
     np.testing.assert_allclose(H.logdet(A, 96), float(fx["logdet"]), rtol=1e-13)
 
 
-@pytest.mark.parametrize("n", [128, 300, 900])
+@pytest.mark.parametrize("n", [128, 300, 900, 2500, 3333])
 def test_potri(H, n):
     from fvgp_amd._lib import pad128
     M = _spd(n, 40 + n)
@@ -305,6 +305,17 @@ def test_potri(H, n):
     H.sync()
     full = A.cpu().numpy()[:n, :n]
     assert np.max(np.abs(full - inv)) / np.max(np.abs(inv)) < 1e-11
+    # the round-2 schedule ((K,N) / (K,M) operands) gives the same inverse
+    A2 = H.to_device(buf)
+    assert H.potrf(A2, n) == 0
+    H.set_option("potri_kminor", 0)
+    try:
+        H.potri(A2, n, W)
+    finally:
+        H.set_option("potri_kminor", 1)
+    H.sync()
+    got2 = np.tril(A2.cpu().numpy()[:n, :n])
+    assert np.max(np.abs(got2 - got)) / np.max(np.abs(inv)) < 1e-12
 
 
 GOLD = ["G1_rbf_n500_d1.npz", "G2_rbf_n512_d3.npz", "G3_matern52_n512_d3.npz", "G6_rbf_2col_n300_d3.npz",
