@@ -166,6 +166,37 @@ def config_records():
                  "loglik_ms": ll, "bound_ms": 1e3 * float(n) ** 3 / 3 / peak, "frac": (1e3 * float(n) ** 3 / 3 / peak) / ll}
     del gp
     torch.cuda.empty_cache()
+    # C4's size on ONE GPU (the 8-GPU run is the driver's): the fused single-GPU evaluation against the row-sharded driver at one
+    # rank, its whole multi-rank code path taken with the collectives issued through RCCL (one-rank communicator)
+    try:
+        from fvgp_amd import _lib
+        from fvgp_amd.device import default_handle
+        from fvgp_amd.dist import ShardedGP
+        n = 100000
+        x, y = synth(n, 3)
+        nv = np.full(n, 0.01)
+        H = default_handle()
+        npad = _lib.pad128(n)
+        KV = H.empty(npad, npad)
+        xd, vd, ymd = H.to_device(x), H.to_device(nv), H.to_device((y - np.mean(y)).reshape(n, 1))
+        vals = []
+        fused = best(lambda: vals.append(H.loglik(0, xd, th * 1.01, vd, ymd, KV, None)[0]), reps=1)
+        del KV
+        torch.cuda.empty_cache()
+        sh = ShardedGP(x, y, nv, kernel="rbf_ard", panel=1024, rank=0, world=1, force_collectives=True, collectives="rccl")
+        svals = []
+        sharded = best(lambda: svals.append(sh.log_likelihood(th * 1.01)[0]), reps=1)
+        flops = float(n) ** 3 / 3
+        out["C4_size_one_gpu"] = {
+            "workload": "N=100000 d=3 RBF log_likelihood(theta) on ONE MI355X: fused driver vs the row-sharded driver at one rank "
+                        "(panel buffers, diagonal-block gather and panel all-gather through a one-rank RCCL communicator)",
+            "fused_ms": fused, "fused_tflops": flops / fused / 1e9, "sharded_world1_rccl_ms": sharded,
+            "sharded_world1_rccl_tflops": flops / sharded / 1e9, "bound_ms": 1e3 * flops / peak,
+            "rel_diff": abs(vals[-1] - svals[-1]) / abs(vals[-1])}
+        del sh
+        torch.cuda.empty_cache()
+    except Exception as e:                      # noqa: BLE001 -- a side record must not take the headline down
+        out["C4_size_one_gpu"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
 
@@ -227,13 +258,18 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d):
     import torch
     from fvgp_amd import _lib
     from fvgp_amd.dist import ShardedGP
+    # world == 1 (`--gpus 1 --mode sharded`): the multi-rank code path on one GPU, its collectives issued through RCCL
+    # (a one-rank communicator) unless --backend says otherwise
+    force = dist is None
     gp = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=args.outer_block or 1024,
-                   rank=rank if dist is not None else 0, world=world if dist is not None else 1)
+                   rank=None if dist is not None else 0, world=None if dist is not None else 1,
+                   force_collectives=force, collectives=("rccl" if args.backend == "nccl" else "torch") if force else "auto")
     for t in range(args.warmup):
         gp.log_likelihood(theta0 * (1.0 + 0.02 * t))
-    H = gp.ops.H
+    H = gp.ops
     H.set_option("profile", 1)
     H.get_profile()
+    gp.collective_summary()
     sync_all()
     t0 = time.perf_counter()
     for t in range(args.steps):
@@ -245,17 +281,16 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     prof = H.get_profile()
-    H.set_option("profile", 0)
-    # one more (untimed) evaluation with events around the collectives on the chain stream
+    # the collectives of the timed evaluations (events on the chain stream around every call)
     coll = {}
-    if world > 1:
-        gp.collective_events = []
-        gp.log_likelihood(theta0)
-        for kind, (calls, nbytes, ms) in gp.collective_summary().items():
-            coll[kind] = {"calls_per_eval": calls, "bytes_received_per_rank_per_eval": nbytes, "ms_on_chain_stream": ms,
-                          "GBps_per_rank": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None,
-                          "frac_of_xgmi_7x153": nbytes / (ms * 1e-3) / 1e9 / XGMI_GBPS_PER_GPU if ms > 0 else None}
-        gp.collective_events = None
+    for kind, (calls, nbytes, ms) in gp.collective_summary().items():
+        if calls:
+            coll[kind] = {"calls_per_eval": calls / args.steps, "bytes_received_per_rank_per_eval": nbytes / args.steps,
+                          "ms_on_chain_stream_per_eval": ms / args.steps,
+                          "GBps_per_rank": nbytes / (ms * 1e-3) / 1e9 if ms > 0 and nbytes > 0 else None,
+                          "frac_of_xgmi_7x153": nbytes / (ms * 1e-3) / 1e9 / XGMI_GBPS_PER_GPU if ms > 0 and nbytes > 0 else None}
+    H.set_option("profile", 0)
+    collectives_via = gp.collectives
     theta_last = theta0 * (1.0 + 0.02 * (args.warmup + args.steps - 1))
     del gp
     torch.cuda.empty_cache()
@@ -278,14 +313,16 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N={n} d={d} RBF(ARD) log_likelihood(theta): K-assembly+noise, Cholesky, forward solve, log-det; "
                                    f"ONE evaluation row-sharded over the GPUs", "n": n, "d": d, "kernel": "rbf_ard",
-                       "parallelism": f"block-cyclic 128-row blocks over {world} GPUs; per {args.outer_block or 1024}-wide panel: all-reduce of the "
-                                      f"diagonal block, RCCL all-gather of the panel factor over xGMI, one panel of look-ahead"},
+                       "parallelism": f"block-cyclic 128-row blocks over {world} GPUs; per {args.outer_block or 1024}-wide panel: all-gather of the "
+                                      f"diagonal block from its owners, RCCL all-gather of the panel factor over xGMI, one panel of look-ahead"},
             "cholesky_tflops": whole, "cholesky_tflops_per_gpu": whole / world,
             "cholesky_frac_of_fp64_mfma_peak": whole / world / PEAK_FP64_MFMA_TFLOPS,
             "loglik_last": ll,
             "rel_diff_vs_single_gpu": abs(ll - vals[0]) / abs(vals[0]),
             "single_gpu_loglik_at_same_theta": vals[0],
-            "collectives": coll, "xgmi_peak_GBps_per_gpu": XGMI_GBPS_PER_GPU,
+            "collectives": coll, "collectives_via": {"rccl": "RCCL called from libfvgp_hip.so on the chain stream (fvgp_hip_comm_init)",
+                                                     "torch": "torch.distributed callbacks (gloo test path)"}[collectives_via],
+            "xgmi_peak_GBps_per_gpu": XGMI_GBPS_PER_GPU,
             "roofline": {"kernel": "gemm_f64_kernel<0, 0, 1, 0> (row-sharded trailing update, rank 0's launches)", "bound": "mfma",
                          "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,

@@ -26,9 +26,52 @@ SYMBOLS = [
     "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_stream_create", "fvgp_hip_stream_destroy", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_grad_trace", "fvgp_hip_posterior", "fvgp_hip_gemm",
-    "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower", "fvgp_hip_trace_dot",
+    "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower", "fvgp_hip_trace_dot", "fvgp_hip_colsumsq",
     "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
+    "fvgp_hip_grad_trace_cols", "fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy", "fvgp_hip_all_reduce",
+    "fvgp_hip_all_gather", "fvgp_hip_comm_profile", "fvgp_hip_dist_workspace", "fvgp_hip_loglik_dist",
 ]
+
+
+# ---- row-sharded entry points: structures of include/fvgp_hip.h ---------------------------------------------------
+ALL_GATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+ALL_REDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+
+class Collectives(ctypes.Structure):
+    _fields_ = [("ctx", ctypes.c_void_p), ("all_gather", ALL_GATHER_FN), ("all_reduce_sum", ALL_REDUCE_FN)]
+
+
+class DistDesc(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int64), ("d", ctypes.c_int), ("ncol", ctypes.c_int), ("panel", ctypes.c_int64),
+                ("rank", ctypes.c_int), ("nranks", ctypes.c_int), ("kernel_id", ctypes.c_int),
+                ("x_all", ctypes.c_void_p), ("vdiag", ctypes.c_void_p), ("zt", ctypes.c_void_p),
+                ("A", ctypes.c_void_p), ("T", ctypes.c_void_p * 2), ("recv", ctypes.c_void_p * 2), ("Dfac", ctypes.c_void_p),
+                ("gather", ctypes.c_void_p), ("info_dev", ctypes.c_void_p), ("logdet_dev", ctypes.c_void_p),
+                ("keep_factor", ctypes.c_int), ("force_general", ctypes.c_int)]
+
+
+def bind_dist(L):
+    """argument types of the row-sharded entry points on a loaded library that implements them (libfvgp_hip.so; the
+    tests bind the CPU twin of the ABI the same way)"""
+    c_i, c_l, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+    P_d = ctypes.POINTER(ctypes.c_double)
+    P_i = ctypes.POINTER(ctypes.c_int)
+    if hasattr(L, "fvgp_hip_comm_unique_id"):
+        L.fvgp_hip_comm_unique_id.argtypes = [c_p]
+        L.fvgp_hip_comm_init.argtypes = [c_p, c_p, c_i, c_i]
+        L.fvgp_hip_comm_profile.argtypes = [c_p, P_d]
+    L.fvgp_hip_comm_init_callbacks.argtypes = [c_p, ctypes.POINTER(Collectives), c_i, c_i]
+    L.fvgp_hip_comm_destroy.argtypes = [c_p]
+    L.fvgp_hip_all_reduce.argtypes = [c_p, c_p, c_l]
+    L.fvgp_hip_all_gather.argtypes = [c_p, c_p, c_p, c_l]
+    L.fvgp_hip_dist_workspace.argtypes = [ctypes.POINTER(DistDesc), ctypes.POINTER(c_l)]
+    L.fvgp_hip_loglik_dist.argtypes = [c_p, ctypes.POINTER(DistDesc), P_d, c_i, P_d, P_i]
+    for s in ("fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_profile", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy",
+              "fvgp_hip_all_reduce", "fvgp_hip_all_gather", "fvgp_hip_dist_workspace", "fvgp_hip_loglik_dist"):
+        if hasattr(L, s):
+            getattr(L, s).restype = c_i
+    return L
 
 
 class HipExtensionError(RuntimeError):
@@ -102,6 +145,7 @@ def lib():
     L.fvgp_hip_symmetrize.argtypes = [c_p, c_p, c_l, c_l]
     L.fvgp_hip_add_lower.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_d]
     L.fvgp_hip_trace_dot.argtypes = [c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_l, P_d]
+    L.fvgp_hip_colsumsq.argtypes = [c_p, c_p, c_l, c_l, c_l, c_p]
     L.fvgp_hip_mfma_peak.argtypes = [c_p, c_p, c_i, c_i]
     L.fvgp_hip_trsm_lower_t.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
     L.fvgp_hip_panel_trsm.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
@@ -111,6 +155,8 @@ def lib():
     L.fvgp_hip_debug_tile_map.restype = c_l
     L.fvgp_hip_debug_tile_table.argtypes = [c_i, c_i, c_i, c_i, c_i, P_i, c_l]
     L.fvgp_hip_debug_tile_table.restype = c_l
+    L.fvgp_hip_grad_trace_cols.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_l, c_l, c_l, c_p, c_l, c_p, P_d]
+    bind_dist(L)
     for s in SYMBOLS:
         if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_workspace_bytes"):
             getattr(L, s).restype = c_i
@@ -132,6 +178,13 @@ def _theta(theta):
 def _ptr(t):
     """device pointer of a torch tensor (or None)."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def comm_unique_id():
+    """128 bytes naming a new RCCL communicator (ncclGetUniqueId): rank 0 calls it and hands the bytes to every rank"""
+    buf = ctypes.create_string_buffer(128)
+    _check(lib().fvgp_hip_comm_unique_id(buf), "fvgp_hip_comm_unique_id")
+    return bytes(buf.raw)
 
 
 def create_stream(device, cu_mask=None, high_priority=False):
@@ -289,6 +342,51 @@ class Handle:
                                          _ptr(b), 1 if b is None else b.stride(0), _ptr(partial), g), "fvgp_hip_grad_trace")
         return np.array(g[:], dtype=np.float64)
 
+    def grad_trace_cols(self, kernel_id, x, theta, W, col0, ncols, b, partial):
+        """the same pass over the slab W (n, >= ncols) of columns [col0, col0 + ncols) of the symmetric matrix"""
+        t, tp, nt = _theta(theta)
+        g = (ctypes.c_double * nt)()
+        n, d = x.shape
+        _check(lib().fvgp_hip_grad_trace_cols(self._h, int(kernel_id), _ptr(x), n, d, tp, nt, _ptr(W), W.stride(0), int(col0), int(ncols),
+                                              _ptr(b), 1 if b is None else b.stride(0), _ptr(partial), g), "fvgp_hip_grad_trace_cols")
+        return np.array(g[:], dtype=np.float64)
+
+    # -- row-sharded evaluation (include/fvgp_hip.h: fvgp_hip_comm_* / fvgp_hip_loglik_dist) ---------------------------
+    def comm_init(self, unique_id, rank, nranks):
+        """bind RCCL: unique_id = the 128 bytes of comm_unique_id() on rank 0, handed to every rank by the caller"""
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        _check(lib().fvgp_hip_comm_init(self._h, buf, int(rank), int(nranks)), "fvgp_hip_comm_init")
+
+    def comm_init_callbacks(self, coll, rank, nranks):
+        self._coll = coll                                          # the callbacks must outlive the handle's use of them
+        _check(lib().fvgp_hip_comm_init_callbacks(self._h, ctypes.byref(coll), int(rank), int(nranks)), "fvgp_hip_comm_init_callbacks")
+
+    def comm_destroy(self):
+        _check(lib().fvgp_hip_comm_destroy(self._h), "fvgp_hip_comm_destroy")
+
+    def all_reduce(self, t):
+        _check(lib().fvgp_hip_all_reduce(self._h, _ptr(t), t.numel()), "fvgp_hip_all_reduce")
+
+    def all_gather(self, send, recv):
+        _check(lib().fvgp_hip_all_gather(self._h, _ptr(send), _ptr(recv), send.numel()), "fvgp_hip_all_gather")
+
+    def comm_profile(self):
+        out = (ctypes.c_double * 6)()
+        _check(lib().fvgp_hip_comm_profile(self._h, out), "fvgp_hip_comm_profile")
+        return {"all_gather": (int(out[0]), out[2], out[4]), "all_reduce": (int(out[1]), out[3], out[5])}
+
+    def dist_workspace(self, desc):
+        out = (ctypes.c_int64 * 6)()
+        _check(lib().fvgp_hip_dist_workspace(ctypes.byref(desc), out), "fvgp_hip_dist_workspace")
+        return list(out)
+
+    def loglik_dist(self, desc, theta):
+        t, tp, nt = _theta(theta)
+        out = (ctypes.c_double * 3)()
+        info = ctypes.c_int(0)
+        _check(lib().fvgp_hip_loglik_dist(self._h, ctypes.byref(desc), tp, nt, out, ctypes.byref(info)), "fvgp_hip_loglik_dist")
+        return out[0], out[1], out[2], info.value
+
     def posterior(self, kernel_id, x, theta, L, alpha, ncol, xpred, kx, mean_out=None, var_out=None, S_out=None):
         t, tp, nt = _theta(theta)
         n, d = x.shape
@@ -318,6 +416,10 @@ class Handle:
         _check(lib().fvgp_hip_trace_dot(self._h, _ptr(W), W.stride(0), _ptr(D), D.stride(0), _ptr(b),
                                         1 if b is None else b.stride(0), int(n), ctypes.byref(out)), "fvgp_hip_trace_dot")
         return out.value
+
+    def colsumsq(self, V, out):
+        """out[p] = sum_i V[i][p]^2 over the rows of V"""
+        _check(lib().fvgp_hip_colsumsq(self._h, _ptr(V), V.shape[0], V.stride(0), V.shape[1], _ptr(out)), "fvgp_hip_colsumsq")
 
     def symmetrize(self, A, n):
         _check(lib().fvgp_hip_symmetrize(self._h, _ptr(A), int(n), A.stride(0)), "fvgp_hip_symmetrize")

@@ -64,6 +64,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     for (auto e : h->rs_ev) (void)hipEventDestroy(e);
     if (h->ev_cols) (void)hipEventDestroy(h->ev_cols);
     gemm_release_tables(h);
+    (void)fvgp_hip_comm_destroy(h);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->linv) (void)hipFree(h->linv);
     if (h->winv) (void)hipFree(h->winv);
@@ -165,6 +166,17 @@ int fvgp_hip_get_profile(fvgp_handle *h, double *out) {
 }
 
 }  // extern "C"
+
+// the high-priority second stream (look-ahead panel chain) and the two events that order it against the main stream
+int fvgp_ensure_side(fvgp_handle *h) {
+    if (h->side) return 0;
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_cols, hipEventDisableTiming));
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------
 static int ensure_blocks(fvgp_handle *h, int64_t nblk) {
@@ -436,13 +448,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             if (np > bnd[J + 1]) { rc = timed_update(bnd[J], bnd[J + 1], bnd[J + 1], np); if (rc) return rc; }
         }
     } else {
-        if (!h->side) {
-            int lo = 0, hi = 0;
-            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_cols, hipEventDisableTiming));
-        }
+        rc = fvgp_ensure_side(h); if (rc) return rc;
         hipStream_t mainS = h->stream, sideS = h->side;
         rc = panel_factor_nested(h, A, n, np, lda, bnd[0], bnd[1]); if (rc) return rc;      // panel 0 on the main stream
         for (size_t J = 0; J + 1 < npan; ++J) {
@@ -646,7 +652,7 @@ static int trsm_bwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl
     return 0;
 }
 
-static int read_back(fvgp_handle *h, const double *dev, double *host, int count) {
+int fvgp_read_back(fvgp_handle *h, const double *dev, double *host, int count) {
     HIPCHK(hipMemcpyAsync(h->hpin, dev, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int i = 0; i < count; ++i) host[i] = h->hpin[i];
@@ -656,8 +662,10 @@ static int read_back(fvgp_handle *h, const double *dev, double *host, int count)
 // g_i = 1/2 sum_jk (W_jk - b_j b_k) dK_jk/dtheta_i over the lower triangle of the symmetric W (b may be null):
 // one fused pass that re-evaluates dK/dtheta in registers, per-tile partial sums reduced on the host in a fixed order
 static int grad_trace_host(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d, const double *theta, int ntheta,
-                           const double *W, int64_t ldw, const double *b, int64_t ldb, double *partial, double *grad_host) {
+                           const double *W, int64_t ldw, const double *b, int64_t ldb, double *partial, double *grad_host,
+                           int64_t col0 = 0, int64_t ncols = 0) {
     GradDesc g{};
+    g.col0 = col0; g.ncols = ncols;
     int rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &g.k); if (rc) return rc;
     g.k.x1 = x; g.k.n1 = n; g.k.x2 = x; g.k.n2 = n;
     g.kernel_id = kernel_id;
@@ -790,7 +798,7 @@ int fvgp_hip_logdet(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, dou
     HIPCHK(hipSetDevice(h->device));
     int rc = launch_diag_logsum(h, L, n, ldl, h->red);
     if (rc) return rc;
-    return read_back(h, h->red, out_host, 1);
+    return fvgp_read_back(h, h->red, out_host, 1);
 }
 
 // POTRI on the factorisation's own product layout.  Every product of dtrtri and of W^T W is arranged as (M,K) x (N,K) --
@@ -963,7 +971,7 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     }
     if (h->profile) HIPCHK(hipEventRecord(h->ev_stage[3], h->stream));
     double r[2];
-    rc = read_back(h, h->red, r, 2); if (rc) return rc;
+    rc = fvgp_read_back(h, h->red, r, 2); if (rc) return rc;
     if (h->profile) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, h->ev_stage[0], h->ev_stage[1])); h->prof_kmat_ms = ms;
@@ -1011,6 +1019,24 @@ int fvgp_hip_grad_trace(fvgp_handle *h, int kernel_id, const double *x, int64_t 
     if (!grad_host) return -13;
     HIPCHK(hipSetDevice(h->device));
     return grad_trace_host(h, kernel_id, x, n, d, theta, ntheta, W, ldw, b, ldb, partial, grad_host);
+}
+
+int fvgp_hip_grad_trace_cols(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                             const double *theta, int ntheta, const double *W, int64_t ldw, int64_t col0, int64_t ncols,
+                             const double *b, int64_t ldb, double *partial, double *grad_host) {
+    if (!h) return -1;
+    if (!x) return -3;
+    if (n <= 0) return -4;
+    if (!theta) return -6;
+    if (!W) return -8;
+    if (col0 < 0 || col0 % TILE || col0 >= n) return -10;
+    if (ncols <= 0) return -11;
+    if (ldw < ncols || (ldw & 1) || ((uintptr_t)W & 15)) return -9;
+    if (b && ldb < 1) return -13;
+    if (!partial) return -14;
+    if (!grad_host) return -15;
+    HIPCHK(hipSetDevice(h->device));
+    return grad_trace_host(h, kernel_id, x, n, d, theta, ntheta, W, ldw, b, ldb, partial, grad_host, col0, ncols);
 }
 
 int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
@@ -1113,7 +1139,7 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
             rc = launch_kt_alpha(h, kx, ldk, kx, ldk, (int)P, n, P, h->vec + np * 8, S_out, lds, -1.0, 1); if (rc) return rc;
         }
         if (var_out) {
-            rc = launch_colsumsq(h, kx, np, ldk, P, k.sig, var_out); if (rc) return rc;
+            rc = launch_colsumsq(h, kx, np, ldk, P, k.sig, var_out, 1.0); if (rc) return rc;
         }
     }
     return 0;
@@ -1263,7 +1289,17 @@ int fvgp_hip_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const doubl
     int nblocks = 0;
     int rc = launch_trace_dot(h, W, ldw, D, ldd, b, ldb, n, h->red + 8, &nblocks); if (rc) return rc;      // <= 2048 partial sums
     rc = launch_sum(h, h->red + 8, nblocks, h->red); if (rc) return rc;
-    return read_back(h, h->red, out_host, 1);
+    return fvgp_read_back(h, h->red, out_host, 1);
+}
+
+int fvgp_hip_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t ncols, double *out) {
+    if (!h) return -1;
+    if (!V) return -2;
+    if (rows <= 0) return -3;
+    if (ncols <= 0 || ldv < ncols) return -4;
+    if (!out) return -6;
+    HIPCHK(hipSetDevice(h->device));
+    return launch_colsumsq(h, V, rows, ldv, ncols, 0.0, out, -1.0);
 }
 
 int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda) {

@@ -81,6 +81,13 @@ struct fvgp_handle {
     std::vector<hipEvent_t> rs_ev;
     std::vector<double> rs_flops;
     size_t rs_used = 0;
+    // row-sharded evaluation: the collectives (RCCL or the caller's), this rank's place, timings of the calls (option "profile")
+    fvgp_collectives coll{nullptr, nullptr, nullptr};
+    int coll_rank = 0, coll_nranks = 1;
+    void *rccl_lib = nullptr, *rccl_comm = nullptr;
+    struct CollRec { int kind; double bytes; hipEvent_t e0, e1; };
+    std::vector<CollRec> coll_rec;
+    std::vector<hipEvent_t> coll_ev_pool;
 };
 constexpr int RED_SLOTS = 4096;
 
@@ -151,6 +158,7 @@ struct GradDesc {
     const double *W; int64_t ldw;   // lower triangle of KV^-1
     const double *b; int64_t ldb;   // KVinvY column (stride ldb)
     double *partial;                // device, nblocks x ntheta
+    int64_t col0 = 0, ncols = 0;    // ncols > 0: W is the slab of columns [col0, col0 + ncols) (col0 % 128 == 0), its column 0 = matrix column col0
 };
 int launch_grad_trace(fvgp_handle *h, const GradDesc &g, int *nblocks_out);
 
@@ -176,7 +184,7 @@ int launch_rowsumsq(fvgp_handle *h, const double *A, int64_t lda, int64_t row0, 
 int launch_copy_cols(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t rows, int64_t cols,
                      int64_t rows_pad, int64_t cols_pad);
 int launch_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda);
-int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t P, double base, double *out);
+int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t P, double base, double *out, double sign);   // out = base - sign * sum_i V[i][p]^2
 // row-wise twins for the transposed cross-covariance block KT (P x n, leading dimension ldk):
 // out[p][c] = sum_n KT[p][n] alpha[n][c]   and   out[p] = base - sum_n KT[p][n]^2
 int launch_rows_dot(fvgp_handle *h, const double *KT, int64_t ldk, const double *alpha, int64_t lda, int ncol, int64_t n, int64_t P,
@@ -197,3 +205,5 @@ int launch_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const double 
 
 int ensure_linv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl);
 int ensure_scratch(fvgp_handle *h, int64_t np);
+int fvgp_ensure_side(fvgp_handle *h);
+int fvgp_read_back(fvgp_handle *h, const double *dev, double *host, int count);

@@ -127,16 +127,28 @@ struct GArgs {
     int d, iso, ntheta;
     double sig;
     double invl[FVGP_MAX_DIM];
+    int ntj, tj0;             // column-slab mode (ntj > 0): W holds the tile columns tj0 .. tj0 + ntj - 1 only (its column 0 is
+    long wcol0;               //   matrix column wcol0); grid = (tile rows, ntj)
 };
 
 template <int KIND>
 __global__ __launch_bounds__(256) void grad_trace_kernel(GArgs a) {
-    // blockIdx.x enumerates lower-triangular tiles
-    const long t = blockIdx.x;
-    int ti = (int)((__builtin_sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while ((long)ti * (ti + 1) / 2 > t) --ti;
-    const int tj = (int)(t - (long)ti * (ti + 1) / 2);
+    int ti, tj;
+    long pidx = blockIdx.x;
+    if (a.ntj > 0) {          // slab: one block per (tile row, tile column of the window); tiles above the diagonal hold nothing
+        ti = blockIdx.x; tj = a.tj0 + blockIdx.y;
+        pidx = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        if (ti < tj) {
+            if (threadIdx.x < a.ntheta) a.partial[pidx * a.ntheta + threadIdx.x] = 0.0;
+            return;
+        }
+    } else {                  // blockIdx.x enumerates lower-triangular tiles
+        const long t = blockIdx.x;
+        ti = (int)((__builtin_sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while ((long)ti * (ti + 1) / 2 > t) --ti;
+        tj = (int)(t - (long)ti * (ti + 1) / 2);
+    }
 
     constexpr int DD = FVGP_MAX_DIM;
     const int d = a.d;
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256) void grad_trace_kernel(GArgs a) {
     for (int rr = wave; rr < 128; rr += 4) {
         const long row = row0 + rr;
         if (row >= a.n) break;
-        const double2_t w2 = *reinterpret_cast<const double2_t *>(a.W + row * a.ldw + c0);
+        const double2_t w2 = *reinterpret_cast<const double2_t *>(a.W + row * a.ldw + (c0 - a.wcol0));
         const double br = sb[rr];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(256) void grad_trace_kernel(GArgs a) {
     }
     __syncthreads();
     if (tid == 0) {
-        double *out = a.partial + (long)blockIdx.x * a.ntheta;
+        double *out = a.partial + pidx * a.ntheta;
         double s = sred[0][0] + sred[1][0] + sred[2][0] + sred[3][0];
         out[0] = s;
         if (a.iso) {
@@ -275,9 +287,17 @@ int launch_grad_trace(fvgp_handle *h, const GradDesc &g, int *nblocks_out) {
     a.sig = g.k.sig;
     for (int i = 0; i < FVGP_MAX_DIM; ++i) a.invl[i] = g.k.invl[i];
     const long T = (a.n + 127) / 128;
-    const long nb = T * (T + 1) / 2;
-    *nblocks_out = (int)nb;
+    a.ntj = 0; a.tj0 = 0; a.wcol0 = 0;
+    long nb = T * (T + 1) / 2;
     dim3 grid((unsigned)nb), block(256);
+    if (g.ncols > 0) {        // a slab of columns [col0, col0 + ncols) of the symmetric matrix
+        a.tj0 = (int)(g.col0 / 128); a.ntj = (int)((g.ncols + 127) / 128); a.wcol0 = g.col0;
+        if (a.tj0 + a.ntj > T) a.ntj = (int)(T - a.tj0);
+        if (a.ntj <= 0) { *nblocks_out = 0; return 0; }
+        grid = dim3((unsigned)T, (unsigned)a.ntj);
+        nb = T * a.ntj;
+    }
+    *nblocks_out = (int)nb;
     switch (g.k.kind) {
         case 0: hipLaunchKernelGGL((grad_trace_kernel<0>), grid, block, 0, h->stream, a); break;
         case 1: hipLaunchKernelGGL((grad_trace_kernel<1>), grid, block, 0, h->stream, a); break;

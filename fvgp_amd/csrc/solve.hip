@@ -225,7 +225,7 @@ __global__ void symmetrize_kernel(double *A, long n, long lda) {
 }
 
 // out[p] = base - sum_{i<rows} V[i*ldv+p]^2, p < P   (posterior variance: k(x_p,x_p) - |L^-1 k_p|^2)
-__global__ void colsumsq_kernel(const double *V, long rows, long ldv, long P, double base, double *out) {
+__global__ void colsumsq_kernel(const double *V, long rows, long ldv, long P, double base, double *out, double sign) {
     __shared__ double sp[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const long p = (long)blockIdx.x * 32 + tx;
@@ -233,7 +233,7 @@ __global__ void colsumsq_kernel(const double *V, long rows, long ldv, long P, do
     if (p < P) for (long i = ty; i < rows; i += 8) { const double v = V[i * ldv + p]; s = fma(v, v, s); }
     sp[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && p < P) { double t = 0.0; for (int k = 0; k < 8; ++k) t += sp[k][tx]; out[p] = base - t; }
+    if (ty == 0 && p < P) { double t = 0.0; for (int k = 0; k < 8; ++k) t += sp[k][tx]; out[p] = base - sign * t; }
 }
 
 // row-wise twins of the two kernels above for the transposed cross-covariance block KT (P x n): one workgroup per
@@ -577,8 +577,8 @@ int launch_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda) {
     return 0;
 }
 
-int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t P, double base, double *out) {
-    hipLaunchKernelGGL(colsumsq_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, h->stream, V, (long)rows, (long)ldv, (long)P, base, out);
+int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t P, double base, double *out, double sign) {
+    hipLaunchKernelGGL(colsumsq_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, h->stream, V, (long)rows, (long)ldv, (long)P, base, out, sign);
     HIPCHK(hipGetLastError());
     return 0;
 }

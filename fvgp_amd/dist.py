@@ -7,26 +7,25 @@ Here the same pattern carries a DENSE factorisation:
   * x is replicated; 128-row blocks of K+V are dealt block-cyclically (block b -> rank b mod P),
     so every rank assembles exactly its own rows, in place, with no gather (contiguous row
     strips as gp2Scale's `ranges()` would leave the last rank 33 % of the flops);
-  * right-looking blocked Cholesky with panel width NB:
-      1. the NB x NB diagonal block is summed to every rank (all_reduce of a zero-filled buffer,
-         <= 8 MB) and stacked on top of the rank's own rows of the panel;
-      2. that tall panel is factored like a panel of the single-GPU driver, 128 columns at a time
-         (leaf, TRSM of every row below, in-panel update): the top block redundantly on every rank
-         -- no pivot traffic inside the panel -- the rank's rows solved along the way;
-      3. the panel factor is all-gathered (the one large collective: sum ~ 4 N^2 bytes per rank);
-      4. each rank applies the trailing update to its own block rows (lower tiles only), reading
-         the gathered panel in the order the all-gather left it (no re-ordering copy);
-     with one panel of look-ahead: the update is split into the next panel's columns and the rest,
-     and steps 1-3 of the next panel run on a second stream while the rest is applied;
+  * right-looking blocked Cholesky with panel width NB, sequenced INSIDE the library
+    (fvgp_hip_loglik_dist, fvgp_amd/csrc/dist_driver.h): per panel the NB x NB diagonal block is
+    all-gathered from its owners, stacked on the rank's own rows of the panel and factored like a
+    panel of the single-GPU driver; the panel factor is all-gathered (the one large collective,
+    sum ~ 4 N^2 bytes per rank) and applied to the rank's block rows, with one panel of look-ahead
+    (the chain of the next panel on the handle's high-priority stream under the trailing update);
+    RCCL is called directly on that stream;
   * the forward solve rides along as one more block row holding (y-m)^T, replicated on every rank;
     log|KV| and (y-m)^T KV^-1 (y-m) come out replicated, so the log-likelihood needs no final
     reduction and one evaluation has exactly one host synchronisation.
 
-All arithmetic goes through an `ops` object; the product ops are the HIP kernels (HipOps, raises
-without a GPU).  tests/ plug in a torch-CPU stand-in to exercise the partition and collective
-logic under gloo -- the analogue of the reference's in-process Dask cluster fixture
-(tests/test_fvgp.py:20).
+This module owns the buffers (torch tensors as device-memory containers) and sequences what follows the
+factorisation -- backward solve, posterior, gradient -- from ABI calls; every collective goes through
+the handle (fvgp_hip_all_reduce / fvgp_hip_all_gather): RCCL when the process group's backend is
+nccl, callbacks into torch.distributed otherwise (gloo: the CPU tests, which bind the CPU twin of
+the ABI through tests/dist_stub_ops.py -- the analogue of the reference's in-process Dask cluster
+fixture, tests/test_fvgp.py:20).
 """
+import ctypes
 import math
 
 import numpy as np
@@ -37,77 +36,23 @@ TILE = 128
 
 
 class HipOps:
-    """The product implementation: every operation is a libfvgp_hip.so call.  `chain` is the same set of
-    operations bound to a second, high-priority stream: the panel chain (diagonal-block factorisation, panel
-    solve, all-gather) runs there while the main stream applies the previous panel to the trailing matrix."""
+    """The product implementation: every operation is a libfvgp_hip.so call on one handle (main stream = torch's
+    current stream, the panel chain on the handle's own high-priority stream)."""
 
-    def __init__(self, handle=None, reserve_cus=0, n_cus=256, _stream=None, chain_everywhere=True):
-        """reserve_cus > 0 (a multiple of 8): the chain gets that many compute units of its own and the main
-        stream the rest, through CU-masked streams -- worth it once the panel chain, not the trailing update,
-        is the critical path (many ranks, small local matrices).  Mask bit i is CU i/8 of XCD i%8 on this part
-        (tools/cu_mask_probe.hip), so the last reserve_cus bits take reserve_cus/8 CUs from every XCD and
-        both streams keep all eight L2s."""
-        from .device import default_handle, local_device
-        torch = self.torch = __import__("torch")
-        if _stream is not None:                                    # the chain-side twin
-            self.H, self._stream, self.chain = handle, _stream, self
-            return
-        self._owned = []
-        if reserve_cus > 0:
-            dev = handle.device if handle is not None else local_device()
-            assert reserve_cus % 8 == 0 and 0 < reserve_cus < n_cus
-            side_cus = list(range(n_cus - reserve_cus, n_cus))
-            main_cus = sorted(set(range(n_cus)) - set(side_cus))
-            sm = _lib.create_stream(dev, cu_mask=main_cus)
-            self._owned = [sm]
-            self._stream = torch.cuda.ExternalStream(sm, device=dev)
-            if chain_everywhere:       # the chain may use every CU: the reserved ones are always free for it, the rest as they free up
-                side = torch.cuda.Stream(device=dev, priority=-1)
-            else:
-                ss = _lib.create_stream(dev, cu_mask=side_cus)
-                self._owned.append(ss)
-                side = torch.cuda.ExternalStream(ss, device=dev)
-            self.H = _lib.Handle(dev, stream=sm)
-        else:
-            self.H = handle or default_handle()
-            self._stream = torch.cuda.current_stream(self.H.device)
-            side = torch.cuda.Stream(device=self.H.device, priority=-1)
-        self.chain = HipOps(_lib.Handle(self.H.device, stream=side.cuda_stream), _stream=side)
+    def __init__(self, handle=None):
+        from .device import default_handle
+        self.torch = __import__("torch")
+        self.H = handle or default_handle()
+        self._stream = self.torch.cuda.current_stream(self.H.device)
+        self.native_collectives = True          # fvgp_hip_comm_init (RCCL) is available
 
     def close(self):
-        """Release what this object created: the chain-side handle, and with reserve_cus the main handle and both
-        CU-masked streams -- handles first, they synchronise their stream when destroyed."""
         self.torch.cuda.synchronize(self.H.device)
-        if self.chain is not self:
-            self.chain.H.close()
-        owned = getattr(self, "_owned", [])
-        if owned:
-            self.H.close()
-        for st in owned:
-            _lib.destroy_stream(st)
-        self._owned = []
+        self.H.comm_destroy()
 
     def stream(self):
-        """context in which torch's own work (copies, collectives) lands on this object's stream"""
+        """context in which torch's own work (copies) lands on this object's stream"""
         return self.torch.cuda.stream(self._stream)
-
-    def fork(self):
-        """the chain stream waits for everything enqueued on the main stream so far"""
-        ev = self.torch.cuda.Event()
-        ev.record(self._stream)
-        self.chain._stream.wait_event(ev)
-
-    def join(self):
-        """the main stream waits for everything enqueued on the chain stream so far"""
-        ev = self.torch.cuda.Event()
-        ev.record(self.chain._stream)
-        self._stream.wait_event(ev)
-
-    def timestamp(self):
-        """a timing event recorded on this object's stream (for the collective timings bench.py reports)"""
-        ev = self.torch.cuda.Event(enable_timing=True)
-        ev.record(self._stream)
-        return ev
 
     def zeros(self, *shape, dtype=None):
         if dtype is None:
@@ -117,16 +62,16 @@ class HipOps:
     def to_device(self, a):
         return self.H.to_device(a)
 
-    def kmat_rows(self, kernel_id, x_rows, x_all, theta, out):
-        """out[:len(x_rows), :len(x_all)] = k(x_rows, x_all); the rest of the padded window is zeroed."""
-        self.H.kmat(kernel_id, x_rows, x_all, theta, out, pad=_lib.PAD_ZERO)
+    def wrap(self, ptr, count):
+        """fp64 tensor view of `count` doubles at the raw device pointer `ptr` (collective callbacks)"""
+        class _Mem:
+            __cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+        return self.torch.as_tensor(_Mem(), device=f"cuda:{self.H.device}")
 
-    def panel_potrf_dev(self, T, w, rows, n_valid, info_dev, logdet_dev):
-        self.H.panel_potrf_dev(T, w, rows, n_valid, info_dev, logdet_dev)
+    def host_sync(self):
+        self.torch.cuda.synchronize(self.H.device)
 
-    def syrk_rowshard(self, M, N, K, A, B, C, scale, off, b_ranks, b_blocks, b_off):
-        self.H.syrk_rowshard(M, N, K, A, B, C, scale, off, b_ranks, b_blocks, b_off)
-
+    # -- ABI pass-throughs -----------------------------------------------------------------------------------------
     def kmat(self, kernel_id, x1, x2, theta, out, vdiag=None, pad=_lib.PAD_ZERO):
         self.H.kmat(kernel_id, x1, x2, theta, out, vdiag=vdiag, pad=pad)
 
@@ -143,11 +88,82 @@ class HipOps:
         self.H.invalidate_factor()
         self.H.trsm_lower_t(L, n, B, nrhs)
 
-    def grad_trace(self, kernel_id, x, theta, W, b, partial):
-        return self.H.grad_trace(kernel_id, x, theta, W, b, partial)
+    def grad_trace_cols(self, kernel_id, x, theta, W, col0, ncols, b, partial):
+        return self.H.grad_trace_cols(kernel_id, x, theta, W, col0, ncols, b, partial)
+
+    def colsumsq(self, V, out):
+        self.H.colsumsq(V, out)
+
+    def dist_workspace(self, desc):
+        return self.H.dist_workspace(desc)
+
+    def loglik_dist(self, desc, theta):
+        return self.H.loglik_dist(desc, theta)
+
+    def all_reduce(self, t):
+        self.H.all_reduce(t)
+
+    def all_gather(self, send, recv):
+        self.H.all_gather(send, recv)
+
+    def comm_init(self, unique_id, rank, nranks):
+        self.H.comm_init(unique_id, rank, nranks)
+
+    def comm_init_callbacks(self, coll, rank, nranks):
+        self.H.comm_init_callbacks(coll, rank, nranks)
+
+    def comm_profile(self):
+        return self.H.comm_profile()
+
+    def set_option(self, key, value):
+        self.H.set_option(key, value)
+
+    def get_profile(self):
+        return self.H.get_profile()
 
     def sync(self):
         self.H.sync()
+
+
+def torch_collectives(ops, dist, group, world):
+    """fvgp_collectives whose two entries run torch.distributed on views of the raw buffers -- the binding for process groups
+    without RCCL (gloo).  Device buffers travel through the host (the collective is then synchronous: test-sized problems)."""
+    torch = ops.torch
+
+    def all_gather(ctx, send, recv, count, stream):
+        try:
+            s, r = ops.wrap(send, count), ops.wrap(recv, count * world)
+            if s.is_cuda:
+                ops.host_sync()
+                sc = s.cpu()
+                out = [torch.empty_like(sc) for _ in range(world)]
+                dist.all_gather(out, sc, group=group)
+                r.copy_(torch.cat(out))
+                ops.host_sync()
+            else:
+                dist.all_gather(list(r.view(world, count).unbind(0)), s.clone(), group=group)
+            return 0
+        except Exception as e:                                 # noqa: BLE001 -- an exception cannot cross the C frame
+            print(f"fvgp_amd.dist: all_gather callback failed: {type(e).__name__}: {e}", flush=True)
+            return 2999
+
+    def all_reduce(ctx, buf, count, stream):
+        try:
+            b = ops.wrap(buf, count)
+            if b.is_cuda:
+                ops.host_sync()
+                bc = b.cpu()
+                dist.all_reduce(bc, op=dist.ReduceOp.SUM, group=group)
+                b.copy_(bc)
+                ops.host_sync()
+            else:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as e:                                 # noqa: BLE001
+            print(f"fvgp_amd.dist: all_reduce callback failed: {type(e).__name__}: {e}", flush=True)
+            return 2999
+
+    return _lib.Collectives(None, _lib.ALL_GATHER_FN(all_gather), _lib.ALL_REDUCE_FN(all_reduce))
 
 
 class ShardedGP:
@@ -156,13 +172,17 @@ class ShardedGP:
     x (n,d), y (n,) or (n,c), noise variances (n,) are given replicated (host arrays); the N x N
     matrix only ever exists as this rank's block rows.  Below them every rank keeps one more 128-row
     block holding (y-m)^T: carried through the panel solves and trailing updates like any other block
-    row it comes out as (L^-1 (y-m))^T, so the forward solve costs no extra pass and no collective."""
+    row it comes out as (L^-1 (y-m))^T, so the forward solve costs no extra pass and no collective.
+
+    force_collectives: a single rank still takes the panel-buffer path and calls its collectives (through RCCL when
+    `collectives` is "rccl"): the whole multi-rank code path on one GPU."""
 
     def __init__(self, x, y, noise_variances, kernel="rbf_ard", group=None, ops=None, panel=1024,
-                 rank=None, world=None):
+                 rank=None, world=None, collectives="auto", force_collectives=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
+        in_group = dist.is_initialized() and rank is None
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
             world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -181,173 +201,80 @@ class ShardedGP:
         self.nb_max = -(-self.nblk // self.P)                       # block rows per rank (uniform, padded)
         self.nb_loc = len(range(self.p, self.nblk, self.P))          # block rows this rank really owns
         self.nloc = self.nb_max + 1                                  # + the block of right-hand-side rows
+        self.general = self.P > 1 or bool(force_collectives)         # panel buffers + collectives (dist_driver.h)
         # global row index of every local row
         gb = np.arange(self.nb_max) * self.P + self.p
         self.gidx = (gb[:, None] * TILE + np.arange(TILE)[None, :]).reshape(-1)
         self.nv = int(np.sum(self.gidx < self.n))                    # valid (non-padding) local rows: a prefix
         assert np.all(self.gidx[:self.nv] < self.n)
         o = self.ops
+        # ---- the collectives of this handle: RCCL (nccl process groups, or one forced rank) or torch.distributed callbacks
+        user_coll = collectives if isinstance(collectives, _lib.Collectives) else None       # the caller's own (tools/shard_emulate.py)
+        if user_coll is not None:
+            collectives = "user"
+        if collectives == "auto":
+            nccl = in_group and dist.get_backend(group) == "nccl"
+            collectives = "rccl" if (nccl or (self.P == 1 and force_collectives)) and getattr(o, "native_collectives", False) else "torch"
+        self.collectives = collectives
+        if self.general:
+            if collectives == "rccl":
+                uid = [_lib.comm_unique_id() if self.p == 0 else None]
+                if self.P > 1:
+                    dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                o.comm_init(uid[0], self.p, self.P)
+            elif user_coll is not None:
+                o.comm_init_callbacks(user_coll, self.p, self.P)
+            elif self.P > 1:
+                o.comm_init_callbacks(torch_collectives(o, dist, group, self.P), self.p, self.P)
+        # ---- replicated inputs and this rank's buffers (sizes from the library)
         self.x_all = o.to_device(x)
         self.x_loc = o.to_device(x[self.gidx[:self.nv]]) if self.nv > 0 else None
         self.v_host = np.asarray(noise_variances, dtype=np.float64)
+        self.v_dev = o.to_device(self.v_host)
         m = float(np.mean(y))                                        # default prior mean, gp_prior.py:449-458
         zt = np.zeros((TILE, self.np_))
         zt[:self.ncol, :self.n] = (y - m).T
         self.zt = o.to_device(zt)
-        self.A = o.zeros(self.nloc * TILE, self.np_)
         self.zrow = self.nb_max * TILE
-        # diagonal of the local rows: + noise on real rows, 1 on the padding rows of the last block
-        inside = self.gidx < self.np_
-        sel = self.gidx[inside]
-        dv = np.ones(len(sel))
-        dv[sel < self.n] = self.v_host[sel[sel < self.n]]
-        dev = self.A.device
-        self._diag_rows = torch.as_tensor(np.nonzero(inside)[0], device=dev)
-        self._diag_cols = torch.as_tensor(sel, device=dev)
-        self._diag_add = torch.as_tensor(dv, device=dev)
-        self._diag_real = torch.as_tensor(sel < self.n, device=dev)
-        # panels
         self.bnd = list(range(0, self.np_, self.NB)) + [self.np_]
         self.npan = len(self.bnd) - 1
+        d = self._desc = _lib.DistDesc()
+        d.n, d.d, d.ncol, d.panel, d.rank, d.nranks, d.kernel_id = self.n, self.d, self.ncol, self.NB, self.p, self.P, self.kernel_id
+        d.force_general = 1 if (self.general and self.P == 1) else 0
+        ws = o.dist_workspace(d)
+        assert ws[0] == self.nloc * TILE * self.np_ and ws[5] == self.npan
+        self.A = o.zeros(self.nloc * TILE, self.np_)
         self.info_dev = o.zeros(self.npan, dtype=torch.int32)
         self.ld_dev = o.zeros(self.npan)
-        if self.P > 1:
+        self._T = self._recv = [None, None]
+        self._Dfac = self._gather = None
+        if self.general:
             # tall panel: diagonal block + local rows; two of them, so that the trailing update of panel J can keep reading its
-            # rows from the compact panel while the chain of panel J + 1 fills the other one
-            self._T = [o.zeros((self.NB + self.nloc * TILE) * self.NB) for _ in range(2)]
-            self._low = [None, None]
-            self._recv = [o.zeros(self.P * self.nb_max * TILE * self.NB) for _ in range(2)]
-            # the factored NB x NB diagonal blocks, replicated: the panel-local part of every later solve
-            # (N x NB doubles per rank, 0.4 GB at N = 50k)
+            # rows from the compact panel while the chain of panel J + 1 fills the other one; the factored NB x NB diagonal
+            # blocks stay replicated for the later solves (N x NB doubles per rank, 0.4 GB at N = 50k)
+            self._T = [o.zeros(ws[1]) for _ in range(2)]
+            self._recv = [o.zeros(ws[2]) for _ in range(2)]
             self._Dfac = o.zeros(self.npan, self.NB, self.NB)
+            self._gather = o.zeros(ws[4])
+        d.x_all, d.vdiag, d.zt, d.A = self.x_all.data_ptr(), self.v_dev.data_ptr(), self.zt.data_ptr(), self.A.data_ptr()
+        for i in range(2):
+            d.T[i] = self._T[i].data_ptr() if self.general else None
+            d.recv[i] = self._recv[i].data_ptr() if self.general else None
+        d.Dfac = self._Dfac.data_ptr() if self.general else None
+        d.gather = self._gather.data_ptr() if self.general else None
+        d.info_dev, d.logdet_dev = self.info_dev.data_ptr(), self.ld_dev.data_ptr()
         self.keep_factor = True            # False: a likelihood-only evaluation leaves the factored panels out of A (no copy back)
         self.theta = None
         self.alpha = None                  # KVinvY, replicated, (np_, 128) with the first ncol columns in use
-        self._into_tensor = self.P > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl"
-        self.collective_events = None      # set to [] to collect (kind, bytes, start, end) per collective
 
-    # -- collectives (no-ops on one rank) ---------------------------------------------------------
+    # -- collectives of the parts sequenced here (through the handle: RCCL or the bound callbacks; nothing on one rank) ----
     def _all_reduce(self, t):
-        if self.P > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-
-    def _all_gather(self, out, inp):
-        """out (P, k) <- every rank's inp (k,)"""
-        if self._into_tensor:
-            self.dist.all_gather_into_tensor(out.view(-1), inp, group=self.group)
-        else:
-            self.dist.all_gather(list(out.unbind(0)), inp, group=self.group)      # contiguous views (gloo)
-
-    def _timed(self, kind, nbytes, fn, *a):
-        rec = self.collective_events
-        if rec is None or not hasattr(self.ops.chain, "timestamp"):
-            return fn(*a)
-        t0 = self.ops.chain.timestamp()
-        fn(*a)
-        rec.append((kind, nbytes, t0, self.ops.chain.timestamp()))
+        if self.general:
+            self.ops.all_reduce(t)
 
     def collective_summary(self):
-        """{kind: (calls, bytes received per rank, milliseconds on the chain stream)} of the events collected so far."""
-        self.ops.sync()
-        self.ops.chain.sync()
-        out = {}
-        for kind, nbytes, t0, t1 in self.collective_events or []:
-            c, b, ms = out.get(kind, (0, 0.0, 0.0))
-            out[kind] = (c + 1, b + nbytes, ms + t0.elapsed_time(t1))
-        return out
-
-    # -- steps ------------------------------------------------------------------------------------
-    def assemble(self, theta):
-        """This rank's block rows of K+V (full width: the rows are short enough that skipping the upper
-        part is not worth a second code path), identity on the padding, (y-m)^T in the extra block."""
-        o, A = self.ops, self.A
-        top = 0
-        if self.nv > 0:
-            o.kmat_rows(self.kernel_id, self.x_loc, self.x_all, np.asarray(theta, dtype=np.float64), A)
-            top = _lib.pad128(self.nv)
-        if top < self.zrow:
-            A[top:self.zrow].zero_()
-        rows, cols = self._diag_rows, self._diag_cols
-        A[rows, cols] = self.torch.where(self._diag_real, A[rows, cols] + self._diag_add, self._diag_add)
-        A[self.zrow:].copy_(self.zt)
-
-    def _chain(self, J):
-        """Panel J on the chain stream.  The diagonal block goes to every rank (all_reduce of a zero-filled
-        buffer) and is stacked on top of this rank's rows of the panel; the tall panel is factored like a panel
-        of the single-GPU driver (the top block redundantly on every rank -- no pivot traffic inside the panel);
-        the solved rows are all-gathered."""
-        o, A, P, p = self.ops.chain, self.A, self.P, self.p
-        J0, Jend = self.bnd[J], self.bnd[J + 1]
-        w = Jend - J0
-        b0, b1 = J0 // TILE, Jend // TILE
-        n_valid = max(0, min(w, self.n - J0))
-        info, ld = self.info_dev[J:J + 1], self.ld_dev[J:J + 1]
-        with o.stream():
-            if P == 1:                                               # the panel is contiguous in A: in place
-                o.panel_potrf_dev(A[J0:, J0:Jend], w, self.nloc * TILE - J0, n_valid, info, ld)
-                return
-            la = max(0, -(-(b0 - p) // P))                          # local blocks [la, lb) lie in the panel's rows
-            lb = max(0, -(-(b1 - p) // P))
-            L0 = b1 // P                                            # uniform first gathered local block (L0 <= lb)
-            kt = (self.nloc - L0) * TILE                            # rows below: local blocks L0.. and the (y-m)^T block
-            T = self._T[J % 2][:(w + kt) * w].view(w + kt, w)
-            D, low = T[:w], T[w:]
-            D.zero_()
-            mine = None
-            if lb > la:
-                mine = D.view(w // TILE, TILE, w)[la * P + p - b0::P][:lb - la]
-                mine.copy_(A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)))
-            self._timed("all_reduce", 8.0 * w * w, self._all_reduce, D)
-            low.copy_(A[L0 * TILE:, J0:Jend])
-            o.panel_potrf_dev(T, w, w + kt, n_valid, info, ld)
-            self._Dfac[J, :w, :w].copy_(D)
-            self._low[J % 2] = low[(lb - L0) * TILE:]                # this rank's rows below the panel, compact (ld = w)
-            if self.keep_factor:                                    # the solves that follow read the factor from A
-                if mine is not None:
-                    A[la * TILE:lb * TILE, J0:Jend].unflatten(0, (lb - la, TILE)).copy_(mine)
-                A[lb * TILE:, J0:Jend].copy_(self._low[J % 2])
-            else:                                                   # only the (y-m)^T rows are read back at the end
-                A[self.zrow:, J0:Jend].copy_(low[(self.nb_max - L0) * TILE:])
-            if Jend < self.np_:
-                k = (self.nb_max - L0) * TILE
-                self._timed("all_gather", 8.0 * (P - 1) * k * w, self._all_gather,
-                            self._recv[J % 2][:P * k * w].view(P, k * w), low[:k].reshape(-1))
-
-    def _update(self, J, c0, c1):
-        """Apply panel J to block columns [c0, c1) of this rank's rows below the panel (lower tiles only)."""
-        if c1 <= c0:
-            return
-        o, A, P, p = self.ops, self.A, self.P, self.p
-        J0, Jend = self.bnd[J], self.bnd[J + 1]
-        w = Jend - J0
-        b1 = Jend // TILE
-        l0 = max(0, -(-(b1 - p) // P))                              # first local block row below the panel
-        M = (self.nloc - l0) * TILE
-        cb = c0 // TILE
-        if P > 1:
-            L0 = b1 // P
-            k = (self.nb_max - L0) * TILE
-            B = self._recv[J % 2][:P * k * w].view(P * k, w)
-            b_blocks, b_off = self.nb_max - L0, cb - L0 * P
-        else:
-            B, b_blocks, b_off = A[c0:self.zrow, J0:Jend], 0, 0
-        Arows = A[l0 * TILE:, J0:Jend] if P == 1 else self._low[J % 2]      # P > 1: the compact panel (same values, ld = w)
-        o.syrk_rowshard(M, c1 - c0, w, Arows, B, A[l0 * TILE:, c0:], P, l0 * P + p - cb,
-                        P, b_blocks, b_off)
-
-    def factor(self):
-        """Blocked right-looking Cholesky of the sharded matrix with one panel of look-ahead, all enqueued
-        without a host round trip; the appended rows come out as (L^-1 (y-m))^T."""
-        o, bnd = self.ops, self.bnd
-        o.fork()
-        self._chain(0)
-        for J in range(self.npan - 1):
-            o.join()                                                # panel J factored and gathered
-            self._update(J, bnd[J + 1], bnd[J + 2])                 # next panel's columns first ...
-            o.fork()
-            self._chain(J + 1)                                      # ... so its chain overlaps the rest
-            self._update(J, bnd[J + 2], self.np_)
-        o.join()
+        """{kind: (calls, bytes received per rank, milliseconds on their stream)} since the last call (option "profile")."""
+        return self.ops.comm_profile() if hasattr(self.ops, "comm_profile") else {}
 
     def set_targets(self, ymean, noise_variances):
         """Replace (y - m) (n, ncol) and the noise variances (n,) -- the O(N) host-side results of the mean and noise
@@ -358,15 +285,12 @@ class ShardedGP:
         zt[:self.ncol, :self.n] = ymean.T
         self.zt.copy_(self.ops.to_device(zt))
         self.v_host = np.asarray(noise_variances, dtype=np.float64)
-        sel = self._diag_cols.cpu().numpy()
-        dv = np.ones(len(sel))
-        dv[sel < self.n] = self.v_host[sel[sel < self.n]]
-        self._diag_add.copy_(self.ops.to_device(dv))
+        self.v_dev.copy_(self.ops.to_device(self.v_host))
 
     def _diag_block(self, J):
         """the factored diagonal block of panel J (lower triangle), on this rank"""
         J0, Jend = self.bnd[J], self.bnd[J + 1]
-        if self.P == 1:
+        if not self.general:
             return self.A[J0:Jend, J0:Jend]
         return self._Dfac[J, :Jend - J0, :Jend - J0]
 
@@ -380,28 +304,22 @@ class ShardedGP:
         return la, lb, la * self.P + self.p - b0, J0, Jend
 
     def evaluate(self, theta, want_alpha=False, keep_factor=True):
-        """One pass of the path on the sharded matrix: assemble, factor (the forward solve rides along), optionally
-        the backward solve.  Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated.
+        """One pass of the path on the sharded matrix (fvgp_hip_loglik_dist: assemble, factor, the forward solve riding
+        along), optionally the backward solve.  Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated.
         keep_factor=False (likelihood only): the factored panels are not copied back into the matrix, so no solve,
         gradient or posterior can follow this evaluation."""
-        torch = self.torch
         self.keep_factor = bool(keep_factor or want_alpha)
+        self._desc.keep_factor = 1 if self.keep_factor else 0
         with self.ops.stream():
-            self.assemble(theta)
-            self.factor()
-            z = self.A[self.zrow:self.zrow + self.ncol, :self.n]
-            out = torch.cat([(z * z).sum().reshape(1), self.ld_dev.sum().reshape(1), self.info_dev.to(torch.float64)]).cpu().numpy()
-        bad = np.nonzero(out[2:])[0]
-        if len(bad):
-            J = int(bad[0])
+            ll, logdet, quad, info = self.ops.loglik_dist(self._desc, np.asarray(theta, dtype=np.float64))
+        if info != 0:
             self.theta = None
-            raise np.linalg.LinAlgError(f"{self.bnd[J] + int(out[2 + J])}-th leading minor of the array is not positive definite")
+            raise np.linalg.LinAlgError(f"{info}-th leading minor of the array is not positive definite")
         self.theta = np.array(theta, dtype=np.float64) if self.keep_factor else None
         self.alpha = None
-        quad, logdet = float(out[0]) / self.ncol, float(out[1])
         if want_alpha:
             self.solve_backward()
-        return -0.5 * (quad + logdet + self.n * math.log(2.0 * math.pi)), logdet, quad
+        return ll, logdet, quad
 
     def log_likelihood(self, theta):
         """GPMarginalLikelihood.log_likelihood(theta) (gp_marginal_likelihood.py:137-179) on the sharded matrix.
@@ -498,29 +416,50 @@ class ShardedGP:
             o.sync()
         return mean[:npred, :self.ncol].cpu().numpy(), (None if S is None else S[:npred, :npred].cpu().numpy())
 
-    def gradient(self, component=0):
+    def _inverse_factor_rows(self):
+        """this rank's rows of inv(L) (rows x np_), by the distributed forward solve of the identity"""
+        o, torch = self.ops, self.torch
+        rows = self.nb_max * TILE
+        W = o.zeros(rows, self.np_)
+        inside = self.gidx < self.np_
+        li = torch.as_tensor(np.nonzero(inside)[0], device=W.device)
+        W[li, torch.as_tensor(self.gidx[inside], device=W.device)] = 1.0          # this rank's rows of the identity
+        self.forward_trsm(W, triangular=True)
+        return W
+
+    def gradient(self, component=0, slab=2048, want_diag=False):
         """1/2 (tr(KV^-1 dK_i) - b^T dK_i b), b = KVinvY[:, component] (gp_marginal_likelihood.py:262-300) for the
-        kernel-owned hyperparameters.  inv(L) is built by rows with the distributed forward solve; each rank forms the
-        Gram matrix of ITS rows (the sum over ranks is KV^-1, never formed) and runs the fused trace pass on it; the
-        (H,) partial results are summed over the ranks."""
+        kernel-owned hyperparameters.  inv(L) is built by rows with the distributed forward solve (N^2 / P doubles per
+        rank); the Gram matrix of the rank's rows (the sum over ranks is KV^-1, never formed) is walked in column slabs of
+        `slab` columns -- an np_ x slab buffer, traced by the fused pass (fvgp_hip_grad_trace_cols) and dropped -- so the
+        per-rank memory falls with the number of ranks; the (H,) partial results are summed over the ranks.
+        want_diag: also return diag(KV^-1) (n,), replicated -- the row sums of squares of inv(L)'s columns, which the
+        gradients of noise-function hyperparameters need (gp_marginal_likelihood.py:262-267)."""
         assert self.theta is not None, "evaluate() first"
         o, torch = self.ops, self.torch
         if self.alpha is None:
             self.solve_backward()
         rows = self.nb_max * TILE
+        slab = max(TILE, (int(slab) // TILE) * TILE)
         with o.stream():
-            W = o.zeros(rows, self.np_)
-            inside = self.gidx < self.np_
-            li = torch.as_tensor(np.nonzero(inside)[0], device=W.device)
-            W[li, torch.as_tensor(self.gidx[inside], device=W.device)] = 1.0          # this rank's rows of the identity
-            self.forward_trsm(W, triangular=True)
-            Gp = o.zeros(self.np_, self.np_)
-            o.gemm(1, 1, 1, self.np_, self.np_, rows, 1.0, W, W, 0.0, Gp)
-            del W
+            W = self._inverse_factor_rows()
             nt = self.np_ // TILE
-            partial = o.zeros(nt * (nt + 1) // 2 * (self.d + 2))
+            partial = o.zeros(nt * (slab // TILE) * (self.d + 2))
             b = self.alpha[:, component] if self.p == 0 else None
-            g = o.grad_trace(self.kernel_id, self.x_all, self.theta, Gp, b, partial)
-            gt = torch.as_tensor(g, device=Gp.device)
+            g = np.zeros(len(self.theta))
+            Gs = o.zeros(self.np_, slab)
+            for c0 in range(0, self.np_, slab):
+                wc = min(slab, self.np_ - c0)
+                # rows >= c0 of the slab: (W^T W)[c0:, c0:c0+wc] = W[:, c0:]^T W[:, c0:c0+wc]
+                o.gemm(1, 1, 0, self.np_ - c0, wc, rows, 1.0, W[:, c0:], W[:, c0:c0 + wc], 0.0, Gs[c0:, :wc])
+                if c0 < self.n:
+                    g += o.grad_trace_cols(self.kernel_id, self.x_all, self.theta, Gs, c0, min(wc, self.n - c0), b, partial)
+            gt = torch.as_tensor(g, device=Gs.device)
             self._all_reduce(gt)
-            return gt.cpu().numpy()
+            out = gt.cpu().numpy()
+            if not want_diag:
+                return out
+            dg = o.zeros(self.np_)
+            o.colsumsq(W, dg)
+            self._all_reduce(dg)
+            return out, dg[:self.n].cpu().numpy()

@@ -472,8 +472,6 @@ class GP(ValidationMixin):
         H, n = self._H, self.point_number
         if self._sharded:
             return self._gradient_sharded(hyperparameters, component)
-        if self._native is None and self._kernel_grad_callable is None:
-            raise NotImplementedError("gradient with a host kernel callable needs kernel_function_grad")
         KV, aw = self._scratch()
         if self._work2 is None:
             self._work2 = H.empty(self._np, self._np)
@@ -484,16 +482,14 @@ class GP(ValidationMixin):
             g = H.loglik_grad(self._native.kernel_id, self._x_dev, hps, aw, ncol, component, KV, self._work2)
             diag_inv = None
         else:
+            # host kernel callable: dK/dtheta_i exists as numbers on the host (user gradient, or the reference's central
+            # differences); one N^2 upload per direction, the trace against KV^-1 on the device (fvgp_hip_trace_dot)
             H.potri(KV, n, self._work2)
             H.symmetrize(KV, n)
-            H.sync()
-            Winv = KV[:n, :n]
             b_dev = aw[:n, component]
-            dK = self._kernel_grad_callable(self.x_data, self.x_data, hps)
             g = np.zeros(len(hps))
-            for i in range(len(hps)):
-                dKi = H.to_device(dK[i])
-                g[i] = 0.5 * float(((Winv * dKi).sum() - b_dev @ (dKi @ b_dev)).item())
+            for i, dKi in enumerate(self._host_kernel_grads(hps)):
+                g[i] = 0.5 * H.trace_dot(KV, H.to_device(dKi), b_dev, n)
             diag_inv = None
         g = np.asarray(g, dtype=np.float64)
         if len(g) < len(hps):
@@ -506,11 +502,10 @@ class GP(ValidationMixin):
                 # matrix-valued noise derivative (gp_marginal_likelihood.py:262-267): 1/2 (tr(KV^-1 dV_i) - b^T dV_i b),
                 # KV^-1 (lower, on the device by now) mirrored once
                 H.symmetrize(KV, n)
-                Winv, bd = KV[:n, :n], aw[:n, component]
+                bd = aw[:n, component]
                 for i in range(len(hps)):
                     if np.any(dV[i] != 0.0):
-                        dVi = H.to_device(dV[i])
-                        g[i] += 0.5 * float(((Winv * dVi).sum() - bd @ (dVi @ bd)).item())
+                        g[i] += 0.5 * H.trace_dot(KV, H.to_device(dV[i]), bd, n)
             elif np.any(dV != 0.0):
                 H.sync()
                 b = aw[:n, component].cpu().numpy()
@@ -528,23 +523,53 @@ class GP(ValidationMixin):
 
     def _gradient_sharded(self, hyperparameters, component):
         """The same gradient on the row-sharded factor (dist.ShardedGP.gradient); mean-owned hyperparameters as in the
-        single-GPU path (:281,301-308).  Noise-function hyperparameters would need diag(KV^-1), which no rank holds."""
-        if self._noise_callable is not None:
-            raise NotImplementedError("gradients of noise-function hyperparameters are not available in the row-sharded mode")
+        single-GPU path (:281,301-308).  Noise-function hyperparameters (diagonal noise models, :262-267) take diag(KV^-1)
+        from the ranks' rows of inv(L): column sums of squares, summed over the ranks -- no N x N buffer anywhere."""
         n = self.point_number
         if hyperparameters is None:
             hps, sh = self._hps, self._sh
         else:
             hps = np.asarray(hyperparameters, dtype=np.float64)
             sh = self._evaluate_sharded(hps, state=False)[4]
-        g = np.asarray(sh.gradient(component), dtype=np.float64)
+        dV = self._noise_grad(hps) if self._noise_callable is not None else None
+        if dV is not None and np.ndim(dV) != 2:
+            raise NotImplementedError("the row-sharded mode takes a diagonal noise model")
+        if dV is not None and np.any(dV != 0.0):
+            g, diag_inv = sh.gradient(component, want_diag=True)
+        else:
+            g, diag_inv = sh.gradient(component), None
+        g = np.asarray(g, dtype=np.float64)
         if len(g) < len(hps):
             g = np.concatenate([g, np.zeros(len(hps) - len(g))])
+        if diag_inv is not None:
+            b = sh.alpha[:n, component].cpu().numpy()
+            g = g + 0.5 * (dV @ (diag_inv - b * b))
         if self._mean_callable is not None:
             b = sh.alpha[:n, component].cpu().numpy()
             gm = -(self._mean_grad(hps) @ b)
             g = np.where(gm == 0.0, g, 0.0) + gm
         return g
+
+    def _host_kernel_grads(self, hps):
+        """dK/dtheta_i, i = 0 .. H-1, one (N, N) host array at a time, as GPprior selects it (gp_prior.py:65-74): the user's
+        kernel_function_grad -- all directions in one call, or called per direction under ram_economy (:236-240) -- else
+        central differences of the kernel itself with the reference's step, eps = 1e-8 (:438-447)."""
+        x = self.x_data
+        if self._kernel_grad_callable is not None:
+            if self.ram_economy:
+                for i in range(len(hps)):
+                    yield np.ascontiguousarray(self._kernel_grad_callable(x, x, hps, i), dtype=np.float64)
+            else:
+                dK = self._kernel_grad_callable(x, x, hps)
+                for i in range(len(hps)):
+                    yield np.ascontiguousarray(dK[i], dtype=np.float64)
+            return
+        eps = 1e-8
+        for i in range(len(hps)):
+            hp, hm = np.array(hps, dtype=np.float64), np.array(hps, dtype=np.float64)
+            hp[i] += eps
+            hm[i] -= eps
+            yield (self._host_kernel(x, x, hp) - self._host_kernel(x, x, hm)) / (2.0 * eps)
 
     def _central_fd(self, f, hps):
         """(H, N) central difference with step 1e-6 -- gp_likelihood.py:123-133, gp_prior.py:460-469."""
@@ -601,18 +626,21 @@ class GP(ValidationMixin):
             H.sync()
             return mean.cpu().numpy(), (None if S is None else S[:P, :P].cpu().numpy())
         # slow path: host cross-covariances, device solves
-        k = self._host_kernel(self.x_data, x_pred, hps)
-        kdev = H.to_device(k)
-        mean_h = (kdev.T @ alpha[:n]).cpu().numpy()
+        kx.zero_()
+        kx[:n, :P] = H.to_device(self._host_kernel(self.x_data, x_pred, hps))
+        aw = H.zeros(self._np, _lib.pad128(ncol))
+        aw[:n, :ncol] = alpha[:n]
+        mw = H.empty(Pp, _lib.pad128(ncol))
+        H.gemm(1, 1, 0, Pp, _lib.pad128(ncol), self._np, 1.0, kx, aw, 0.0, mw)           # k^T KVinvY
+        mean_h = mw[:P, :ncol].cpu().numpy()
         if not want_cov:
             return mean_h, None
-        kx.zero_()
-        kx[:n, :P] = kdev
         H.trsm_lower(L, n, kx, Pp)
+        S = H.zeros(Pp, Pp)
+        S[:P, :P] = H.to_device(self._host_kernel(x_pred, x_pred, hps))
+        H.gemm(1, 1, 0, Pp, Pp, self._np, -1.0, kx, kx, 1.0, S)                            # kk - v^T v, v = L^-1 k
         H.sync()
-        v = kx[:n, :P]
-        S = H.to_device(self._host_kernel(x_pred, x_pred, hps)) - v.T @ v
-        return mean_h, S.cpu().numpy()
+        return mean_h, S[:P, :P].cpu().numpy()
 
     def _variance_from_inverse(self, x_pred):
         H, n = self._H, self.point_number

@@ -133,6 +133,55 @@ int fvgp_hip_trsm_lower_t(fvgp_handle *h, const double *L, int64_t n, int64_t ld
  *                q, q + b_ranks, ...; tile column tj reads cyclic block tj + b_off
  *                (b_ranks = 1, b_off = 0: plain row order). */
 int fvgp_hip_panel_trsm(fvgp_handle *h, const double *D, int64_t nd, int64_t ldd, double *P, int64_t rows, int64_t ldp);
+
+/* ---- row-sharded (multi-GPU) evaluation: one process per GPU, RCCL over xGMI ---------------------------------
+ * Stands in for the reference's distribution switch and scheduler: GP(..., gp2Scale=True, dask_client=...) (gp.py:419-439),
+ * GPprior._gp2Scale_covariance / distributed_covariance (gp_prior.py:324-347, gp2Scale_covariance.py:313-431) and the
+ * broadcast of x (gp_prior.py:319-322) -- with a dense factorisation behind it.
+ *
+ * Collectives are function pointers on device buffers, enqueued on `stream`: fvgp_hip_comm_init binds RCCL
+ * (ncclAllGather / ncclAllReduce on a communicator built from the 128-byte ncclUniqueId of fvgp_hip_comm_unique_id, which
+ * rank 0 hands to the others by any means -- torch.distributed's store on the Python side); fvgp_hip_comm_init_callbacks
+ * binds the caller's own (the CPU tests bind gloo).  bytes = what this rank receives (bookkeeping for the timings). */
+typedef struct fvgp_collectives {
+    void *ctx;
+    int (*all_gather)(void *ctx, const double *send, double *recv, int64_t count_per_rank, void *stream);    /* recv: nranks x count */
+    int (*all_reduce_sum)(void *ctx, double *buf, int64_t count, void *stream);                             /* in place */
+} fvgp_collectives;
+int fvgp_hip_comm_unique_id(void *out128_host);
+int fvgp_hip_comm_init(fvgp_handle *h, const void *unique_id128_host, int rank, int nranks);
+int fvgp_hip_comm_init_callbacks(fvgp_handle *h, const fvgp_collectives *cb, int rank, int nranks);
+int fvgp_hip_comm_destroy(fvgp_handle *h);
+/* the handle's collectives on its stream (the parts of the sharded path that are sequenced by the caller: backward solve,
+ * posterior, gradient -- gp_kv.py:574-593, gp_posterior.py:139-288 on the distributed factor) */
+int fvgp_hip_all_reduce(fvgp_handle *h, double *buf, int64_t count);
+int fvgp_hip_all_gather(fvgp_handle *h, const double *send, double *recv, int64_t count_per_rank);
+/* out[0..1] = calls, out[2..3] = bytes received, out[4..5] = milliseconds on the chain stream of the all_gather /
+ * all_reduce calls since the last call of this function (option "profile" on); out needs 6 doubles */
+int fvgp_hip_comm_profile(fvgp_handle *h, double *out6_host);
+
+/* One GP sharded over the ranks.  Every buffer is the caller's (sizes in doubles from fvgp_hip_dist_workspace):
+ *   x_all (n, d) and vdiag (n) replicated; zt (128, np): (y-m)^T in the first ncol rows, zeros below;
+ *   A ((nb_max + 1) * 128, np): this rank's block rows (local block l = global block l * nranks + rank) and the block of
+ *   right-hand-side rows; T[2], recv[2], Dfac, gather: panel buffers (nranks > 1 or force_general); info_dev (npan ints)
+ *   and logdet_dev (npan doubles): per-panel results, on the device.
+ * np = padded_dim(n), nb_max = ceil(np / 128 / nranks), npan = ceil(np / panel). */
+typedef struct fvgp_dist_desc {
+    int64_t n; int d; int ncol; int64_t panel; int rank, nranks; int kernel_id;
+    const double *x_all; const double *vdiag; const double *zt;
+    double *A; double *T[2]; double *recv[2]; double *Dfac; double *gather;
+    int *info_dev; double *logdet_dev;
+    int keep_factor;      /* 0: likelihood only -- the factored panels are not copied back into A (no solve can follow) */
+    int force_general;    /* 1: a single rank still takes the panel-buffer / collective path (exercises RCCL on one GPU) */
+} fvgp_dist_desc;
+/* out[0] A, [1] each T, [2] each recv, [3] Dfac, [4] gather (doubles); [5] = npan */
+int fvgp_hip_dist_workspace(const fvgp_dist_desc *d, int64_t *out6);
+/* GPMarginalLikelihood.log_likelihood(theta) (gp_marginal_likelihood.py:137-179) on the sharded matrix: assembly of the
+ * rank's rows, blocked right-looking Cholesky with one panel of look-ahead (per panel: all-gather of the diagonal block from
+ * its owners, factorisation of the tall panel, all-gather of the panel factor, trailing update of the rank's block rows),
+ * the forward solve riding along.  out_host = {log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol}, replicated;
+ * *info_host = dpotrf's info (global index of the first non-positive pivot) or 0.  One host synchronisation. */
+int fvgp_hip_loglik_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *theta_host, int ntheta, double *out_host, int *info_host);
 /* one tall panel T (rows x w, row-major, ldt): the w x w diagonal block on top (lower triangle; the first
  * n_valid rows are data, the rest identity padding), this rank's rows of the panel below it.  Factors the top
  * block and solves the rows below against it, 128 columns at a time (leaf, TRSM by the inverted diagonal tile,
@@ -174,6 +223,13 @@ int fvgp_hip_loglik_grad(fvgp_handle *h, int kernel_id, const double *x, int64_t
 int fvgp_hip_grad_trace(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
                         const double *theta_host, int ntheta, const double *W, int64_t ldw,
                         const double *b_or_null, int64_t ldb, double *partial, double *grad_host);
+/* the same pass over a SLAB of columns [col0, col0 + ncols) of the symmetric matrix (col0 % 128 == 0): W (n, ldw) holds those
+ * columns only, entries with row >= column are read.  The row-sharded gradient walks its partial Gram matrix of inv(L) slab by
+ * slab, so that no rank ever holds an N x N buffer; the slabs' results add up to fvgp_hip_grad_trace's.
+ * partial: ceil(n/128) * ceil(ncols/128) * ntheta doubles (device scratch). */
+int fvgp_hip_grad_trace_cols(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                             const double *theta_host, int ntheta, const double *W, int64_t ldw, int64_t col0, int64_t ncols,
+                             const double *b, int64_t ldb, double *partial, double *grad_host);
 
 /* posterior: GPposterior.posterior_mean / posterior_covariance  gp_posterior.py:139-182,229-288
  *   L: factor (padded), alpha: KVinvY (padded_dim(n), ncol)
@@ -218,6 +274,9 @@ int fvgp_hip_add_lower(fvgp_handle *h, double *A, int64_t n, int64_t lda, const 
  * device vector with stride ldb or NULL.  Fixed-order reduction. */
 int fvgp_hip_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const double *D, int64_t ldd, const double *b, int64_t ldb,
                        int64_t n, double *out_host);
+/* out[p] = sum_i V[i][p]^2, p < ncols: the column sums of squares of a rank's rows of inv(L) are its share of diag(KV^-1)
+ * (gradients of noise-function hyperparameters, gp_marginal_likelihood.py:262-267, in the row-sharded mode) */
+int fvgp_hip_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t ncols, double *out);
 /* mirror the lower triangle into the upper (for exporting K / KV^-1 to numpy) */
 int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda);
 

@@ -16,18 +16,20 @@
  *   loglik      gp_marginal_likelihood.py:137-179, gp_kv.py:574-593
  *   grad        gp_marginal_likelihood.py:224-309 in the trace form 1/2 sum (KVinv - b b^T) o dK
  *   posterior   gp_posterior.py:139-182,229-288
- * Not provided (GPU-only scheduling pieces): streams, *_dev variants, the row-shard building blocks, MFMA probes.
+ * The row-sharded evaluation (fvgp_hip_loglik_dist and the collective entries) is in fvgp_cpu_dist.cpp: the SAME driver the
+ * HIP library runs (fvgp_amd/csrc/dist_driver.h) over host loops.
+ * Not provided (GPU-only scheduling pieces): streams, potrf_dev, MFMA probes.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "../../include/fvgp_hip.h"
+#include "fvgp_cpu.h"
 
-struct fvgp_handle { int device; int64_t outer_block; };
 static char g_err[256] = "";
 static void set_err(const char *s) { snprintf(g_err, sizeof g_err, "%s", s); }
+void fvgp_cpu_set_err(const char *s) { set_err(s); }
 static int64_t pad128(int64_t n) { return (n + FVGP_TILE - 1) / FVGP_TILE * FVGP_TILE; }
 
 int fvgp_hip_version(void) { return 100; }
@@ -40,6 +42,7 @@ int fvgp_hip_create(fvgp_handle **out, int device, void *stream) {
     if (device != 0) { set_err("no such device"); return -2; }
     *out = (fvgp_handle *)calloc(1, sizeof(fvgp_handle));
     (*out)->outer_block = 1024;
+    (*out)->coll_nranks = 1;
     return 0;
 }
 int fvgp_hip_destroy(fvgp_handle *h) { free(h); return 0; }

@@ -153,20 +153,90 @@ def test_ranks_sharing_one_gpu_over_gloo(tmp_path, world, n, panel):
         np.testing.assert_allclose(ll, ref, rtol=1e-10)
 
 
-def test_reserved_compute_units_give_the_same_numbers():
-    """The chain on its own CU-masked stream (HipOps(reserve_cus=32)) is a scheduling choice only."""
-    from fvgp_amd.dist import ShardedGP, HipOps
-    n = 2500
+WORKER_RCCL = r'''
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from conftest import synth
+from fvgp_amd.dist import ShardedGP
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda:0"))
+n, d = {n}, 3
+x, y = synth(n, d)
+theta = np.array([1.0, 0.3, 0.3, 0.3])
+gp = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel={panel}, force_collectives=True)
+assert gp.collectives == "rccl" and gp.general
+gp.ops.set_option("profile", 1)
+ll = [gp.log_likelihood(theta * (1 + 0.02 * t))[0] for t in range(2)]
+prof = gp.collective_summary()
+ev = gp.evaluate(theta, want_alpha=True)
+xp = np.random.default_rng(3).random((150, d))
+mean, S = gp.posterior(xp)
+g = gp.gradient()
+t = torch.ones(4, dtype=torch.float64, device="cuda:0")
+dist.all_reduce(t)                               # torch's own RCCL communicator next to the library's
+print("RESULT " + json.dumps(dict(ll=ll, prof=prof, ev=list(ev), alpha=gp.alpha[:n, :1].cpu().numpy().ravel().tolist(),
+                                  mean=mean.ravel().tolist(), S=S.tolist(), g=g.tolist(), t=float(t.sum().item()))))
+dist.destroy_process_group()
+'''
+
+
+def test_one_rank_through_rccl(tmp_path):
+    """The whole multi-rank code path on ONE GPU with the collectives really issued through RCCL (ncclCommInitRank on one
+    rank, ncclAllGather / ncclAllReduce on the chain / main stream): ShardedGP(force_collectives=True) under
+    backend="nccl".  Panel buffers, gather of the diagonal block, all-gather of the panel factor, replicated diagonal
+    blocks in the solves -- against the oracle."""
+    n, panel = 2500, 512
+    out = _spawn(tmp_path, WORKER_RCCL.format(root=ROOT, n=n, panel=panel), 1)
     x, y = synth(n, 3)
     nv = np.full(n, 0.01)
     theta = np.array([1.0, 0.3, 0.3, 0.3])
-    ops = HipOps(reserve_cus=32)
-    gp = ShardedGP(x, y, nv, kernel="rbf_ard", panel=512, rank=0, world=1, ops=ops)
-    got = [gp.log_likelihood(theta * (1 + 0.05 * t))[0] for t in range(3)]
-    for t, ll in enumerate(got):
-        ref, _ = orc.log_likelihood_once(x, y, nv, theta * (1 + 0.05 * t), "rbf_ard")
+    for t, ll in enumerate(out["ll"]):
+        ref, _ = orc.log_likelihood_once(x, y, nv, theta * (1 + 0.02 * t), "rbf_ard")
         np.testing.assert_allclose(ll, ref, rtol=1e-10)
-    ops.close()
+    calls, nbytes, ms = out["prof"]["all_gather"]
+    assert calls == 2 * (2 * 5 - 1) and ms > 0.0               # per evaluation: 5 diagonal blocks + 4 panel factors
+    ref = orc.OracleGP(x, y, theta, nv, kernel="rbf_ard")
+    np.testing.assert_allclose(out["ev"][0], ref.log_likelihood(), rtol=1e-10)
+    assert np.max(np.abs(np.array(out["alpha"]) - ref.KVinvY[:, 0])) <= 1e-8 * np.max(np.abs(ref.KVinvY))
+    xp = np.random.default_rng(3).random((150, 3))
+    np.testing.assert_allclose(np.array(out["mean"]) + np.mean(y), ref.posterior_mean(xp)["m(x)"], rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(np.array(out["S"]) - ref.posterior_covariance(xp)["S"])) <= 1e-10
+    g_ref = ref.neg_log_likelihood_gradient(theta)
+    np.testing.assert_allclose(out["g"], g_ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(g_ref)))
+    assert out["t"] == 4.0
+
+
+def test_forced_general_path_matches_the_in_place_path():
+    """One rank without a process group: force_collectives routes through the panel buffers with copy collectives; the
+    result is the in-place path's."""
+    from fvgp_amd.dist import ShardedGP
+    n = 3000
+    x, y = synth(n, 3)
+    nv = np.full(n, 0.01)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    a = ShardedGP(x, y, nv, kernel="rbf_ard", panel=512, rank=0, world=1)
+    b = ShardedGP(x, y, nv, kernel="rbf_ard", panel=512, rank=0, world=1, force_collectives=True, collectives="torch")
+    la, lb = a.log_likelihood(theta), b.log_likelihood(theta)
+    np.testing.assert_allclose(la, lb, rtol=1e-12)
+
+
+def test_sharded_noise_function_gradient_uses_the_distributed_diagonal():
+    """Gradients of noise-function hyperparameters in the row-sharded mode (diag(KV^-1) from the ranks' rows of inv(L),
+    gp_marginal_likelihood.py:262-267) against the single-GPU facade."""
+    import warnings
+    import fvgp_amd
+    n = 1500
+    x, y = synth(n, 3)
+    th = np.array([1.0, 0.3, 0.3, 0.3, 0.02])
+    noise = lambda xx, h: np.full(len(xx), h[4]) * (1.0 + xx[:, 0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = fvgp_amd.GP(x, y, init_hyperparameters=th, kernel_function="rbf_ard", noise_function=noise)
+        gp = fvgp_amd.GP(x, y, init_hyperparameters=th, kernel_function="rbf_ard", noise_function=noise,
+                         args={"process_group": True, "shard_panel": 256, "shard_rank": 0, "shard_world": 1})
+    g_ref, g = ref.neg_log_likelihood_gradient(th), gp.neg_log_likelihood_gradient(th)
+    np.testing.assert_allclose(g, g_ref, rtol=1e-7, atol=1e-8 * np.max(np.abs(g_ref)))
 
 
 def test_bench_multi_rank_line_is_the_sharded_evaluation(tmp_path):

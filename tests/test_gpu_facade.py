@@ -162,6 +162,37 @@ def test_host_callable_kernel_slow_path_and_custom_mean_noise():
     np.testing.assert_allclose(g, fd, rtol=2e-5, atol=1e-4)
 
 
+def test_callable_kernel_without_gradient_takes_the_reference_finite_differences():
+    """SURVEY 8 row a13, third route: a kernel callable with no kernel_function_grad is differentiated by central
+    differences with eps = 1e-8 (gp_prior.py:438-447; one direction at a time under ram_economy, :236-240).  G1 holds the
+    gradient the REFERENCE computes this way; the host callable here is the oracle's expression-for-expression kernel, so
+    the difference matrices are the reference's and only KV^-1 and the trace come from the device."""
+    import fvgp_amd
+    fx = load_golden("G1_rbf_n500_d1.npz")
+    x, y, th, nv = fx["x"], fx["y"], fx["theta"], fx["noise_variances"]
+    calls = []
+
+    def grad_dir(x1, x2, h, direction):                 # the ram_economy signature of kernel_function_grad
+        calls.append(direction)
+        return orc.rbf_ard_grad(x1, x2, h)[direction]
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function=lambda a, b, h: orc.rbf_ard(a, b, h))
+        gp_re = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function=lambda a, b, h: orc.rbf_ard(a, b, h),
+                            ram_economy=True)
+        gp_dir = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function=lambda a, b, h, args: orc.rbf_ard(a, b, h),
+                             kernel_function_grad=grad_dir, ram_economy=True)
+    g = gp.neg_log_likelihood_gradient(th)
+    # the reference's own finite-difference result; the noise of an eps = 1e-8 difference quotient is ~1e-8 per entry of dK
+    np.testing.assert_allclose(g, fx["grad_fd"], rtol=1e-6)
+    np.testing.assert_allclose(gp_re.neg_log_likelihood_gradient(th), g, rtol=1e-12)
+    np.testing.assert_allclose(gp.neg_log_likelihood_gradient(), g, rtol=1e-9)       # hyperparameters=None: the state
+    # user gradient, one direction per call (4-argument kernel: args is passed through)
+    np.testing.assert_allclose(gp_dir.neg_log_likelihood_gradient(th), fx["grad"], rtol=1e-8)
+    assert calls == [0, 1]
+
+
 def test_matrix_valued_noise_model():
     """A noise function that returns a 2-d matrix: KV = K + V (gp_kv.py:654-657), gradient with the 3-d noise derivative
     (gp_marginal_likelihood.py:262-267), add_noise with the matrix at the prediction points (gp_posterior.py:554-569)."""
