@@ -50,6 +50,7 @@ int fvgp_hip_create(fvgp_handle **out, int device, void *stream) {
     HIPCHK(hipMalloc((void **)&h->red, RED_SLOTS * sizeof(double)));
     HIPCHK(hipMalloc((void **)&h->dinfo, 64));
     HIPCHK(hipHostMalloc((void **)&h->hpin, RED_SLOTS * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     *out = h;
     return 0;
 }
@@ -136,6 +137,8 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "k128_kernels")) { h->k128_kernels = value ? 1 : 0; return 0; }
     if (!strcmp(key, "block_inverses")) { h->block_inverses = value ? 1 : 0; return 0; }
     if (!strcmp(key, "potri_kminor")) { h->potri_kminor = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "update_reserve")) { h->update_reserve = (int)value; return 0; }
+    if (!strcmp(key, "reserve_rows")) { h->reserve_rows = value; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
     return -2;
 }
@@ -343,6 +346,7 @@ static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, i
     s.A = A + c0 * lda + J0; s.lda = lda;
     s.B = A + c0 * lda + J0; s.ldb = lda;
     s.C = A + c0 * lda + c0; s.ldc = lda;
+    if (role == 1 && (h->reserve_rows < 0 || np - c0 <= h->reserve_rows)) s.reserve_cus = h->update_reserve;
     if (big_kernel) *big_kernel = !gemm_takes_small_tiles(h, s);
     return launch_gemm(h, s);
 }
@@ -1164,6 +1168,7 @@ int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, cons
     g.bc_ranks = b_ranks; g.bc_blocks = b_blocks; g.bc_off = b_off;
     g.M = M; g.N = N; g.K = K; g.alpha = -1.0; g.beta = 1.0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    if (h->reserve_rows < 0 || M * scale <= h->reserve_rows) g.reserve_cus = h->update_reserve;
     if (!h->profile || gemm_takes_small_tiles(h, g)) return launch_gemm(h, g);      // only launches of the kernel the roofline names are timed
     // timed with events on the launch stream; algorithmic flops = the tiles with tj <= ti * scale + off
     while (h->rs_ev.size() < h->rs_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->rs_ev.push_back(e); }

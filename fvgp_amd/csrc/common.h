@@ -67,6 +67,11 @@ struct fvgp_handle {
     unsigned long *leaf_stamps = nullptr;   // diagnostics (option "leaf_stamps" = device pointer): phase timestamps of the leaf kernel
     std::map<TileTabKey, TileTab> tile_tabs;   // device-resident, freed with the handle
     int tile_tables = 1;              // plain launches of the 128-tile kernels take the XCD-balanced tile table instead of the formula map
+    // persistent trailing update: > 0 = the update launches 2 x (n_cus - update_reserve) workgroups that pull tiles from per-XCD
+    // queues, so `update_reserve` compute units' worth of slots stay free for the panel chain for the whole launch
+    int update_reserve = 0, n_cus = 256;
+    int64_t reserve_rows = 0;         // ... applied while at most this many rows remain to be updated (0: never, < 0: always)
+    int *tile_queue = nullptr; unsigned tile_queue_next = 0;
     int gemm_probe = 0;               // fvgp_hip_gemm launches a K-loop timing probe instead (diagnostics)
     int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel
@@ -118,6 +123,7 @@ struct GemmDesc {
     // holding the blocks q, q + bc_ranks, ...; output tile column tj reads block tj + bc_off of that cyclic order
     int bc_ranks = 1, bc_blocks = 0, bc_off = 0;
     int probe = 0;                    // timing probe variant of the K loop (diagnostics only)
+    int reserve_cus = 0;              // role 1: persistent launch that leaves this many compute units' worth of slots free
     int direct = 0;                   // (M,K) x (N,K) only: operands straight from global memory into MFMA registers (no LDS)
     int rev_m = 0;                    // walk the tile rows from the last to the first (per-tile K grows with ti: longest first)
     // split-K for products with few output tiles and a long K (S -= V^T V of the posterior: 64 tiles, K = N): `split`

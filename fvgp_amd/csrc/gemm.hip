@@ -55,6 +55,7 @@ struct GemmArgs {
     long kb0, kbi, kbj, ke0, kei, kej;
     long ntiles;
     const int *tab;                   // balanced block -> tile table ((ti << 16) | tj, -1 = no tile), or nullptr: formula
+    int *queue;                       // persistent launch (needs tab): eight per-XCD heads into the table's runs; nullptr: one tile per block
     long ksplit, csplit;              // split-K (gridDim.y > 1): block row y takes K elements [y ksplit, (y+1) ksplit), its tile goes to C + y csplit
     int ny;                           // strided batch (ksplit == 0, gridDim.y > 1): problem (y, z) = (blockIdx.y % ny, blockIdx.y / ny)
     long ab1, ab2, bb1, bb2, cb1, cb2;   // takes its operands at A + y ab1 + z ab2, B + .., C + ..
@@ -187,7 +188,7 @@ __device__ __forceinline__ void atomic_tile(double4_t (&acc)[4][4], double *cbas
                 unsafeAtomicAdd(&cbase[(i * 16 + 4 * v) * ldc + j * 16], alpha * acc[i][j][v]);
 }
 
-template <int AKM, int BNM, int ROLE, int DBG = 0>
+template <int AKM, int BNM, int ROLE, int DBG = 0, int PERSIST = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // 76 KB, a little more than the 72 KB of operand images: the look-ahead leaf kernel (73 KB) must fit
     // into the LDS range one retiring workgroup of this kernel frees
@@ -196,8 +197,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // XCD-aware remap: hardware deals block b to XCD b%8.  Blocks b, b+8, b+16, .. (one XCD) walk whole
     // super-tiles: the 8*SN tiles of a super-tile run together on one L2, and super-tiles are dealt
     // round-robin over the XCDs so every XCD gets the same mix of full and diagonal (half-empty) ones.
+    // Persistent form (g.queue; the trailing update in the chain-bound phase): the launch has FEWER workgroups than the chip has
+    // slots and every workgroup pulls tiles until the table is empty, so the slots it leaves free stay free for the whole
+    // launch -- the panel chain's kernels (look-ahead, other stream) start at once instead of waiting for a round of update
+    // tiles to retire.  Each XCD walks its own run of the table (same L2 locality as the one-tile-per-block launch: block b
+    // -> XCD b % 8) and steals from the others when it runs dry.
+    __shared__ int s_next;
+    const int tid = threadIdx.x;
+    int xcc = 0;
+    if constexpr (PERSIST) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+  for (;;) {
     int ti, tj;
-    if (g.tab) {                      // balanced table: every XCD (blocks b, b + 8, ..) gets the same number of real tiles
+    if constexpr (PERSIST) {
+        if (tid == 0) {
+            const int per = (int)(g.ntiles >> 3);
+            int found = -1;
+            for (int s = 0; s < 8 && found < 0; ++s) {
+                const int y = (xcc + s) & 7;
+                const int i = atomicAdd(g.queue + y, 1);
+                if (i < per) found = 8 * i + y;
+            }
+            s_next = found;
+        }
+        __syncthreads();
+        const int b = s_next;
+        __syncthreads();              // everybody has read it before thread 0 may write the next one
+        if (b < 0) return;
+        const int e = g.tab[b];
+        if (e < 0) continue;
+        ti = e >> 16; tj = e & 0xffff;
+    } else if (g.tab) {               // balanced table: every XCD (blocks b, b + 8, ..) gets the same number of real tiles
         const int e = g.tab[blockIdx.x];
         if (e < 0) return;
         ti = e >> 16; tj = e & 0xffff;
@@ -210,7 +239,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         if (g.lower == 2 && tj > ti * g.ls + g.lo) return;
     }
     if (g.rev) ti = g.tiles_m - 1 - ti;
-    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 15, q = lane >> 4;
@@ -569,9 +597,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         if (!(DBG & 2)) __syncthreads();
     }
 
-    constexpr bool ATOM = (DBG & 4096) || (DBG == 0 && FVGP_GEMM_ATOMIC_DEFAULT);
-    if (ATOM && g.beta == 1.0) atomic_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha);
+    // the persistent form adds its tile with fire-and-forget atomics (beta == 1 there): no registers for the old values, so the
+    // addressing it keeps alive across tiles fits beside the accumulators
+    constexpr bool ATOM = PERSIST || (DBG & 4096) || (DBG == 0 && FVGP_GEMM_ATOMIC_DEFAULT);
+    if (ATOM && (PERSIST || g.beta == 1.0)) atomic_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha);
     else store_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
+    if constexpr (!PERSIST) return;
+  }
 }
 
 // Small-tile variant for the latency-bound steps of the panel chain (TRSM by the inverted diagonal block, in-panel
@@ -1062,6 +1094,7 @@ long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int ls, int lo, in
 void gemm_release_tables(fvgp_handle *h) {
     for (auto &kv : h->tile_tabs) (void)hipFree(kv.second.dev);
     h->tile_tabs.clear();
+    if (h->tile_queue) { (void)hipFree(h->tile_queue); h->tile_queue = nullptr; }
 }
 
 static std::vector<int> build_tile_table(int tm, int tn, int lower, int ls, int lo) {
@@ -1142,7 +1175,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     if ((d.bc_ranks > 1 || d.bc_off) && d.b_nmajor) { fvgp_set_error("gemm: block-cyclic B needs the (N, K) layout"); return -7; }
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
-    g.tab = nullptr; g.ksplit = 0; g.csplit = 0;
+    g.tab = nullptr; g.queue = nullptr; g.ksplit = 0; g.csplit = 0;
     g.ny = 0; g.ab1 = g.ab2 = g.bb1 = g.bb2 = g.cb1 = g.cb2 = 0;
     const bool plain_k = d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && d.kei == 0 && d.kej == 0;
     if (h->tile_tables && plain_k && !d.rev_m && !d.probe && g.tiles_m < 32768 && g.tiles_n < 32768 &&
@@ -1204,6 +1237,19 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         else hipLaunchKernelGGL((gemm_f64_direct_kernel<0>), grid, block, 0, h->stream, g);
         HIPCHK(hipGetLastError());
         return 0;
+    }
+    // the trailing update as a persistent launch that leaves `update_reserve` compute units' worth of slots free for the chain
+    if (d.role == 1 && !d.a_kmajor && !d.b_nmajor && g.tab && !split && !batched && d.reserve_cus > 0 && d.reserve_cus < h->n_cus) {
+        const long slots = 2L * (h->n_cus - d.reserve_cus);
+        if (g.ntiles > slots && d.beta == 1.0) {
+            if (!h->tile_queue) HIPCHK(hipMalloc((void **)&h->tile_queue, 8 * sizeof(int) * 512));
+            g.queue = h->tile_queue + 8 * (h->tile_queue_next++ % 512);
+            HIPCHK(hipMemsetAsync(g.queue, 0, 8 * sizeof(int), h->stream));
+            grid.x = (unsigned)slots;
+            hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 1, 0, 1>), grid, block, 0, h->stream, g);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
     }
 #define GO(AK, BN) do { if (d.role == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 1>), grid, block, 0, h->stream, g); \
                         else hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 0>), grid, block, 0, h->stream, g); } while (0)
