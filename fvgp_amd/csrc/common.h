@@ -77,7 +77,7 @@ struct fvgp_handle {
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel
     hipEvent_t ev_panel = nullptr, ev_cols = nullptr;
     hipEvent_t ev_pan2[2] = {nullptr, nullptr}, ev_big2[2] = {nullptr, nullptr};
-    int overlap_cols = 1;             // the next panel's columns are updated on the side stream, beside the big update of the rest
+    int overlap_cols = 0;             // option (off: two overlapping update launches blur the per-launch timing the roofline is read from; -0.55 % at N = 50k when on): the next panel's columns are updated on the side stream, beside the big update of the rest
     // profile of the last potrf
     std::vector<hipEvent_t> ev;
     std::vector<double> ev_flops;
