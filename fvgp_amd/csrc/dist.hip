@@ -107,6 +107,10 @@ struct HipBackend {
     }
     int copy2d(double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int64_t cols) {
         if (rows <= 0 || cols <= 0) return 0;
+        if (ldd == cols && lds == cols) {         // contiguous on both sides: one linear copy (the rectangle path costs ~40 us per call)
+            HIPCHK(hipMemcpyAsync(dst, src, (size_t)rows * cols * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            return 0;
+        }
         HIPCHK(hipMemcpy2DAsync(dst, (size_t)ldd * sizeof(double), src, (size_t)lds * sizeof(double), (size_t)cols * sizeof(double),
                                 (size_t)rows, hipMemcpyDeviceToDevice, h->stream));
         return 0;

@@ -100,10 +100,16 @@ static int chain(B &b, const fvgp_dist_desc &d, const Geom &g, int J, const doub
     const int64_t per = ((g.NB / T128) + P - 1) / P, chunk = per * T128 * w;
     double *S = d.gather, *G = d.gather + per * T128 * g.NB;
     if (lb > la) { rc = b.copy2d(S, w, A + la * T128 * g.ld + J0, g.ld, (lb - la) * T128, w); if (rc) return rc; }
-    rc = b.all_gather(S, G, chunk, 8.0 * (P - 1) * chunk); if (rc) return rc;
-    for (int64_t t = 0; t < nbw; ++t) {
-        const int64_t gb = b0 + t, q = gb % P, li = gb / P, laq = ceil_pos(b0 - q, P);
-        rc = b.copy2d(D + t * T128 * w, w, G + q * chunk + (li - laq) * T128 * w, w, T128, w); if (rc) return rc;
+    if (per == 1 && P == nbw && b0 % P == 0) {
+        // one block per rank and block t of the panel on rank t: the gathered order IS the panel's row order, the all-gather
+        // writes the diagonal block in place (P = 8 ranks, 1024-wide panels)
+        rc = b.all_gather(S, D, chunk, 8.0 * (P - 1) * chunk); if (rc) return rc;
+    } else {
+        rc = b.all_gather(S, G, chunk, 8.0 * (P - 1) * chunk); if (rc) return rc;
+        for (int64_t t = 0; t < nbw; ++t) {
+            const int64_t gb = b0 + t, q = gb % P, li = gb / P, laq = ceil_pos(b0 - q, P);
+            rc = b.copy2d(D + t * T128 * w, w, G + q * chunk + (li - laq) * T128 * w, w, T128, w); if (rc) return rc;
+        }
     }
     // 2. this rank's rows at / below the panel, compact
     rc = b.copy2d(low, w, A + L0 * T128 * g.ld + J0, g.ld, kt, w); if (rc) return rc;
