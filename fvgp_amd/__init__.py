@@ -7,3 +7,4 @@ from .gp import GP                      # noqa: E402,F401
 from .fvgp import fvGP                  # noqa: E402,F401
 from .gp_lin_alg import NonPositiveDefiniteError   # noqa: E402,F401
 from . import kernels                   # noqa: E402,F401
+from .gp_training import ProposalDistribution   # noqa: E402,F401

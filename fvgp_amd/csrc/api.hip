@@ -1326,6 +1326,16 @@ int fvgp_hip_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const doubl
     return fvgp_read_back(h, h->red, out_host, 1);
 }
 
+int fvgp_hip_add_matrix(fvgp_handle *h, double *A, int64_t lda, const double *B, int64_t ldb, int64_t rows, int64_t cols, double alpha) {
+    if (!h) return -1;
+    if (!A) return -2;
+    if (!B) return -4;
+    if (rows <= 0) return -6;
+    if (cols <= 0 || lda < cols || ldb < cols) return -7;
+    HIPCHK(hipSetDevice(h->device));
+    return launch_add_matrix(h, A, lda, B, ldb, rows, cols, alpha);
+}
+
 int fvgp_hip_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t ncols, double *out) {
     if (!h) return -1;
     if (!V) return -2;

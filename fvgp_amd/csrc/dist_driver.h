@@ -142,7 +142,9 @@ template <class B>
 static int assemble(B &b, const fvgp_dist_desc &d, const Geom &g, const double *theta, int ntheta) {
     double *A = d.A;
     int rc;
-    if (g.P == 1) {
+    if (d.preassembled) {                      // the caller's rows of K are in place: noise / identity on the diagonal only
+        rc = b.diag(A, g.ld, g.nb_max * T128, g.P, g.p, g.n, g.np, d.vdiag); if (rc) return rc;
+    } else if (g.P == 1) {
         rc = b.kmat_lower(d.kernel_id, d.x_all, g.n, d.d, theta, ntheta, d.vdiag, A, g.ld); if (rc) return rc;
     } else {
         for (int64_t l = 0; l < g.nb_max; ++l) {

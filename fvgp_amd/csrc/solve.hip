@@ -410,6 +410,15 @@ __global__ void add_lower_kernel(double *A, long lda, const double *B, long ldb,
             A[i * lda + j] = fma(alpha, B[i * ldb + j], A[i * lda + j]);
 }
 
+// A[i][j] += alpha * B[i][j] on a rows x cols rectangle
+__global__ void add_matrix_kernel(double *A, long lda, const double *B, long ldb, long rows, long cols, double alpha) {
+    const long tot = rows * cols;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        const long i = e / cols, j = e - i * cols;
+        A[i * lda + j] = fma(alpha, B[i * ldb + j], A[i * lda + j]);
+    }
+}
+
 // rows n..np-1 of a padded square matrix <- identity rows (lower part; the strict upper is never read)
 __global__ void pad_identity_kernel(double *A, long n, long np, long lda) {
     const long rows = np - n;
@@ -493,6 +502,15 @@ int launch_add_lower(fvgp_handle *h, double *A, int64_t lda, const double *B, in
     long bx = (n + 255) / 256; if (bx > 64) bx = 64;
     const long by = n < 65535 ? n : 65535;                 // gridDim.y is limited to 65535: the rows are walked with that stride
     hipLaunchKernelGGL(add_lower_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, h->stream, A, (long)lda, B, (long)ldb, (long)n, alpha);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_add_matrix(fvgp_handle *h, double *A, int64_t lda, const double *B, int64_t ldb, int64_t rows, int64_t cols, double alpha) {
+    long tot = rows * cols;
+    if (tot <= 0) return 0;
+    long blocks = (tot + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(add_matrix_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, A, (long)lda, B, (long)ldb, (long)rows, (long)cols, alpha);
     HIPCHK(hipGetLastError());
     return 0;
 }

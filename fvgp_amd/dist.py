@@ -33,6 +33,8 @@ import numpy as np
 from . import _lib
 
 TILE = 128
+DEFAULT_OPS_FACTORY = None        # callable() -> ops object used when ShardedGP is given none (None: HipOps); the CPU tests point it
+                                  # at their host stand-in so that unpickled objects find it again
 
 
 class HipOps:
@@ -90,6 +92,9 @@ class HipOps:
 
     def grad_trace_cols(self, kernel_id, x, theta, W, col0, ncols, b, partial):
         return self.H.grad_trace_cols(kernel_id, x, theta, W, col0, ncols, b, partial)
+
+    def add_matrix(self, A, B, alpha=1.0):
+        self.H.add_matrix(A, B, alpha)
 
     def colsumsq(self, V, out):
         self.H.colsumsq(V, out)
@@ -189,9 +194,14 @@ class ShardedGP:
         self.p, self.P = int(rank), int(world)
         assert panel % TILE == 0 and panel >= TILE, "panel width must be a multiple of 128"
         self.NB = int(panel)
-        self.ops = ops if ops is not None else HipOps()
-        self.kernel_id = _lib.KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+        self.ops = ops if ops is not None else (DEFAULT_OPS_FACTORY() if DEFAULT_OPS_FACTORY is not None else HipOps())
+        # a host callable k(x1, x2, theta) -> ndarray (gp_prior.py:217-224) is evaluated per rank for the rank's rows and uploaded
+        # (slow path, N^2 / P over PCIe per evaluation); named kernels are assembled on the device
+        self.kernel_callable = kernel if callable(kernel) else None
+        self.kernel_id = 0 if self.kernel_callable is not None else (_lib.KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel))
+        self.noise_matrix = None                                     # (n, n) host array: matrix-valued noise model (gp_kv.py:654-657)
         x = np.ascontiguousarray(x, dtype=np.float64)
+        self.x_host = x
         y = np.asarray(y, dtype=np.float64).reshape(len(x), -1)
         self.n, self.d = x.shape
         self.ncol = y.shape[1]
@@ -284,8 +294,35 @@ class ShardedGP:
         zt = np.zeros((TILE, self.np_))
         zt[:self.ncol, :self.n] = ymean.T
         self.zt.copy_(self.ops.to_device(zt))
-        self.v_host = np.asarray(noise_variances, dtype=np.float64)
+        V = np.asarray(noise_variances, dtype=np.float64)
+        if V.ndim == 2:                                              # K + V with a full matrix: its rows are added at assembly
+            self.noise_matrix, self.v_host = V, np.zeros(self.n)
+        else:
+            self.noise_matrix, self.v_host = None, V
         self.v_dev.copy_(self.ops.to_device(self.v_host))
+
+    def _kernel_rows(self, x2_host, x2_dev, theta, out):
+        """out[:nv, :len(x2)] = k(this rank's points, x2) (padded window zeroed): device assembly, or the host callable"""
+        o = self.ops
+        if self.kernel_callable is None:
+            if self.nv > 0:
+                o.kmat(self.kernel_id, self.x_loc, x2_dev, theta, out)
+            return
+        out.zero_()
+        if self.nv > 0:
+            k = np.ascontiguousarray(self.kernel_callable(self.x_host[self.gidx[:self.nv]], x2_host, theta), dtype=np.float64)
+            out[:self.nv, :k.shape[1]].copy_(o.to_device(k))
+
+    def _assemble_rows(self, theta):
+        """The rank's rows of K (+ its rows of a matrix-valued noise model) placed in A by this module: what the library's own
+        assembly cannot do (Python kernel callables, 2-d noise).  The driver then adds the diagonal noise / identity padding."""
+        o, A = self.ops, self.A
+        with o.stream():
+            A[:self.zrow].zero_()
+            self._kernel_rows(self.x_host, self.x_all, theta, A[:self.zrow])
+            if self.noise_matrix is not None and self.nv > 0:
+                o.add_matrix(A[:self.nv, :self.n], o.to_device(self.noise_matrix[self.gidx[:self.nv]]))
+        self._desc.preassembled = 1
 
     def _diag_block(self, J):
         """the factored diagonal block of panel J (lower triangle), on this rank"""
@@ -310,6 +347,9 @@ class ShardedGP:
         gradient or posterior can follow this evaluation."""
         self.keep_factor = bool(keep_factor or want_alpha)
         self._desc.keep_factor = 1 if self.keep_factor else 0
+        self._desc.preassembled = 0
+        if self.kernel_callable is not None or self.noise_matrix is not None:
+            self._assemble_rows(np.asarray(theta, dtype=np.float64))
         with self.ops.stream():
             ll, logdet, quad, info = self.ops.loglik_dist(self._desc, np.asarray(theta, dtype=np.float64))
         if info != 0:
@@ -397,8 +437,7 @@ class ShardedGP:
         with o.stream():
             xp = o.to_device(x_pred)
             k = o.zeros(rows, pp)
-            if self.nv > 0:
-                o.kmat(self.kernel_id, self.x_loc, xp, self.theta, k)
+            self._kernel_rows(x_pred, xp, self.theta, k)
             a_loc = o.zeros(rows, TILE)
             inside = self.gidx < self.np_
             a_loc[:int(inside.sum())] = self.alpha[self.torch.as_tensor(self.gidx[inside], device=self.alpha.device)]
@@ -410,11 +449,46 @@ class ShardedGP:
                 self.forward_trsm(k)
                 S = o.zeros(pp, pp)
                 if self.p == 0:
-                    o.kmat(self.kernel_id, xp, xp, self.theta, S)
+                    if self.kernel_callable is None:
+                        o.kmat(self.kernel_id, xp, xp, self.theta, S)
+                    else:
+                        S[:npred, :npred].copy_(o.to_device(np.ascontiguousarray(self.kernel_callable(x_pred, x_pred, self.theta), dtype=np.float64)))
                 o.gemm(1, 1, 0, pp, pp, rows, -1.0, k, k, 1.0, S)
                 self._all_reduce(S)
             o.sync()
         return mean[:npred, :self.ncol].cpu().numpy(), (None if S is None else S[:npred, :npred].cpu().numpy())
+
+    def gather_rows(self, rows_local, ncols=None):
+        """Host array (n, ncols) of a row-distributed matrix from this rank's rows (nb_max*128 x >= ncols, block-cyclic like
+        the matrix itself): one all-gather, replicated result.  What the reference keeps as whole host arrays (`GP.K`,
+        `kv.Chol_factor`, fvgp/gp.py:625-635) is materialised this way, on request only."""
+        o = self.ops
+        rows = self.nb_max * TILE
+        ncols = self.np_ if ncols is None else ncols
+        send = rows_local[:rows, :ncols].contiguous().view(-1)
+        recv = o.zeros(self.P * send.numel())
+        if self.general:
+            o.all_gather(send, recv)
+        else:
+            recv.copy_(send)
+        o.sync()
+        full = recv.view(self.P, self.nb_max, TILE, ncols).cpu().numpy()              # [rank, local block, row, col]
+        out = full.transpose(1, 0, 2, 3).reshape(self.nb_max * self.P * TILE, ncols)     # global block = local * P + rank
+        return out[:self.n]
+
+    def kernel_matrix(self, theta):
+        """K(theta) (n, n) on the host, replicated: every rank assembles its rows, one all-gather"""
+        o = self.ops
+        with o.stream():
+            k = o.zeros(self.nb_max * TILE, self.np_)
+            self._kernel_rows(self.x_host, self.x_all, np.asarray(theta, dtype=np.float64), k)
+            return self.gather_rows(k)[:, :self.n].copy()
+
+    def factor_matrix(self):
+        """tril of the Cholesky factor (n, n) on the host, replicated (needs an evaluation that kept the factor)"""
+        assert self.theta is not None, "evaluate(keep_factor=True) first"
+        with self.ops.stream():
+            return np.tril(self.gather_rows(self.A)[:, :self.n])
 
     def _inverse_factor_rows(self):
         """this rank's rows of inv(L) (rows x np_), by the distributed forward solve of the identity"""
@@ -436,6 +510,8 @@ class ShardedGP:
         want_diag: also return diag(KV^-1) (n,), replicated -- the row sums of squares of inv(L)'s columns, which the
         gradients of noise-function hyperparameters need (gp_marginal_likelihood.py:262-267)."""
         assert self.theta is not None, "evaluate() first"
+        if self.kernel_callable is not None:
+            raise NotImplementedError("the row-sharded gradient re-evaluates dK/dtheta inside its trace kernel: it takes the named kernels")
         o, torch = self.ops, self.torch
         if self.alpha is None:
             self.solve_backward()

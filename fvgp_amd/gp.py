@@ -69,10 +69,21 @@ class GP(ValidationMixin):
         if gp2Scale:
             raise NotImplementedError("gp2Scale (sparse, Dask-distributed) is outside this engine's scope; "
                                       "the dense path scales by sharding over GPUs (fvgp_amd.dist).")
-        if linalg_mode not in (None, "Chol", "CholInv"):
-            raise NotImplementedError("only the dense Cholesky modes ('Chol', 'CholInv') run natively")
-        self.linalg_mode = linalg_mode or "Chol"
+        # gp_kv.py:138-147: "Chol", "CholInv" / "Inv" (an explicit KV^-1 is kept next to the factor: the fast variance path of
+        # gp_posterior.py:238-244), or three callables [f_factor, f_solve, f_logdet] that take over the linear algebra on HOST
+        # arrays exactly as in the reference (gp_kv.py:457-458,552-554,625-628,697-698,715; documented gp.py:274-281)
+        self._linalg_callables = None
+        if isinstance(linalg_mode, (list, tuple)):
+            assert len(linalg_mode) == 3 and all(callable(f) for f in linalg_mode), \
+                "linalg_mode as a list needs three callables [f_factor(KV), f_solve(obj, b), f_logdet(obj)]"
+            self._linalg_callables = list(linalg_mode)
+            warnings.warn("linalg_mode callables work on host arrays: K+V crosses PCIe for every evaluation (slow path).", stacklevel=2)
+            linalg_mode = "Chol"
+        if linalg_mode not in (None, "Chol", "CholInv", "Inv"):
+            raise NotImplementedError("the dense modes 'Chol', 'CholInv', 'Inv' or three callables run here; the sparse modes belong to gp2Scale")
+        self.linalg_mode = {"Inv": "CholInv"}.get(linalg_mode, linalg_mode) or "Chol"
         self._KVinv = None
+        self._custom_obj = None
         if isinstance(noise_variances, np.ndarray):
             assert np.ndim(noise_variances) == 1, "noise_variances must be 1-d"
             assert len(noise_variances) == len(y_data), "noise_variances and y_data have different lengths"
@@ -89,10 +100,8 @@ class GP(ValidationMixin):
         self._sharded = self.args.get("process_group") is not None and self.args.get("process_group") is not False
         self._sh = self._sh_work = None
         if self._sharded:
-            if _kernels.resolve(kernel_function) is None:
-                raise NotImplementedError("the row-sharded mode assembles on the device: it takes the named kernels of fvgp_amd.kernels")
-            if self.linalg_mode != "Chol":
-                raise NotImplementedError("the row-sharded mode keeps the Cholesky factor only (linalg_mode 'Chol')")
+            # every linalg mode keeps the distributed Cholesky factor ('CholInv' caches an explicit inverse in the reference,
+            # gp_kv.py:429-432: a speed choice with the same results); kernel callables are evaluated per rank for its rows
             self._H = None
         else:
             self._H = default_handle()
@@ -197,7 +206,8 @@ class GP(ValidationMixin):
     def _make_sharded(self):
         from .dist import ShardedGP
         pg = self.args.get("process_group")
-        return ShardedGP(self.x_data, self.y_data, np.ones(self.point_number), kernel=self._native.kernel_id,
+        return ShardedGP(self.x_data, self.y_data, np.ones(self.point_number),
+                         kernel=self._native.kernel_id if self._native is not None else (lambda a, b, h: self._host_kernel(a, b, h)),
                          group=None if pg is True else pg, ops=self.args.get("shard_ops"),
                          panel=int(self.args.get("shard_panel", 1024)), rank=self.args.get("shard_rank"),
                          world=self.args.get("shard_world"))
@@ -213,16 +223,15 @@ class GP(ValidationMixin):
         sh = self._sh if state else self._sh_work
         m = self._mean(self.x_data, hps)
         V = self._noise(self.x_data, hps)
-        if np.ndim(V) != 1:
-            raise NotImplementedError("the row-sharded mode takes a diagonal noise model")
-        sh.set_targets(self.y_data - m[:, None], V)
+        sh.set_targets(self.y_data - m[:, None], V)                    # 2-d V: the ranks add their rows of it (gp_kv.py:654-657)
         try:
             ll, logdet, _ = sh.evaluate(hps, want_alpha=state, keep_factor=keep_factor)
         except np.linalg.LinAlgError as e:
-            raise NonPositiveDefiniteError(_non_pd_message(self.point_number, str(e).split("-th")[0], float(np.min(V)), 0.0)) from e
+            raise NonPositiveDefiniteError(_non_pd_message(self.point_number, str(e).split("-th")[0],
+                                                           float(np.min(V if np.ndim(V) == 1 else np.diag(V))), 0.0)) from e
         return ll, logdet, m, V, sh
 
-    def _evaluate(self, hps, KV, alpha, need_alpha=True):
+    def _evaluate(self, hps, KV, alpha, need_alpha=True, use_callables=True):
         """need_alpha=False: the caller wants the likelihood only.  The forward solve rides along in the factorisation
         (quad = |L^-1 (y-m)|^2), so the backward solve that would produce KVinvY is skipped when the fused call can
         run without it (it needs ncol free padding rows)."""
@@ -237,6 +246,8 @@ class GP(ValidationMixin):
         V2 = V if np.ndim(V) == 2 else None                        # matrix-valued noise: KV = K + V (gp_kv.py:654-657)
         if V2 is not None:
             V = np.ascontiguousarray(np.diag(V2))
+        if self._linalg_callables is not None and use_callables:
+            return self._evaluate_callables(hps, KV, alpha, m, V, V2, ymean)
         if V2 is None and self._native is not None and ncol <= _lib.MAX_RHS_VEC and float(np.min(V)) > 0.0:
             skip = (not need_alpha) and (self._np - n) >= ncol
             ll, logdet, quad, info = H.loglik(self._native.kernel_id, self._x_dev, hps, H.to_device(V), ym_dev, KV,
@@ -265,6 +276,38 @@ class GP(ValidationMixin):
                 ll = -0.5 * (quad + logdet + n * np.log(2.0 * np.pi))
         if info != 0:
             raise NonPositiveDefiniteError(_non_pd_message(n, info, float(np.min(V)) if self._native is not None else None, 0.0))
+        return ll, logdet, m, (V if V2 is None else V2)
+
+    def _host_KV(self, hps, KV, V, V2):
+        """K + V as a full symmetric host array (what GPkv.addKV hands to the callables, gp_kv.py:639-669)"""
+        H, n = self._H, self.point_number
+        if self._native is not None:
+            H.kmat(self._native.kernel_id, self._x_dev, self._x_dev, hps, KV, vdiag=None if V2 is not None else H.to_device(V),
+                   uplo=_lib.LOWER, pad=_lib.PAD_IDENTITY)
+            H.symmetrize(KV, n)
+            H.sync()
+            K = KV[:n, :n].cpu().numpy().copy()
+        else:
+            K = self._host_kernel(self.x_data, self.x_data, hps)
+            if V2 is None:
+                K = K.copy()
+                np.fill_diagonal(K, np.diag(K) + V)
+        return K + V2 if V2 is not None else K
+
+    def _evaluate_callables(self, hps, KV, alpha, m, V, V2, ymean):
+        """compute_new_KVlogdet_KVinvY with user linear algebra (gp_kv.py:625-628): factor = f(KV), KVinvY = f_solve(factor,
+        y-m).reshape(y.shape), logdet = f_logdet(factor); the factor object is kept with the buffer it was computed into."""
+        f_factor, f_solve, f_logdet = self._linalg_callables
+        n = self.point_number
+        obj = f_factor(self._host_KV(hps, KV, V, V2))
+        a = np.asarray(f_solve(obj, ymean), dtype=np.float64).reshape(ymean.shape)
+        logdet = float(f_logdet(obj))
+        alpha[:n] = self._H.to_device(a)
+        if KV is self._L:
+            self._custom_obj = obj
+        else:
+            self._custom_obj_work = obj
+        ll = -0.5 * (np.sum(ymean * a) / ymean.shape[1] + logdet + n * np.log(2.0 * np.pi))
         return ll, logdet, m, (V if V2 is None else V2)
 
     def _scratch(self):
@@ -343,7 +386,7 @@ class GP(ValidationMixin):
         y = np.vstack([self.y_data, y_new])
         nv = None if self.noise_variances is None else np.concatenate([self.noise_variances, noise_variances_new])
         n_old = self.point_number
-        if not (rank_n_update and self._native is not None and len(x_new) > 0) or self._sharded:
+        if not (rank_n_update and self._native is not None and len(x_new) > 0) or self._sharded or self._linalg_callables is not None:
             self._set_data(x, y, nv)
             self.set_hyperparameters(self._hps)
             return
@@ -413,8 +456,8 @@ class GP(ValidationMixin):
         if self._K_host is None:
             n = self.point_number
             if self._sharded:
-                raise NotImplementedError("K is assembled by rows on the ranks of the process group and is not gathered")
-            if self._native is not None:
+                self._K_host = self._sh.kernel_matrix(self._hps)           # every rank's rows, one all-gather
+            elif self._native is not None:
                 buf = self._H.empty(n, n + (n & 1))
                 self._H.kmat(self._native.kernel_id, self._x_dev, self._x_dev, self._hps, buf)
                 self._H.sync()
@@ -434,7 +477,7 @@ class GP(ValidationMixin):
     def Chol_factor(self):
         """tril of the device factor (what np.tril(kv.Chol_factor) is in the reference)."""
         if self._sharded:
-            raise NotImplementedError("the factor is distributed by rows over the process group and is not gathered")
+            return self._sh.factor_matrix()                                # gathered on request, replicated
         self._H.sync()
         n = self.point_number
         return np.tril(self._L[:n, :n].cpu().numpy())
@@ -476,7 +519,7 @@ class GP(ValidationMixin):
         if self._work2 is None:
             self._work2 = H.empty(self._np, self._np)
         hps = self._hps if hyperparameters is None else np.asarray(hyperparameters, dtype=np.float64)
-        self._evaluate(hps, KV, aw)
+        self._evaluate(hps, KV, aw, use_callables=False)       # the reference's gradient goes around the linalg callables too (gp_marginal_likelihood.py:274)
         ncol = self.y_data.shape[1]
         if self._native is not None:
             g = H.loglik_grad(self._native.kernel_id, self._x_dev, hps, aw, ncol, component, KV, self._work2)
@@ -618,6 +661,18 @@ class GP(ValidationMixin):
         Pp = _lib.pad128(P)
         ncol = self.y_data.shape[1]
         xp = H.to_device(x_pred)
+        if self._linalg_callables is not None:
+            # kv.solve through the user's f_solve on the kept factor object (gp_kv.py:697-698; gp_posterior.py:120-136,158)
+            obj = self._custom_obj if L is self._L else self._custom_obj_work
+            k = (np.asarray(self._native(self.x_data, x_pred, hps)) if self._native is not None
+                 else self._host_kernel(self.x_data, x_pred, hps))
+            H.sync()
+            mean_h = k.T @ alpha[:n].cpu().numpy()
+            if not want_cov:
+                return mean_h, None
+            kk = (np.asarray(self._native(x_pred, x_pred, hps)) if self._native is not None
+                  else self._host_kernel(x_pred, x_pred, hps))
+            return mean_h, kk - k.T @ np.asarray(self._linalg_callables[1](obj, k), dtype=np.float64).reshape(k.shape)
         mean = H.empty(P, ncol)
         kx = H.empty(self._np, Pp)
         if self._native is not None:
@@ -894,9 +949,6 @@ class GP(ValidationMixin):
         instead); 'local' / 'adam' / callable results that lower the log marginal likelihood are rejected unless
         accept_only_if_improved=False (gp.py:1086-1168)."""
         from . import gp_training
-        if mcmc_prop_distrs not in ("normal", None):
-            raise NotImplementedError("the MCMC driver here has the reference's default proposal only: one adaptive "
-                                      "normal distribution over all hyperparameters (mcmc_prop_distrs='normal')")
         if asynchronous:
             if dask_client is None:
                 raise Exception("Please provide a dask_client for asynchronous training")
@@ -951,7 +1003,8 @@ class GP(ValidationMixin):
                                 objective_function=objective_function,
                                 objective_function_gradient=objective_function_gradient,
                                 objective_function_hessian=objective_function_hessian,
-                                mcmc_prior=mcmc_prior, mcmc_args={} if mcmc_args is None else mcmc_args)
+                                mcmc_prior=mcmc_prior, mcmc_args={} if mcmc_args is None else mcmc_args,
+                                mcmc_prop_distrs=mcmc_prop_distrs)
         self.set_hyperparameters(np.asarray(hps, dtype=np.float64))
         if guarded and not self.log_likelihood() >= ll_incumbent:          # exact mode: strict comparison (gp.py:1158-1160)
             warnings.warn(f"Training with method=`{method}` returned hyperparameters with a lower log marginal likelihood "
@@ -978,19 +1031,34 @@ class GP(ValidationMixin):
     # ------------------------------------------------------------------------------------------
     def __getstate__(self):
         if self._sharded:
-            raise NotImplementedError("a row-sharded GP holds one slice of the factor per rank and is not picklable")
+            # one slice of the factor per rank: the pickle carries the data and the hyperparameters, the factor is rebuilt by
+            # the (collective) re-evaluation at first use after unpickling (fvgp/gp_data.py:147, gp_prior.py:494 drop the Dask
+            # client the same way); a ProcessGroup object does not pickle -- the default group takes its place
+            st = {k: v for k, v in self.__dict__.items() if k not in ("_H", "_sh", "_sh_work", "_K_host", "args")}
+            st["args"] = {k: (True if k == "process_group" else v) for k, v in self.args.items() if k != "shard_ops"}
+            st["_sharded_pickle"] = True
+            return st
         self._H.sync()
         st = {k: v for k, v in self.__dict__.items()
-              if k not in ("_H", "_x_dev", "_L", "_alpha", "_work", "_work2", "_alpha_work", "_KVinv")}
+              if k not in ("_H", "_x_dev", "_L", "_alpha", "_work", "_work2", "_alpha_work", "_KVinv", "_custom_obj", "_custom_obj_work")}
         n = self.point_number
         st["_L_host"] = np.tril(self._L[:n, :n].cpu().numpy())
         st["_alpha_host"] = self._alpha[:n].cpu().numpy()
         return st
 
     def __setstate__(self, st):
+        if st.pop("_sharded_pickle", False):
+            self.__dict__.update(st)
+            self._H = self._sh = self._sh_work = self._K_host = None
+            self.set_hyperparameters(self._hps)                       # collective: every rank unpickles
+            return
         L_host, a_host = st.pop("_L_host"), st.pop("_alpha_host")
         self.__dict__.update(st)
         self._H = default_handle()
+        if self.__dict__.get("_linalg_callables") is not None:       # the user's factor object does not travel: rebuild the state
+            self._set_data(self.x_data, self.y_data, self.noise_variances)
+            self.set_hyperparameters(self._hps)
+            return
         H, n = self._H, self.point_number
         self._x_dev = H.to_device(self.x_data)
         self._L = H.zeros(self._np, self._np)

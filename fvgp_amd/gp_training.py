@@ -12,6 +12,117 @@ def _in_bounds(theta, bounds):
     return bool(np.all((theta >= bounds[:, 0]) & (theta <= bounds[:, 1])))
 
 
+class ProposalDistribution:
+    """A user-defined proposal distribution over some of the hyperparameters (gp_mcmc.py:234-364, same constructor):
+    `proposal_dist(x_part, x_all, obj)` returns the proposal for the entries `indices` ("normal": N(x_part,
+    prop_args["prop_Sigma"])), `adapt_callable(iteration, chain)` may update `obj.prop_args` (chain.trace["x"] is the list
+    of positions so far; "normal": the adaptive covariance of :337-356), auto_accept skips the Metropolis test."""
+
+    def __init__(self, indices, proposal_dist="normal", init_prop_Sigma=None, adapt_callable=None, r_opt=.234, c_0=10, c_1=.8,
+                 K=10, auto_accept=False, adapt_cov=True, prop_args=None, ID=None):
+        self.indices, self.r_opt, self.c_0, self.c_1, self.K = indices, r_opt, c_0, c_1, K
+        self.auto_accept, self.adapt_cov, self.ID, self.jump_trace = auto_accept, adapt_cov, ID, []
+        dim = len(indices)
+        if proposal_dist == "normal":
+            self.proposal_dist = self.normal_proposal_dist
+        elif callable(proposal_dist):
+            self.proposal_dist = proposal_dist
+        else:
+            raise Exception("No proposal distribution specified!")
+        if proposal_dist == "normal" and init_prop_Sigma is None:
+            init_prop_Sigma = np.identity(dim)
+            warnings.warn("You are using the normal proposal distribution for normal distributions\n "
+                          "but did not provide `init_prop_sigma`. This can lead to slow convergence")
+        if callable(adapt_callable):
+            self.adapt = adapt_callable
+        elif adapt_callable == "normal" or proposal_dist == "normal":
+            self.adapt = self._adapt
+        else:
+            if isinstance(adapt_callable, str):
+                raise Exception("Invalid string provided for adapt callable.")
+            self.adapt = lambda end, chain: None
+        if prop_args is None:
+            self.prop_args = {"prop_Sigma": init_prop_Sigma, "sigma_m": 2.4 ** 2 / dim}
+        else:
+            self.prop_args = prop_args
+            if adapt_callable == "normal":
+                self.prop_args["prop_Sigma"] = init_prop_Sigma
+                self.prop_args["sigma_m"] = 2.4 ** 2 / dim
+
+    def normal_proposal_dist(self, x, hps, obj):
+        return obj.rng.multivariate_normal(mean=x, cov=obj.prop_args["prop_Sigma"], size=1).reshape(len(x))
+
+    def _adapt(self, end, chain):
+        K = self.K
+        if (end % K) == 0:
+            start = end - K + 1
+            gamma2 = 1. / ((end / K) + 3) ** self.c_1
+            r_hat = np.mean(self.jump_trace[start:end])
+            self.prop_args["sigma_m"] = np.exp(np.log(self.prop_args["sigma_m"]) + self.c_0 * gamma2 * (r_hat - self.r_opt))
+            if self.adapt_cov:
+                seg = np.asarray(chain.trace["x"]).T[self.indices, start:end]
+                self.prop_args["prop_Sigma"] = self.prop_args["prop_Sigma"] + gamma2 * (np.cov(seg) - self.prop_args["prop_Sigma"])
+
+    rng = np.random
+
+
+class _Chain:
+    """what adapt callables and run_in_every_iteration see of the sampler (gpMCMC's `trace` and `args`)"""
+
+    def __init__(self, args):
+        self.trace, self.args = {"f(x)": [], "x": [], "time stamp": []}, args
+
+
+def run_mcmc_proposals(log_likelihood, bounds, x0, proposal_distributions, n_updates=10000, info=False, rng=None, prior=None,
+                       args=None, break_default=True):
+    """gpMCMC.run_mcmc / _jump (gp_mcmc.py:96-224) with user ProposalDistribution objects: per iteration every proposal
+    object moves its own entries in turn (one likelihood evaluation each), then adapts."""
+    rng = np.random if rng is None else rng
+    if prior is None:
+        def prior(theta, box, _args):
+            return 0.0 if _in_bounds(theta, box) else -np.inf
+    chain = _Chain(args)
+    x = np.array(x0, dtype=np.float64)
+    chain.trace["x"].append(x.copy())
+    f = log_likelihood(x)
+    p = prior(x, bounds, args)
+    accepted = []
+    for obj in proposal_distributions:
+        obj.rng = rng
+    for i in range(1, max(int(n_updates), 2)):
+        for obj in proposal_distributions:
+            x_star = x.copy()
+            x_star[obj.indices] = obj.proposal_dist(x[obj.indices].copy(), x, obj)
+            p_star, jumped = prior(x_star, bounds, args), 0.0
+            if p_star != -np.inf:
+                f_star = log_likelihood(x_star)
+                if np.isnan(f_star):
+                    raise Exception("Likelihood evaluation = NaN in gpMCMC")
+                expo = p_star + f_star - p - f
+                ratio = np.exp(expo) if expo < 50 else 1.1
+                if np.isnan(ratio):
+                    ratio = 0.0
+                if ratio > rng.uniform(0, 1, 1) or obj.auto_accept:
+                    x, f, p, jumped = x_star, f_star, p_star, 1.0
+            obj.jump_trace.append(jumped)
+            accepted.append(jumped)
+            obj.adapt(i, chain)
+        chain.trace["x"].append(x.copy())
+        chain.trace["f(x)"].append(f)
+        if info and i % 10 == 0:
+            print("Finished ", i, " out of ", n_updates, " iterations. f(x)= ", f)
+        if break_default and len(chain.trace["f(x)"]) >= 1000:
+            fl = np.asarray(chain.trace["f(x)"])
+            if abs(fl[-100:].mean() - fl[-200:-100].mean()) < 1e-3:
+                break
+    xs, fs = np.asarray(chain.trace["x"]), chain.trace["f(x)"]
+    dist_index = int(len(xs) - (len(xs) / 100))
+    arg_max = int(np.argmax(fs))
+    return {"f(x)": fs, "max f(x)": fs[arg_max], "MAP": fs[arg_max], "max x": xs[arg_max], "x": xs,
+            "mean(x)": np.mean(xs[dist_index:], axis=0), "median(x)": np.median(xs[dist_index:], axis=0),
+            "var(x)": np.var(xs[dist_index:], axis=0), "acceptance": float(np.mean(accepted)) if accepted else 0.0}
+
+
 def run_mcmc(log_likelihood, bounds, x0, n_updates=10000, info=False, rng=None, break_default=True, prior=None,
              args=None):
     """Adaptive Metropolis-Hastings with one normal proposal over all hyperparameters.
@@ -109,7 +220,8 @@ def adam_optimize(nlml, grad_nlml, theta0, lr=1e-2, beta1=0.9, beta2=0.999, eps=
 
 def train(gp, bounds, init_hyperparameters, method="mcmc", pop_size=20, tolerance=1e-4, max_iter=10000,
           local_optimizer="L-BFGS-B", constraints=(), info=False, seed=None, objective_function=None,
-          objective_function_gradient=None, objective_function_hessian=None, mcmc_prior=None, mcmc_args=None):
+          objective_function_gradient=None, objective_function_hessian=None, mcmc_prior=None, mcmc_args=None,
+          mcmc_prop_distrs="normal"):
     """Dispatch on `method` (GPtraining.train, fvgp/gp_training.py:28-196).  The objective is log_likelihood for
     'mcmc' and neg_log_likelihood (+ gradient) otherwise unless the caller hands in their own (gp.py:1038-1053); a
     callable `method` gets the GP and returns the hyperparameters (:194); the result must be a 1-d ndarray (:196)."""
@@ -123,8 +235,13 @@ def train(gp, bounds, init_hyperparameters, method="mcmc", pop_size=20, toleranc
     if objective_function_gradient is None and method in ("local", "adam"):
         objective_function_gradient = gp.neg_log_likelihood_gradient
     if method == "mcmc":
-        res = run_mcmc(objective_function, bounds, init_hyperparameters, n_updates=max_iter, info=info,
-                       rng=None if seed is None else np.random.RandomState(seed), prior=mcmc_prior, args=mcmc_args)
+        rng = None if seed is None else np.random.RandomState(seed)
+        if mcmc_prop_distrs in ("normal", None):
+            res = run_mcmc(objective_function, bounds, init_hyperparameters, n_updates=max_iter, info=info, rng=rng,
+                           prior=mcmc_prior, args=mcmc_args)
+        else:                                                                   # the user's ProposalDistribution objects
+            res = run_mcmc_proposals(objective_function, bounds, init_hyperparameters, list(mcmc_prop_distrs), n_updates=max_iter,
+                                     info=info, rng=rng, prior=mcmc_prior, args=mcmc_args)
         gp.mcmc_info = res
         hps = res["median(x)"]
     elif method == "global":

@@ -173,6 +173,8 @@ typedef struct fvgp_dist_desc {
     int *info_dev; double *logdet_dev;
     int keep_factor;      /* 0: likelihood only -- the factored panels are not copied back into A (no solve can follow) */
     int force_general;    /* 1: a single rank still takes the panel-buffer / collective path (exercises RCCL on one GPU) */
+    int preassembled;     /* 1: the caller has filled A's block rows with its rows of K (host kernel callables, matrix-valued noise
+                           *    already added; zero padding rows): the driver adds vdiag / the identity padding and (y-m)^T only */
 } fvgp_dist_desc;
 /* out[0] A, [1] each T, [2] each recv, [3] Dfac, [4] gather (doubles); [5] = npan */
 int fvgp_hip_dist_workspace(const fvgp_dist_desc *d, int64_t *out6);
@@ -277,6 +279,8 @@ int fvgp_hip_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const doubl
 /* out[p] = sum_i V[i][p]^2, p < ncols: the column sums of squares of a rank's rows of inv(L) are its share of diag(KV^-1)
  * (gradients of noise-function hyperparameters, gp_marginal_likelihood.py:262-267, in the row-sharded mode) */
 int fvgp_hip_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t ncols, double *out);
+/* A[i][j] += alpha * B[i][j], rows x cols: a rank's rows of a matrix-valued noise model added to its rows of K (gp_kv.py:654-657) */
+int fvgp_hip_add_matrix(fvgp_handle *h, double *A, int64_t lda, const double *B, int64_t ldb, int64_t rows, int64_t cols, double alpha);
 /* mirror the lower triangle into the upper (for exporting K / KV^-1 to numpy) */
 int fvgp_hip_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda);
 

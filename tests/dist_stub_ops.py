@@ -134,6 +134,9 @@ class StubOps:
         m = np.where(jj > kk, 2.0, np.where(jj == kk, 1.0, 0.0))
         return np.array([0.5 * np.sum(m * Ws * dK[i]) for i in range(len(theta))])
 
+    def add_matrix(self, A, B, alpha=1.0):
+        A[:B.shape[0], :B.shape[1]] += alpha * B
+
     def colsumsq(self, V, out):
         out.copy_((V * V).sum(dim=0))
 

@@ -51,7 +51,7 @@ theta = np.array({theta})
 ll, logdet, quad = gp.evaluate(theta, want_alpha=True)
 xp = np.random.default_rng(7).random(({npred}, d))
 mean, S = gp.posterior(xp)
-g = gp.gradient(component={ncol} - 1)
+g = gp.gradient(component={ncol} - 1, slab=256)
 out = dict(ll=ll, alpha=gp.alpha[:n, :{ncol}].numpy().tolist(), mean=mean.tolist(), S=S.tolist(), g=g.tolist())
 # every rank must hold the same replicated answers
 chk = torch.tensor([ll, float(np.sum(mean)), float(np.sum(S)), float(np.sum(g))], dtype=torch.float64)
@@ -83,10 +83,55 @@ out = dict(loglik=gp.log_likelihood(), logliks=[gp.log_likelihood(t) for t in fx
            pm_theta1=np.asarray(gp.posterior_mean(fx["x_pred"], hyperparameters=fx["thetas"][0])["m(x)"]).tolist(),
            pS=gp.posterior_covariance(fx["x_pred"])["S"].tolist(),
            pv_noise=gp.posterior_covariance(fx["x_pred"], variance_only=True, add_noise=True)["v(x)"].tolist())
+# what the reference keeps as whole host arrays is gathered on request (fvgp/gp.py:625-635), and the object pickles
+import pickle
+from oracle import fvgp_oracle as orc
+Kref = orc.KERNELS[str(fx["kernel"])](fx["x"], fx["x"], fx["theta"])
+out["K_err"] = float(np.max(np.abs(gp.K - Kref)))
+Lref = np.linalg.cholesky(Kref + np.diag(fx["noise_variances"]))
+out["L_err"] = float(np.max(np.abs(gp.Chol_factor - Lref)) / np.max(np.abs(Lref)))
+import fvgp_amd.dist
+fvgp_amd.dist.DEFAULT_OPS_FACTORY = StubOps          # the unpickled object builds its ops itself
+gp2 = pickle.loads(pickle.dumps(gp))
+out["pickle_loglik"] = gp2.log_likelihood()
+out["pickle_pm"] = np.asarray(gp2.posterior_mean(fx["x_pred"])["m(x)"]).tolist()
+del gp2
 gp.set_hyperparameters(fx["thetas"][1])
 out["loglik_set"] = gp.log_likelihood()
 trained = gp.train(hyperparameter_bounds=np.array([[0.1, 10.0]] + [[0.05, 5.0]] * (len(fx["theta"]) - 1)), method="mcmc", max_iter=30)
 out["trained"] = trained.tolist()
+if dist.get_rank() == 0:
+    print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+WORKER_SLOW = r'''
+import os, sys, json, warnings
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from conftest import load_golden
+from dist_stub_ops import StubOps
+from oracle import fvgp_oracle as orc
+import fvgp_amd
+dist.init_process_group(backend="gloo")
+fx = load_golden("G2_rbf_n512_d3.npz")
+x, y, th = fx["x"][:{n}], fx["y"][:{n}], fx["theta"]
+warnings.simplefilter("ignore")
+# (a) a Python kernel callable (4-argument form) in the row-sharded mode: every rank evaluates its own rows on the host
+gp = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=fx["noise_variances"][:{n}], linalg_mode="CholInv",
+                 kernel_function=lambda a, b, h, args: orc.rbf_ard(a, b, h), args={{"process_group": True, "shard_ops": StubOps(), "shard_panel": 128}})
+out = dict(ll=gp.log_likelihood(), ll2=gp.log_likelihood(th * 1.05), pm=np.asarray(gp.posterior_mean(fx["x_pred"])["m(x)"]).tolist(),
+           pS=gp.posterior_covariance(fx["x_pred"])["S"].tolist(), K_err=float(np.max(np.abs(gp.K - orc.rbf_ard(x, x, th)))))
+# (b) a matrix-valued noise model: theta = [sig, l1, l2, l3, noise level]
+def noise(xx, h):
+    d2 = ((xx[:, None, :] - xx[None, :, :]) ** 2).sum(axis=2)
+    return h[4] * (np.eye(len(xx)) + 0.3 * np.exp(-d2 / 0.02))
+th5 = np.concatenate([th, [0.02]])
+gpn = fvgp_amd.GP(x, y, init_hyperparameters=th5, kernel_function="rbf_ard", noise_function=noise,
+                  args={{"process_group": True, "shard_ops": StubOps(), "shard_panel": 256}})
+out["lln"] = gpn.log_likelihood()
+out["pvn"] = gpn.posterior_covariance(fx["x_pred"], variance_only=True, add_noise=True)["v(x)"].tolist()
 if dist.get_rank() == 0:
     print("RESULT " + json.dumps(out))
 dist.destroy_process_group()
@@ -184,6 +229,9 @@ def test_gp_facade_routes_through_the_process_group(tmp_path, world, fixture, pa
     np.testing.assert_allclose(out["pm_theta1"], fx["pm_theta1"], rtol=1e-8, atol=1e-10)
     assert np.max(np.abs(np.array(out["pS"]) - fx["pS"])) <= 1e-10 * fx["theta"][0] + 1e-12
     assert np.max(np.abs(np.array(out["pv_noise"]) - fx["pv_noise"])) <= 1e-10 * fx["theta"][0] + 1e-12
+    assert out["K_err"] <= 1e-14 * fx["theta"][0] and out["L_err"] <= 1e-11
+    np.testing.assert_allclose(out["pickle_loglik"], fx["loglik"], rtol=1e-10)
+    np.testing.assert_allclose(out["pickle_pm"], fx["pm"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(out["loglik_set"], fx["logliks"][1], rtol=1e-10)
     assert len(out["trained"]) == len(fx["theta"])
 
@@ -215,3 +263,36 @@ def test_sharded_non_positive_definite_raises():
     gp = ShardedGP(x, y, nv, kernel="rbf_ard", ops=StubOps(), panel=256, rank=0, world=1)
     with pytest.raises(np.linalg.LinAlgError, match="leading minor"):
         gp.log_likelihood(np.array([1.0, 0.3, 0.5]))
+
+
+def test_sharded_mode_takes_kernel_callables_and_matrix_valued_noise(tmp_path):
+    """The reference's distributed mode answers the whole API (tests/test_fvgp.py:3112-3149): a Python kernel callable
+    (each rank evaluates its own rows, gp_prior.py:217-224), linalg_mode="CholInv" (same results as "Chol"), the gathered K, and a
+    2-d noise model (K + V, gp_kv.py:654-657; add_noise with the matrix, gp_posterior.py:554-569) through 3 ranks."""
+    from conftest import load_golden
+    n = 400
+    out = _run_file(3, tmp_path, template=WORKER_SLOW, n=n)
+    fx = load_golden("G2_rbf_n512_d3.npz")
+    x, y, th, nv = fx["x"][:n], fx["y"][:n], fx["theta"], fx["noise_variances"][:n]
+    ref = orc.OracleGP(x, y, th, nv, kernel="rbf_ard")
+    np.testing.assert_allclose(out["ll"], ref.log_likelihood(), rtol=1e-10)
+    np.testing.assert_allclose(out["ll2"], ref.log_likelihood(th * 1.05), rtol=1e-10)
+    np.testing.assert_allclose(out["pm"], ref.posterior_mean(fx["x_pred"])["m(x)"], rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(np.array(out["pS"]) - ref.posterior_covariance(fx["x_pred"])["S"])) <= 1e-10
+    assert out["K_err"] == 0.0
+    # matrix-valued noise against plain numpy
+    d2 = ((x[:, None, :] - x[None, :, :]) ** 2).sum(axis=2)
+    V = 0.02 * (np.eye(n) + 0.3 * np.exp(-d2 / 0.02))
+    K = orc.rbf_ard(x, x, th)
+    L = np.linalg.cholesky(K + V)
+    ym = y - np.mean(y)
+    a = np.linalg.solve(L.T, np.linalg.solve(L, ym))
+    ll = -0.5 * (ym @ a + 2 * np.sum(np.log(np.diag(L))) + n * np.log(2 * np.pi))
+    np.testing.assert_allclose(out["lln"], ll, rtol=1e-10)
+    xp = fx["x_pred"]
+    k = orc.rbf_ard(x, xp, th)
+    v = np.linalg.solve(L, k)
+    d2p = ((xp[:, None, :] - xp[None, :, :]) ** 2).sum(axis=2)
+    Vp = 0.02 * (np.eye(len(xp)) + 0.3 * np.exp(-d2p / 0.02))
+    var = np.diag(orc.rbf_ard(xp, xp, th) - v.T @ v) + np.diag(Vp)
+    np.testing.assert_allclose(out["pvn"], var, rtol=1e-8, atol=1e-10)

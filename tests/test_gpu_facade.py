@@ -193,6 +193,52 @@ def test_callable_kernel_without_gradient_takes_the_reference_finite_differences
     assert calls == [0, 1]
 
 
+def test_linalg_mode_callables_and_inv_on_the_facade():
+    """gp_kv.py:138-147: linalg_mode = [f_factor, f_solve, f_logdet] hands K+V to the user's host callables (reference tests
+    tests/test_fvgp.py:417-426,5030-5052: the callables are really invoked and reproduce the Chol results); "Inv" keeps an
+    explicit inverse like "CholInv"."""
+    import fvgp_amd
+    from scipy.linalg import cho_factor, cho_solve
+    fx = load_golden("G2_rbf_n512_d3.npz")
+    x, y, th, nv = fx["x"], fx["y"], fx["theta"], fx["noise_variances"]
+    calls = {"f": 0, "s": 0, "l": 0}
+
+    def f_factor(KV):
+        calls["f"] += 1
+        assert isinstance(KV, np.ndarray) and KV.shape == (len(x), len(x)) and np.allclose(KV, KV.T)
+        return cho_factor(KV, lower=True)
+
+    def f_solve(obj, b):
+        calls["s"] += 1
+        assert np.ndim(b) == 2
+        return cho_solve(obj, b)
+
+    def f_logdet(obj):
+        calls["l"] += 1
+        return 2.0 * np.sum(np.log(np.diag(obj[0])))
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function="rbf_ard",
+                         linalg_mode=[f_factor, f_solve, f_logdet])
+        gpi = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function="rbf_ard", linalg_mode="Inv")
+    assert calls == {"f": 1, "s": 1, "l": 1}
+    np.testing.assert_allclose(gp.log_likelihood(), fx["loglik"], rtol=1e-10)
+    np.testing.assert_allclose(gp.log_likelihood(fx["thetas"][0]), fx["logliks"][0], rtol=1e-10)
+    assert calls["f"] == 2
+    assert np.max(np.abs(gp.KVinvY - fx["KVinvY"])) <= 1e-8 * np.max(np.abs(fx["KVinvY"]))
+    np.testing.assert_allclose(gp.posterior_mean(fx["x_pred"])["m(x)"], fx["pm"], rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(gp.posterior_covariance(fx["x_pred"])["S"] - fx["pS"])) <= 1e-10
+    assert calls["s"] >= 3
+    np.testing.assert_allclose(gp.neg_log_likelihood_gradient(th), fx["grad"], rtol=1e-8, atol=1e-9 * np.max(np.abs(fx["grad"])))
+    gp.set_hyperparameters(fx["thetas"][1])
+    np.testing.assert_allclose(gp.log_likelihood(), fx["logliks"][1], rtol=1e-10)
+    # "Inv": explicit inverse, variance-only fast path
+    np.testing.assert_allclose(gpi.log_likelihood(), fx["loglik"], rtol=1e-10)
+    v = gpi.posterior_covariance(fx["x_pred"], variance_only=True)["v(x)"]
+    assert np.max(np.abs(v - np.diag(fx["pS"]))) <= 1e-9
+
+
 def test_matrix_valued_noise_model():
     """A noise function that returns a 2-d matrix: KV = K + V (gp_kv.py:654-657), gradient with the 3-d noise derivative
     (gp_marginal_likelihood.py:262-267), add_noise with the matrix at the prediction points (gp_posterior.py:554-569)."""

@@ -231,3 +231,37 @@ def test_host_kernel_building_blocks_equal_the_oracles():
         for length in (1.0, 0.37):
             np.testing.assert_allclose(getattr(kernels, name)(d, length), getattr(orc, name)(d, length), rtol=1e-14)
     np.testing.assert_allclose(kernels.exponential_kernel(d, 0.5), np.exp(-d / 0.5), rtol=1e-15)
+
+
+def test_user_proposal_distributions_drive_the_mcmc():
+    """gp_mcmc.py:234-364: ProposalDistribution objects.  One normal proposal over all indices walks the default chain
+    (same random stream, same adaptation); two objects -- a normal one and a user callable with its own adapt function --
+    each move their own entries once per iteration."""
+    from fvgp_amd import gp_training as T
+    b = np.array([[0.1, 5.0], [0.05, 3.0]])
+    f = lambda x: -0.5 * np.sum((x - np.array([1.0, 0.7])) ** 2 / 0.05)
+    x0 = np.array([2.0, 1.0])
+    np.random.seed(3)
+    a = T.run_mcmc(f, b, x0, n_updates=300, break_default=False)
+    np.random.seed(3)
+    std = (b[:, 1] - b[:, 0]) * 0.2 / np.sqrt(12)
+    c = T.run_mcmc_proposals(f, b, x0, [T.ProposalDistribution(np.arange(2), init_prop_Sigma=np.diag(std ** 2))],
+                             n_updates=300, break_default=False)
+    np.testing.assert_allclose(c["x"], a["x"], rtol=0, atol=1e-12)
+    calls = []
+
+    def shrink(end, chain):                              # user adapt: (iteration, chain) -> None, updates prop_args
+        calls.append(len(chain.trace["x"]))
+        pd2.prop_args["width"] *= 0.999
+
+    def uniform_step(x_part, x_all, obj):                # user proposal: (own entries, all entries, obj) -> new own entries
+        return x_part + obj.rng.uniform(-obj.prop_args["width"], obj.prop_args["width"], len(x_part))
+
+    pd1 = T.ProposalDistribution([0], init_prop_Sigma=np.array([[0.05]]))
+    pd2 = T.ProposalDistribution([1], proposal_dist=uniform_step, adapt_callable=shrink, prop_args={"width": 0.2})
+    res = T.run_mcmc_proposals(f, b, x0, [pd1, pd2], n_updates=400, rng=np.random.RandomState(5), break_default=False)
+    assert res["x"].shape == (400, 2) and len(calls) == 399 and len(pd1.jump_trace) == len(pd2.jump_trace) == 399
+    assert 0.0 < res["acceptance"] < 1.0 and np.all((res["x"] >= b[:, 0]) & (res["x"] <= b[:, 1]))
+    assert abs(res["mean(x)"][0] - 1.0) < 0.6 and abs(res["mean(x)"][1] - 0.7) < 0.6
+    with pytest.raises(Exception, match="No proposal distribution"):
+        T.ProposalDistribution([0], proposal_dist=3)
