@@ -26,7 +26,7 @@ SYMBOLS = [
     "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_stream_create", "fvgp_hip_stream_destroy", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_grad_trace", "fvgp_hip_posterior", "fvgp_hip_gemm",
-    "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower", "fvgp_hip_trace_dot", "fvgp_hip_colsumsq", "fvgp_hip_add_matrix",
+    "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower", "fvgp_hip_trace_dot", "fvgp_hip_colsumsq", "fvgp_hip_add_matrix", "fvgp_hip_dot", "fvgp_hip_coldot",
     "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
     "fvgp_hip_grad_trace_cols", "fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy", "fvgp_hip_all_reduce",
     "fvgp_hip_all_gather", "fvgp_hip_comm_profile", "fvgp_hip_dist_workspace", "fvgp_hip_loglik_dist",
@@ -147,6 +147,8 @@ def lib():
     L.fvgp_hip_trace_dot.argtypes = [c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_l, P_d]
     L.fvgp_hip_colsumsq.argtypes = [c_p, c_p, c_l, c_l, c_l, c_p]
     L.fvgp_hip_add_matrix.argtypes = [c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_d]
+    L.fvgp_hip_dot.argtypes = [c_p, c_p, c_l, c_p, c_l, c_l, c_i, P_d]
+    L.fvgp_hip_coldot.argtypes = [c_p, c_p, c_l, c_p, c_l, c_l, c_l, c_p]
     L.fvgp_hip_mfma_peak.argtypes = [c_p, c_p, c_i, c_i]
     L.fvgp_hip_trsm_lower_t.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
     L.fvgp_hip_panel_trsm.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l, c_l]
@@ -422,6 +424,15 @@ class Handle:
         """A += alpha * B on the rectangle of B's shape"""
         _check(lib().fvgp_hip_add_matrix(self._h, _ptr(A), A.stride(0), _ptr(B), B.stride(0), B.shape[0], B.shape[1], float(alpha)),
                "fvgp_hip_add_matrix")
+
+    def dot(self, a, b, n):
+        """sum of the elementwise products of the first n rows of two (rows, c) arrays"""
+        out = ctypes.c_double(0.0)
+        _check(lib().fvgp_hip_dot(self._h, _ptr(a), a.stride(0), _ptr(b), b.stride(0), int(n), a.shape[1], ctypes.byref(out)), "fvgp_hip_dot")
+        return out.value
+
+    def coldot(self, A, B, rows, cols, out):
+        _check(lib().fvgp_hip_coldot(self._h, _ptr(A), A.stride(0), _ptr(B), B.stride(0), int(rows), int(cols), _ptr(out)), "fvgp_hip_coldot")
 
     def colsumsq(self, V, out):
         """out[p] = sum_i V[i][p]^2 over the rows of V"""

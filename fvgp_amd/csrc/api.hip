@@ -1336,6 +1336,29 @@ int fvgp_hip_add_matrix(fvgp_handle *h, double *A, int64_t lda, const double *B,
     return launch_add_matrix(h, A, lda, B, ldb, rows, cols, alpha);
 }
 
+int fvgp_hip_dot(fvgp_handle *h, const double *a, int64_t lda, const double *b, int64_t ldb, int64_t n, int c, double *out_host) {
+    if (!h) return -1;
+    if (!a) return -2;
+    if (!b) return -4;
+    if (n <= 0) return -6;
+    if (c < 1 || lda < c || ldb < c) return -7;
+    if (!out_host) return -8;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = launch_dot_rows(h, a, lda, b, ldb, n, c, h->red); if (rc) return rc;
+    return fvgp_read_back(h, h->red, out_host, 1);
+}
+
+int fvgp_hip_coldot(fvgp_handle *h, const double *A, int64_t lda, const double *B, int64_t ldb, int64_t rows, int64_t cols, double *out) {
+    if (!h) return -1;
+    if (!A) return -2;
+    if (!B) return -4;
+    if (rows <= 0) return -6;
+    if (cols <= 0 || lda < cols || ldb < cols) return -7;
+    if (!out) return -8;
+    HIPCHK(hipSetDevice(h->device));
+    return launch_coldot(h, A, lda, B, ldb, rows, cols, out);
+}
+
 int fvgp_hip_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t ncols, double *out) {
     if (!h) return -1;
     if (!V) return -2;

@@ -185,6 +185,7 @@ int launch_diag_logsum(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, 
 int launch_sum(fvgp_handle *h, const double *v, int64_t n, double *out_dev);
 int launch_dot_rows(fvgp_handle *h, const double *a, int64_t lda, const double *b, int64_t ldb, int64_t n, int c, double *out_dev);
 int launch_add_lower(fvgp_handle *h, double *A, int64_t lda, const double *B, int64_t ldb, int64_t n, double alpha);
+int launch_coldot(fvgp_handle *h, const double *A, int64_t lda, const double *B, int64_t ldb, int64_t rows, int64_t P, double *out);
 int launch_add_matrix(fvgp_handle *h, double *A, int64_t lda, const double *B, int64_t ldb, int64_t rows, int64_t cols, double alpha);
 int launch_pad_identity(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda);
 int launch_rhs_rows(fvgp_handle *h, double *A, int64_t n, int64_t lda, const double *ymean, int ncol, const double *vdiag);

@@ -236,6 +236,18 @@ __global__ void colsumsq_kernel(const double *V, long rows, long ldv, long P, do
     if (ty == 0 && p < P) { double t = 0.0; for (int k = 0; k < 8; ++k) t += sp[k][tx]; out[p] = base - sign * t; }
 }
 
+// out[p] = sum_{i<rows} A[i*lda+p] * B[i*ldb+p], p < P   (column-wise dot products: k^T (KV^-1 k) per prediction point)
+__global__ void coldot_kernel(const double *A, long lda, const double *B, long ldb, long rows, long P, double *out) {
+    __shared__ double sp[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long p = (long)blockIdx.x * 32 + tx;
+    double s = 0.0;
+    if (p < P) for (long i = ty; i < rows; i += 8) s = fma(A[i * lda + p], B[i * ldb + p], s);
+    sp[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && p < P) { double t = 0.0; for (int k = 0; k < 8; ++k) t += sp[k][tx]; out[p] = t; }
+}
+
 // row-wise twins of the two kernels above for the transposed cross-covariance block KT (P x n): one workgroup per
 // prediction point streams its row (16-byte loads, coalesced), block sums in a fixed order
 template <int C>
@@ -597,6 +609,12 @@ int launch_symmetrize(fvgp_handle *h, double *A, int64_t n, int64_t lda) {
 
 int launch_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t P, double base, double *out, double sign) {
     hipLaunchKernelGGL(colsumsq_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, h->stream, V, (long)rows, (long)ldv, (long)P, base, out, sign);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_coldot(fvgp_handle *h, const double *A, int64_t lda, const double *B, int64_t ldb, int64_t rows, int64_t P, double *out) {
+    hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, h->stream, A, (long)lda, B, (long)ldb, (long)rows, (long)P, out);
     HIPCHK(hipGetLastError());
     return 0;
 }

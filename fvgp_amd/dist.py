@@ -380,9 +380,10 @@ class ShardedGP:
             for J in range(self.npan - 1, -1, -1):
                 la, lb, first, J0, Jend = self._panel_rows(J)
                 w = Jend - J0
-                G = S[J0:Jend].clone()
-                self._all_reduce(G)
-                G = Y[J0:Jend] - G
+                Sg = S[J0:Jend].clone()
+                self._all_reduce(Sg)
+                G = Y[J0:Jend].clone()
+                o.add_matrix(G, Sg, -1.0)                                         # right-hand side of the panel: z_J - sum of the ranks' parts
                 o.trsm_lower_t(self._diag_block(J), w, G, TILE)
                 alpha[J0:Jend].copy_(G)
                 if lb > la and J0 > 0:

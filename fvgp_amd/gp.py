@@ -258,9 +258,10 @@ class GP(ValidationMixin):
                        uplo=_lib.LOWER, pad=_lib.PAD_IDENTITY)
             else:
                 K = self._host_kernel(self.x_data, self.x_data, hps)     # slow path: N^2 over PCIe
-                KV[:n, :n] = H.to_device(K)
                 if V2 is None:
-                    KV[:n, :n].diagonal().add_(H.to_device(V))
+                    K = K.copy()
+                    np.fill_diagonal(K, np.diag(K) + V)                  # addKV on the host (gp_kv.py:665-667), then one upload
+                KV[:n, :n] = H.to_device(K)
             if V2 is not None:
                 H.add_lower(KV, n, H.to_device(V2))                      # one N^2 upload per evaluation, added on the device
             info = H.potrf(KV, n)
@@ -272,7 +273,7 @@ class GP(ValidationMixin):
                 if rhs is not alpha:
                     alpha[:n] = rhs[:n, :ncol]
                 logdet = H.logdet(KV, n)
-                quad = float((ym_dev * alpha[:n]).sum().item()) / ncol
+                quad = H.dot(ym_dev, alpha, n) / ncol
                 ll = -0.5 * (quad + logdet + n * np.log(2.0 * np.pi))
         if info != 0:
             raise NonPositiveDefiniteError(_non_pd_message(n, info, float(np.min(V)) if self._native is not None else None, 0.0))
@@ -442,7 +443,7 @@ class GP(ValidationMixin):
             H.potrs(Lnew, n, rhs, _lib.pad128(ncol))
             self._alpha[:n] = rhs[:n, :ncol]
         self._logdet = H.logdet(Lnew, n)
-        quad = float((H.to_device(ymean) * self._alpha[:n]).sum().item()) / ncol
+        quad = H.dot(H.to_device(ymean), self._alpha, n) / ncol
         self._loglik = -0.5 * (quad + self._logdet + n * np.log(2.0 * np.pi))
         self.m, self.V = mean, V
         self._K_host = None
@@ -705,8 +706,10 @@ class GP(ValidationMixin):
         H.kmat(self._native.kernel_id, self._x_dev, H.to_device(x_pred), self._hps, kx, pad=_lib.PAD_ZERO)
         Wk = H.empty(self._np, Pp)
         H.gemm(0, 1, 0, self._np, Pp, self._np, 1.0, self._KVinv, kx, 0.0, Wk)        # KVinv @ k on MFMA
+        q = H.empty(P)
+        H.coldot(kx, Wk, n, P, q)                                                     # k_p^T KVinv k_p per prediction point
         H.sync()
-        return self._hps[0] - (kx[:n, :P] * Wk[:n, :P]).sum(dim=0).cpu().numpy()
+        return self._hps[0] - q.cpu().numpy()
 
     def posterior_mean(self, x_pred, hyperparameters=None, x_out=None):
         """fvgp/gp.py:1376-1431, gp_posterior.py:139-182."""

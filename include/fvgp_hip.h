@@ -276,6 +276,11 @@ int fvgp_hip_add_lower(fvgp_handle *h, double *A, int64_t n, int64_t lda, const 
  * device vector with stride ldb or NULL.  Fixed-order reduction. */
 int fvgp_hip_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const double *D, int64_t ldd, const double *b, int64_t ldb,
                        int64_t n, double *out_host);
+/* out_host = sum_{i<n, k<c} a[i][k] b[i][k]: the data-fit term sum((y-m) o KVinvY) (gp_marginal_likelihood.py:175) */
+int fvgp_hip_dot(fvgp_handle *h, const double *a, int64_t lda, const double *b, int64_t ldb, int64_t n, int c, double *out_host);
+/* out[p] = sum_i A[i][p] B[i][p], p < cols (device): einsum('ij,jk,ki->i', k^T, KVinv, k) of the CholInv variance path
+ * (gp_posterior.py:238-244) after KVinv k came from fvgp_hip_gemm */
+int fvgp_hip_coldot(fvgp_handle *h, const double *A, int64_t lda, const double *B, int64_t ldb, int64_t rows, int64_t cols, double *out);
 /* out[p] = sum_i V[i][p]^2, p < ncols: the column sums of squares of a rank's rows of inv(L) are its share of diag(KV^-1)
  * (gradients of noise-function hyperparameters, gp_marginal_likelihood.py:262-267, in the row-sharded mode) */
 int fvgp_hip_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t ncols, double *out);
