@@ -125,6 +125,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "gemm_probe")) { h->gemm_probe = (int)value; return 0; }
     if (!strcmp(key, "gemm_direct")) { h->gemm_direct = (int)value; return 0; }
     if (!strcmp(key, "tile_tables")) { h->tile_tables = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "chain_stamps")) { h->chain_stamps = reinterpret_cast<unsigned long long *>((uintptr_t)value); h->chain_seq = 0; return 0; }
     if (!strcmp(key, "leaf_stamps")) { h->leaf_stamps = reinterpret_cast<unsigned long *>((uintptr_t)value); return 0; }
     if (!strcmp(key, "small_tile_max")) { h->small_tile_max = value; return 0; }
     if (!strcmp(key, "small_tile_max_update")) { h->small_tile_max_update = value; return 0; }

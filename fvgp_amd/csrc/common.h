@@ -64,6 +64,7 @@ struct fvgp_handle {
     int gemm_direct = 0;              // diagnostics: 1 trailing updates use the LDS-free kernel, 2 every (M,K) x (N,K) product
     int64_t small_tile_max_update = 512;   // trailing updates of at most this many 128-tiles also run on 64-tiles
     int64_t small_tile_max = 160;     // (M,K) x (N,K) products of at most this many 128-tiles and K <= 512 run on 64-tiles
+    unsigned long long *chain_stamps = nullptr; int chain_seq = 0;   // diagnostics (option "chain_stamps"): trsm_tiles workgroup start / end times
     unsigned long *leaf_stamps = nullptr;   // diagnostics (option "leaf_stamps" = device pointer): phase timestamps of the leaf kernel
     std::map<TileTabKey, TileTab> tile_tabs;   // device-resident, freed with the handle
     int tile_tables = 1;              // plain launches of the 128-tile kernels take the XCD-balanced tile table instead of the formula map

@@ -821,7 +821,8 @@ __global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
 // owns 32 rows, a wave 16 of them; everything is computed transposed so that a finished tile is already the next
 // product's B operand: R^T = A_t^T - sum L[t,s] X_s^T accumulates in the MFMA D layout, X_t^T = inv(L_tt) R^T takes it as
 // it is.  L passes through LDS in four phases of 32 rows (all of it is fetched into registers up front); 67 KB of LDS.
-struct TrsmTilesArgs { double *A; long lda; const double *L; long ldl; const double *dinv; };
+struct TrsmTilesArgs { double *A; long lda; const double *L; long ldl; const double *dinv;
+                       unsigned long long *stamps; int seq; };      // diagnostics (option "chain_stamps"): per-workgroup start / end times
 
 __global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
     constexpr int LDS_ = 130;
@@ -830,6 +831,8 @@ __global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
     __builtin_amdgcn_s_setprio(3);        // a step of the chain: ahead of the trailing-update waves it shares its SIMDs with
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
+    unsigned long long t_start = 0;
+    if (g.stamps && tid == 0) t_start = __builtin_amdgcn_s_memrealtime();
     double *Arows = g.A + (long)blockIdx.x * 32 * g.lda;
     // every global load of the kernel goes out at once (the phases would otherwise each wait a memory round trip):
     // the workgroup's 32 rows of A, all 128 rows of L (four phases of 32), the eight tile inverses
@@ -893,6 +896,13 @@ __global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
 #pragma unroll
     for (int p = 0; p < 16; ++p)
         *reinterpret_cast<double2_t *>(Arows + (long)(2 * p + wave) * g.lda + 2 * lane) = *reinterpret_cast<const double2_t *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]);
+    if (g.stamps && tid == 0) {           // {launch number, workgroup, start, end} in 100 MHz ticks
+        const unsigned long long i = atomicAdd(g.stamps, 1ull);
+        if (i < (1ull << 20)) {
+            unsigned long long *e = g.stamps + 8 + 4 * i;
+            e[0] = (unsigned long long)g.seq; e[1] = blockIdx.x; e[2] = t_start; e[3] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
 }
 
 // LDS-free variant for the (M,K) x (N,K) layout (the trailing update): every wave loads its own MFMA operands straight
@@ -1267,7 +1277,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
 int launch_trsm_tiles(fvgp_handle *h, double *A, int64_t lda, int64_t rows, const double *L, int64_t ldl, const double *dinv) {
     if (rows <= 0) return 0;
     if (rows % 32 || (lda & 1) || (ldl & 1) || ((uintptr_t)A & 15) || ((uintptr_t)L & 15)) { fvgp_set_error("trsm_tiles: rows % 32, even leading dimensions, 16-byte alignment"); return -2; }
-    TrsmTilesArgs g{A, (long)lda, L, (long)ldl, dinv};
+    TrsmTilesArgs g{A, (long)lda, L, (long)ldl, dinv, h->chain_stamps, h->chain_seq++};
     hipLaunchKernelGGL(trsm_tiles_kernel, dim3((unsigned)(rows / 32)), dim3(128), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
