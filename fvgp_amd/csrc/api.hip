@@ -49,6 +49,8 @@ int fvgp_hip_create(fvgp_handle **out, int device, void *stream) {
     h->stream = (hipStream_t)stream;
     HIPCHK(hipMalloc((void **)&h->red, RED_SLOTS * sizeof(double)));
     HIPCHK(hipMalloc((void **)&h->dinfo, 64));
+    HIPCHK(hipMalloc((void **)&h->cu_yield, (size_t)CU_YIELD_KEYS * CU_YIELD_STRIDE * sizeof(int)));
+    HIPCHK(hipMemset(h->cu_yield, 0, (size_t)CU_YIELD_KEYS * CU_YIELD_STRIDE * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&h->hpin, RED_SLOTS * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     *out = h;
@@ -73,6 +75,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     if (h->logdet_parts) (void)hipFree(h->logdet_parts);
     if (h->red) (void)hipFree(h->red);
     if (h->dinfo) (void)hipFree(h->dinfo);
+    if (h->cu_yield) (void)hipFree(h->cu_yield);
     if (h->vec) (void)hipFree(h->vec);
     if (h->hpin) (void)hipHostFree(h->hpin);
     delete h;
@@ -140,6 +143,9 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "block_inverses")) { h->block_inverses = value ? 1 : 0; return 0; }
     if (!strcmp(key, "potri_kminor")) { h->potri_kminor = value ? 1 : 0; return 0; }
     if (!strcmp(key, "update_reserve")) { h->update_reserve = (int)value; return 0; }
+    if (!strcmp(key, "leaf_yield")) { h->leaf_yield = (int)value; return 0; }
+    if (!strcmp(key, "outer_block_small")) { if (value < 0 || value % TILE) return -3; h->outer_block_small = value; return 0; }
+    if (!strcmp(key, "small_threshold")) { h->small_threshold = value; return 0; }
     if (!strcmp(key, "overlap_cols")) { h->overlap_cols = value ? 1 : 0; return 0; }
     if (!strcmp(key, "reserve_rows")) { h->reserve_rows = value; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
@@ -445,7 +451,12 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     std::vector<int64_t> bnd;
     for (int64_t J0 = 0; J0 < np;) {
         bnd.push_back(J0);
-        const int64_t w = (h->outer_block_big > NB && np - J0 > h->big_threshold) ? h->outer_block_big : NB;
+        // three widths: `outer_block_big` (2048) while the trailing update hides any chain, NB (1024), and `outer_block_small`
+        // (512) for the last `small_threshold` rows, where the chain is what the factorisation waits for: a 512-wide panel's
+        // update tiles retire twice as often (K = 512), so the chain's many-workgroup kernels find slots sooner (N=8k -4 %,
+        // N=12k -3 %, N=20k +-0 with 512 throughout)
+        int64_t w = (h->outer_block_big > NB && np - J0 > h->big_threshold) ? h->outer_block_big : NB;
+        if (h->outer_block_small > 0 && h->outer_block_small < w && np - J0 <= h->small_threshold) w = h->outer_block_small;
         J0 = (J0 + w < np) ? J0 + w : np;
     }
     bnd.push_back(np);

@@ -9,6 +9,8 @@
 
 constexpr int TILE = FVGP_TILE;        // 128: tile edge of every kernel and the leaf Cholesky block
 constexpr int LEAF_DOUBLES = TILE * TILE;
+constexpr int CU_YIELD_STRIDE = 32;    // ints between two compute units' yield counters (one 128-byte line each)
+constexpr int CU_YIELD_KEYS = 8 * 256;   // XCC id (3 bits) << 8 | HW_ID[15:8] (CU, SH, SE)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -73,6 +75,12 @@ struct fvgp_handle {
     int update_reserve = 0, n_cus = 256;
     int64_t reserve_rows = 0;         // ... applied while at most this many rows remain to be updated (0: never, < 0: always)
     int *tile_queue = nullptr; unsigned tile_queue_next = 0;
+    // cooperative yield: one counter per compute unit (key = XCC id << 8 | HW_ID[15:8], a line of its own each).  A leaf that
+    // runs under look-ahead raises its CU's counter; the trailing-update waves of that CU poll it once per K step with a scalar
+    // load and sleep while it is up (fp64 MFMA and the vector ALU share a pipe: beside an MFMA stream every dependent instruction
+    // of the latency-bound leaf waits for a 64-cycle MFMA -- 3.5 to 6.7 times the standalone time).  Option "leaf_yield".
+    int *cu_yield = nullptr; int leaf_yield = 1;
+    int64_t outer_block_small = 512, small_threshold = 12288;   // panel width for the last `small_threshold` rows (potrf_driver)
     int gemm_probe = 0;               // fvgp_hip_gemm launches a K-loop timing probe instead (diagnostics)
     int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel

@@ -29,6 +29,9 @@ namespace {
 #ifndef FVGP_GEMM_DMA_DEFAULT
 #define FVGP_GEMM_DMA_DEFAULT 1
 #endif
+#ifndef FVGP_GEMM_YIELD_DEFAULT
+#define FVGP_GEMM_YIELD_DEFAULT 1
+#endif
 #ifndef FVGP_GEMM_LEAN_DEFAULT
 #define FVGP_GEMM_LEAN_DEFAULT 1
 #endif
@@ -59,6 +62,7 @@ struct GemmArgs {
     long ksplit, csplit;              // split-K (gridDim.y > 1): block row y takes K elements [y ksplit, (y+1) ksplit), its tile goes to C + y csplit
     int ny;                           // strided batch (ksplit == 0, gridDim.y > 1): problem (y, z) = (blockIdx.y % ny, blockIdx.y / ny)
     long ab1, ab2, bb1, bb2, cb1, cb2;   // takes its operands at A + y ab1 + z ab2, B + .., C + ..
+    const int *yield;                 // trailing update (ROLE 1): per-CU counters raised by a co-resident leaf (common.h, cu_yield)
 };
 
 // linear index -> (ti, tj).  Tiles are enumerated in super-tiles of 8 x SN (SN = min(8, tiles_n)),
@@ -395,6 +399,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         u32x4 la[4] = {}, lb[4] = {};
         u32x4 sink = {};
         int soff = 0;                                   // byte offset of the K step being fetched
+        // Cooperative yield (the trailing update only).  A leaf of the panel chain that shares this compute unit (look-ahead)
+        // is a chain of dependent vector / MFMA instructions, and beside this loop each of them waits for a 64-cycle MFMA:
+        // 130-250 us instead of 37.  The leaf raises its CU's counter; every wave here reads that word once per K step with a
+        // scalar load (no vector-ALU work: issued behind the step's LDS reads, long landed when the step's MFMAs are through)
+        // and sleeps while it is up -- the CU is the leaf's for its 37 us, this workgroup loses those instead of sharing its
+        // pipes for 250.  Bounded: a wave sleeps at most ~1 ms per tile whatever the counter says.
+        constexpr bool YIELD = ROLE == 1 && !PERSIST && DBG == 0 && FVGP_GEMM_YIELD_DEFAULT;
+        const int *yp = nullptr;
+        int ybudget = 256;
+        if constexpr (YIELD) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 8, 8)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+            yp = g.yield + ((xcc << 8 | hw) * CU_YIELD_STRIDE);
+        }
         auto kstep = [&](auto curc, const bool more) {
             constexpr int CUR = decltype(curc)::value;
             if (more && !(PB & 1) && !(PB & 8)) {
@@ -427,6 +446,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                     }
                 }
             __builtin_amdgcn_sched_barrier(0);
+            int yv = 0;
+            if constexpr (YIELD) asm volatile("s_load_dword %0, %1, 0x0 glc" : "={s95}"(yv) : "s"(yp));
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -437,6 +458,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                         for (int j = 0; j < 4; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[hf][i][s], b2[hf][j][s], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(ROLE ? 0 : 1);
+            if constexpr (YIELD) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+{s95}"(yv) :: "memory");
+                while (yv != 0 && ybudget > 0) {
+                    --ybudget;
+                    __builtin_amdgcn_s_sleep(127);
+                    asm volatile("s_load_dword %0, %1, 0x0 glc\n s_waitcnt lgkmcnt(0)" : "={s95}"(yv) : "s"(yp) : "memory");
+                }
+            }
             if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next step's image has landed
             if (!DMA && more && !(PB & 1) && !(PB & 16)) {
 #pragma unroll
@@ -1185,7 +1214,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     if ((d.bc_ranks > 1 || d.bc_off) && d.b_nmajor) { fvgp_set_error("gemm: block-cyclic B needs the (N, K) layout"); return -7; }
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
-    g.tab = nullptr; g.queue = nullptr; g.ksplit = 0; g.csplit = 0;
+    g.tab = nullptr; g.queue = nullptr; g.ksplit = 0; g.csplit = 0; g.yield = h->cu_yield;
     g.ny = 0; g.ab1 = g.ab2 = g.bb1 = g.bb2 = g.cb1 = g.cb2 = 0;
     const bool plain_k = d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && d.kei == 0 && d.kej == 0;
     if (h->tile_tables && plain_k && !d.rev_m && !d.probe && g.tiles_m < 32768 && g.tiles_n < 32768 &&

@@ -47,6 +47,7 @@ struct LeafArgs {
     long a_stride, linv_stride;   // batched mode: block b at A + b*a_stride
     unsigned long *stamps;        // diagnostics: s_memtime at the phase boundaries (nullptr in the product path)
     int tiles_only;               // linv <- the inverses of the eight 16x16 diagonal tiles only (8 x 256 doubles, lower, zeros above)
+    int *yield;                   // per-CU counters the trailing update's waves poll (common.h, cu_yield); nullptr: nobody yields
 };
 
 __device__ __forceinline__ double4_t mfma(double a, double b, double4_t c) {
@@ -186,6 +187,15 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
     double *A = g.A + (long)blockIdx.x * g.a_stride;
     double *linv = g.linv + (long)blockIdx.x * g.linv_stride;
     int nst = 0;
+    // this compute unit is the leaf's while it runs: the co-resident trailing-update workgroup sleeps (gemm.hip, YIELD)
+    int *yflag = nullptr;
+    if (g.yield && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 8, 8)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        yflag = g.yield + ((xcc << 8 | hw) * CU_YIELD_STRIDE);
+        atomicAdd(yflag, 1);
+    }
 #define FVGP_STAMP() do { if (g.stamps && tid == 0) g.stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
     FVGP_STAMP();
 
@@ -333,6 +343,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
             linv[wave * 256 + a * 16 + r] = d;
         }
         FVGP_STAMP();
+        if (yflag) atomicAdd(yflag, -1);
         return;
     }
     // ---- block column `wave` of inv(L), kept in registers in MFMA B-operand layout -----------------------
@@ -394,6 +405,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
         }
     }
     FVGP_STAMP();
+    if (yflag) atomicAdd(yflag, -1);
 #undef FVGP_STAMP
 }
 
@@ -405,6 +417,7 @@ int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *lo
     g.tiles_only = tiles_only;
     g.A = A; g.lda = lda; g.linv = linv; g.logdet_part = logdet_part; g.info = h->dinfo; g.info_base = info_base;
     g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid; g.stamps = h->leaf_stamps;
+    g.yield = (h->leaf_yield && do_factor) ? h->cu_yield : nullptr;
     hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
@@ -414,7 +427,7 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
     if (nblk <= 0) return 0;
     LeafArgs g;
     g.A = const_cast<double *>(L); g.lda = ldl; g.linv = linv; g.logdet_part = nullptr; g.info = h->dinfo; g.info_base = 0;
-    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr; g.tiles_only = 0;
+    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr; g.tiles_only = 0; g.yield = nullptr;
     hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)nblk), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
