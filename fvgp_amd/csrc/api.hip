@@ -76,6 +76,8 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     if (h->red) (void)hipFree(h->red);
     if (h->dinfo) (void)hipFree(h->dinfo);
     if (h->cu_yield) (void)hipFree(h->cu_yield);
+    if (h->panel_w) (void)hipFree(h->panel_w);
+    if (h->panel_ws) (void)hipFree(h->panel_ws);
     if (h->vec) (void)hipFree(h->vec);
     if (h->hpin) (void)hipHostFree(h->hpin);
     delete h;
@@ -144,6 +146,8 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "potri_kminor")) { h->potri_kminor = value ? 1 : 0; return 0; }
     if (!strcmp(key, "update_reserve")) { h->update_reserve = (int)value; return 0; }
     if (!strcmp(key, "leaf_yield")) { h->leaf_yield = (int)value; return 0; }
+    if (!strcmp(key, "panel_square")) { h->panel_square = (int)value; return 0; }
+    if (!strcmp(key, "panel_square_rows")) { h->panel_square_rows = value; return 0; }
     if (!strcmp(key, "outer_block_small")) { if (value < 0 || value % TILE) return -3; h->outer_block_small = value; return 0; }
     if (!strcmp(key, "small_threshold")) { h->small_threshold = value; return 0; }
     if (!strcmp(key, "overlap_cols")) { h->overlap_cols = value ? 1 : 0; return 0; }
@@ -397,6 +401,71 @@ static int panel_factor_nested(fvgp_handle *h, double *A, int64_t n, int64_t np,
     return 0;
 }
 
+// inverse of ONE w x w diagonal block of L (w = 128 times a power of two) from its 128-block inverses, by the doubling of
+// ensure_winv: W (w x w, row stride w), T scratch of w*w/4 doubles
+static int block_inverse(fvgp_handle *h, const double *Lsq, int64_t ldl, const double *linv0, int64_t w, double *W, double *T) {
+    int rc = launch_winv_seed(h, linv0, w / TILE, W, w); if (rc) return rc;
+    for (int64_t hs = TILE; hs < w; hs *= 2) {
+        const int64_t ny = w / (2 * hs);
+        GemmDesc a{};   // T[y] = C inv(A)
+        a.a_kmajor = 0; a.b_nmajor = 1; a.lower = 0; a.M = hs; a.N = hs; a.K = hs; a.alpha = 1.0; a.beta = 0.0;
+        a.A = Lsq + hs * ldl; a.lda = ldl; a.B = W; a.ldb = w; a.C = T; a.ldc = hs;
+        a.batch_y = (int)ny; a.batch_z = 1;
+        a.a_by = 2 * hs * ldl + 2 * hs; a.b_by = 2 * hs * w + 2 * hs; a.c_by = hs * hs;
+        rc = launch_gemm(h, a); if (rc) return rc;
+        GemmDesc b{};   // W21[y] = -inv(B) T
+        b.a_kmajor = 0; b.b_nmajor = 1; b.lower = 0; b.M = hs; b.N = hs; b.K = hs; b.alpha = -1.0; b.beta = 0.0;
+        b.A = W + hs * w + hs; b.lda = w; b.B = T; b.ldb = hs; b.C = W + hs * w; b.ldc = w;
+        b.batch_y = (int)ny; b.batch_z = 1;
+        b.a_by = 2 * hs * w + 2 * hs; b.b_by = hs * hs; b.c_by = 2 * hs * w + 2 * hs;
+        rc = launch_gemm(h, b); if (rc) return rc;
+    }
+    return 0;
+}
+
+// Square-first panel.  The chain (leaf / TRSM / in-panel update per 128 columns) factors only the panel's w x w diagonal
+// square; the rows below it then follow in ONE product with the explicit inverse of the square,
+//     L[below, panel] = A[below, panel] inv(L_sq)^T       (w x w inverse by doubling from the 128-block inverses),
+// from a compact copy of those rows (a tile of the product reads the columns to its left, so it cannot run in place), on the
+// fast (M,K) x (N,K) loop with the triangular K range k < 128 (tj + 1).  Same flops as the chain's per-step TRSMs and in-panel
+// updates of those rows, in m/128 x w/128 tiles with K up to w instead of 2 w/128 launches of m/32 latency-bound workgroups:
+// under look-ahead every workgroup of the chain waits for a slot one retiring trailing-update tile frees (about two per
+// microsecond), which is what made a panel at 20k rows take 4.6 ms.  Backward error ~ eps cond(L_sq) instead of
+// eps cond(128-block) -- the bound the posterior's and POTRI's 1024-block inverses already work under.
+static int panel_factor_square(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+    const int64_t w = Jend - J0, below = np - Jend;
+    bool pow2 = w >= 2 * TILE;
+    for (int64_t t = w / TILE; t > 1; t >>= 1) if (t & 1) pow2 = false;
+    if (!h->panel_square || below <= h->panel_square_rows || !pow2) return panel_factor_nested(h, A, n, np, lda, J0, Jend);
+    int rc = panel_factor_nested(h, A, n, Jend, lda, J0, Jend);          // the chain, confined to the square
+    if (rc) return rc;
+    const size_t need_w = (size_t)w * w + (size_t)w * w / 4, need_ws = (size_t)below * w;
+    if (need_w > h->panel_w_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->panel_w) HIPCHK(hipFree(h->panel_w));
+        h->panel_w = nullptr; h->panel_w_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->panel_w, need_w * sizeof(double)));
+        h->panel_w_cap = need_w;
+    }
+    if (need_ws > h->panel_ws_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->panel_ws) HIPCHK(hipFree(h->panel_ws));
+        h->panel_ws = nullptr; h->panel_ws_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->panel_ws, need_ws * sizeof(double)));
+        h->panel_ws_cap = need_ws;
+    }
+    double *W = h->panel_w, *T = W + (size_t)w * w, *P = h->panel_ws;
+    const double *linv0 = h->linv + (J0 / TILE) * LEAF_DOUBLES;
+    rc = launch_leaf_inverse_batched(h, A + J0 * lda + J0, lda, w / TILE, const_cast<double *>(linv0)); if (rc) return rc;
+    rc = block_inverse(h, A + J0 * lda + J0, lda, linv0, w, W, T); if (rc) return rc;
+    rc = launch_copy_panel(h, A + Jend * lda + J0, lda, P, w, below, w); if (rc) return rc;
+    GemmDesc t{};
+    t.a_kmajor = 0; t.b_nmajor = 0; t.lower = 0; t.M = below; t.N = w; t.K = w; t.alpha = 1.0; t.beta = 0.0;
+    t.A = P; t.lda = w; t.B = W; t.ldb = w; t.C = A + Jend * lda + J0; t.ldc = lda;
+    t.kb0 = 0; t.ke0 = TILE; t.kej = TILE;                                // W is lower triangular: k < 128 (tj + 1)
+    return launch_gemm(h, t);
+}
+
 static double lower_flops(int64_t M, int64_t N, int64_t K) {     // algorithmic flops of a lower-tile update
     const double tm = (double)(M / TILE), tn = (double)(N / TILE);
     const double tiles = tn * (tn + 1.0) * 0.5 + (tm - tn) * tn;
@@ -466,13 +535,13 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     const bool la = h->lookahead && npan > 2 && np >= 6144;
     if (!la) {
         for (size_t J = 0; J < npan; ++J) {
-            rc = panel_factor_nested(h, A, n, np, lda, bnd[J], bnd[J + 1]); if (rc) return rc;
+            rc = panel_factor_square(h, A, n, np, lda, bnd[J], bnd[J + 1]); if (rc) return rc;
             if (np > bnd[J + 1]) { rc = timed_update(bnd[J], bnd[J + 1], bnd[J + 1], np); if (rc) return rc; }
         }
     } else {
         rc = fvgp_ensure_side(h); if (rc) return rc;
         hipStream_t mainS = h->stream, sideS = h->side;
-        rc = panel_factor_nested(h, A, n, np, lda, bnd[0], bnd[1]); if (rc) return rc;      // panel 0 on the main stream
+        rc = panel_factor_square(h, A, n, np, lda, bnd[0], bnd[1]); if (rc) return rc;      // panel 0 on the main stream
         if (h->overlap_cols && np >= 12288) {      // (measured: N = 8k +2.7 %, N = 20k -1.2 %, N = 50k -0.55 %)
             // The update of the next panel's columns goes to the side stream too, in front of that panel's chain, and the big
             // update of the rest starts on the main stream at the same time (they write disjoint columns): the small launch's
@@ -486,7 +555,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
                 if (J > 0) HIPCHK(hipStreamWaitEvent(sideS, h->ev_big2[p ^ 1], 0));     // the big update J-1 touched these columns
                 h->stream = sideS;
                 rc = timed_update(J0, Jend, Jend, Nend);
-                if (!rc) rc = panel_factor_nested(h, A, n, np, lda, Jend, Nend);
+                if (!rc) rc = panel_factor_square(h, A, n, np, lda, Jend, Nend);
                 h->stream = mainS;
                 if (rc) return rc;
                 HIPCHK(hipEventRecord(h->ev_pan2[p ^ 1], sideS));
@@ -504,7 +573,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             // (2) side: factor the next panel as soon as (1) is done ...
             HIPCHK(hipStreamWaitEvent(sideS, h->ev_cols, 0));
             h->stream = sideS;
-            rc = panel_factor_nested(h, A, n, np, lda, Jend, Nend);
+            rc = panel_factor_square(h, A, n, np, lda, Jend, Nend);
             h->stream = mainS;
             if (rc) return rc;
             HIPCHK(hipEventRecord(h->ev_panel, sideS));

@@ -80,6 +80,11 @@ struct fvgp_handle {
     // load and sleep while it is up (fp64 MFMA and the vector ALU share a pipe: beside an MFMA stream every dependent instruction
     // of the latency-bound leaf waits for a 64-cycle MFMA -- 3.5 to 6.7 times the standalone time).  Option "leaf_yield".
     int *cu_yield = nullptr; int leaf_yield = 1;
+    // square-first panels (potrf_driver, panel_factor_square): the inverse of the panel's square + T scratch, and the compact copy of
+    // the rows below it
+    double *panel_w = nullptr; size_t panel_w_cap = 0;
+    double *panel_ws = nullptr; size_t panel_ws_cap = 0;
+    int panel_square = 0; int64_t panel_square_rows = 0;   // measured away: N=8k +30 %, N=20k +2 %, N=50k +0.5 %
     int64_t outer_block_small = 512, small_threshold = 12288;   // panel width for the last `small_threshold` rows (potrf_driver)
     int gemm_probe = 0;               // fvgp_hip_gemm launches a K-loop timing probe instead (diagnostics)
     int lookahead = 1;
@@ -211,7 +216,8 @@ int launch_rows_dot(fvgp_handle *h, const double *KT, int64_t ldk, const double 
 int launch_rows_sumsq_base(fvgp_handle *h, const double *KT, int64_t ldk, int64_t n, int64_t P, double base, double *out);
 int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M, int64_t N, int lower, const double *C, int64_t ldc, double beta,
                          double *out, int64_t ldo);
-int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W);
+int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W, int64_t w = 1024);
+int launch_copy_panel(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t rows, int64_t cols);
 int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D);
 int launch_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);
 int64_t kt_alpha_scratch_doubles(int64_t n, int64_t P, int ncol);

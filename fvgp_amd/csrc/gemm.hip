@@ -853,7 +853,9 @@ __global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
 struct TrsmTilesArgs { double *A; long lda; const double *L; long ldl; const double *dinv;
                        unsigned long long *stamps; int seq; };      // diagnostics (option "chain_stamps"): per-workgroup start / end times
 
-__global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
+// at most 256 registers: under look-ahead a workgroup must fit beside the ONE trailing-update wave (224) a SIMD keeps when the other
+// update workgroup of its compute unit retires (with 362 the kernel waited for the whole update to drain: 5 ms at 20k rows)
+__global__ __launch_bounds__(128, 2) void trsm_tiles_kernel(TrsmTilesArgs g) {
     constexpr int LDS_ = 130;
     __shared__ double sX[32 * LDS_];
     __shared__ double sL[32 * LDS_];
@@ -865,23 +867,38 @@ __global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
     double *Arows = g.A + (long)blockIdx.x * 32 * g.lda;
     // every global load of the kernel goes out at once (the phases would otherwise each wait a memory round trip):
     // the workgroup's 32 rows of A, all 128 rows of L (four phases of 32), the eight tile inverses
-    double2_t ra[16], rl[4][16], rd[8];
+    // (two of the four phases of L up front, the other two as soon as a phase's registers have gone to LDS -- a phase computes
+    // for longer than a load takes: 245 registers instead of 362, see the launch bounds)
+    // Addresses: one buffer descriptor per operand, the lane's 16 bytes as the only vector offset, the row as a scalar offset
+    // (a 64-bit pointer per load would hold 112 more registers than the data).
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(Arows)), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t l_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(g.L)), 0, 0xffffffff, 0x00020000);
+    const int vo = 16 * lane;
+    const int arow = (int)(g.lda * 8), lrow = (int)(g.ldl * 8);
+    u32x4 ra[16], rl[2][16];
+    double2_t rd[8];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) ra[p] = *reinterpret_cast<const double2_t *>(Arows + (long)(2 * p + wave) * g.lda + 2 * lane);
+    for (int p = 0; p < 16; ++p) ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_src, vo, (2 * p + wave_u) * arow, 0);
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph)
+    for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
-            rl[ph][p] = *reinterpret_cast<const double2_t *>(g.L + (long)(32 * ph + 2 * p + wave) * g.ldl + 2 * lane);
+        for (int p = 0; p < 16; ++p) rl[ph][p] = __builtin_amdgcn_raw_buffer_load_b128(l_src, vo, (32 * ph + 2 * p + wave_u) * lrow, 0);
 #pragma unroll
     for (int t = 0; t < 8; ++t) rd[t] = *reinterpret_cast<const double2_t *>(g.dinv + t * 256 + 2 * tid);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) *reinterpret_cast<double2_t *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]) = ra[p];
+    for (int p = 0; p < 16; ++p) *reinterpret_cast<u32x4 *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]) = ra[p];
     double *xrow = &sX[(16 * wave + r) * LDS_];
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
 #pragma unroll
-        for (int p = 0; p < 16; ++p) *reinterpret_cast<double2_t *>(&sL[(2 * p + wave) * LDS_ + 2 * lane]) = rl[ph][p];
+        for (int p = 0; p < 16; ++p) *reinterpret_cast<u32x4 *>(&sL[(2 * p + wave) * LDS_ + 2 * lane]) = rl[ph & 1][p];
+        if (ph + 2 < 4) {
+            __builtin_amdgcn_sched_barrier(0);        // behind the LDS writes: the phase's registers are free again
+#pragma unroll
+            for (int p = 0; p < 16; ++p) rl[ph & 1][p] = __builtin_amdgcn_raw_buffer_load_b128(l_src, vo, (32 * (ph + 2) + 2 * p + wave_u) * lrow, 0);
+        }
         __syncthreads();
         {   // the two diagonal tiles of these rows <- their inverses (thread -> two adjacent entries of each tile)
             const int a = tid >> 3, b = (tid & 7) * 2;
@@ -924,7 +941,7 @@ __global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 16; ++p)
-        *reinterpret_cast<double2_t *>(Arows + (long)(2 * p + wave) * g.lda + 2 * lane) = *reinterpret_cast<const double2_t *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]);
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]), a_src, vo, (2 * p + wave_u) * arow, 0);
     if (g.stamps && tid == 0) {           // {launch number, workgroup, start, end} in 100 MHz ticks
         const unsigned long long i = atomicAdd(g.stamps, 1ull);
         if (i < (1ull << 20)) {

@@ -315,16 +315,30 @@ __global__ void splitk_reduce_kernel(const double *ws, int split, long M, long N
 
 // seed of the 1024-block inverses: block row b (128 x 1024) of W <- zeros, with inv(L_bb) at its place on the diagonal of
 // the 1024-block the row belongs to
-__global__ __launch_bounds__(256) void winv_seed_kernel(const double *linv, double *W) {
+__global__ __launch_bounds__(256) void winv_seed_kernel(const double *linv, double *W, int wshift) {
     const long b = blockIdx.x;
-    const int c0 = (int)(b & 7) * 128;
+    const int w = 1 << wshift;                       // width of the blocks being inverted (1024; 512 ... 2048 for a panel's square)
+    const int c0 = (int)(b & ((w >> 7) - 1)) * 128;
     const double *src = linv + b * 128 * 128;
-    double *dst = W + b * 128 * 1024;
-    for (int e = threadIdx.x * 2; e < 128 * 1024; e += 512) {
-        const int i = e >> 10, j = e & 1023;
+    double *dst = W + b * 128 * w;
+    // blockIdx.y: sixteen rows of the block row each (eight workgroups per 128 rows: a panel's seed is on the chain's path)
+    for (int e = (blockIdx.y * 16 << wshift) + threadIdx.x * 2; e < ((blockIdx.y + 1) * 16 << wshift); e += 512) {
+        const int i = e >> wshift, j = e & (w - 1);
         double2_t v = {0.0, 0.0};
         if (j >= c0 && j < c0 + 128) v = *reinterpret_cast<const double2_t *>(src + i * 128 + (j - c0));
         *reinterpret_cast<double2_t *>(dst + e) = v;
+    }
+}
+
+// dst (rows x cols, row stride ldd) <- src (row stride lds), 16 bytes per thread and trip: the compact copy of the rows below a
+// panel's square (api.hip, panel_factor_square)
+__global__ __launch_bounds__(256) void copy_panel_kernel(const double *src, long lds, double *dst, long ldd, long rows, int cols2) {
+    const long tot = rows * cols2;
+#pragma unroll 4
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+        const long i = e / cols2;
+        const int j = (int)(e - i * cols2);
+        *reinterpret_cast<double2_t *>(dst + i * ldd + 2 * j) = *reinterpret_cast<const double2_t *>(src + i * lds + 2 * j);
     }
 }
 
@@ -648,9 +662,21 @@ int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M,
     return 0;
 }
 
-int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W) {
+int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W, int64_t w) {
     if (nblk <= 0) return 0;
-    hipLaunchKernelGGL(winv_seed_kernel, dim3((unsigned)nblk), dim3(256), 0, h->stream, linv, W);
+    int wshift = 7;
+    while ((1L << wshift) < w) ++wshift;
+    if ((1L << wshift) != w || w > 8192) { fvgp_set_error("block inverses: the width must be 128 times a power of two"); return -5; }
+    hipLaunchKernelGGL(winv_seed_kernel, dim3((unsigned)nblk, 8), dim3(256), 0, h->stream, linv, W, wshift);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_copy_panel(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t rows, int64_t cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    if ((cols & 1) || (lds & 1) || (ldd & 1) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) { fvgp_set_error("copy_panel: even widths, 16-byte alignment"); return -2; }
+    long blocks = (rows * (cols / 2) + 1023) / 1024; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(copy_panel_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, src, (long)lds, dst, (long)ldd, (long)rows, (int)(cols / 2));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -1,5 +1,6 @@
 """Same-box A/B of one library option on the log-likelihood evaluation: alternates the values round by round in ONE process.
   python tools/option_ab.py leaf_yield 0,1 8000,20000,50000 [reps]
+  python tools/option_ab.py panel_square=0/panel_square=1,update_reserve=16 - 20000     (whole configurations, '/'-separated)
 Prints the median and the minimum of the evaluation time per (size, value)."""
 import os
 import sys
@@ -14,7 +15,11 @@ def main():
     import torch
     from fvgp_amd import _lib
     key = sys.argv[1]
-    values = [int(v) for v in sys.argv[2].split(",")]
+    if "=" in key:
+        values = key.split("/")
+        key = "cfg"
+    else:
+        values = [int(v) for v in sys.argv[2].split(",")]
     sizes = [int(v) for v in sys.argv[3].split(",")]
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
     H = _lib.Handle(0)
@@ -28,7 +33,11 @@ def main():
         out = {}
         for t in range(reps + 1):
             for v in values:
-                H.set_option(key, v)
+                if key == "cfg":
+                    for kv in v.split(","):
+                        H.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+                else:
+                    H.set_option(key, v)
                 theta = np.array([1.0, 0.3, 0.3, 0.3])
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 out[v] = H.loglik(0, xd, theta, V, ym, KV, alpha)
