@@ -51,6 +51,8 @@ int fvgp_hip_create(fvgp_handle **out, int device, void *stream) {
     HIPCHK(hipMalloc((void **)&h->dinfo, 64));
     HIPCHK(hipMalloc((void **)&h->cu_yield, (size_t)CU_YIELD_KEYS * CU_YIELD_STRIDE * sizeof(int)));
     HIPCHK(hipMemset(h->cu_yield, 0, (size_t)CU_YIELD_KEYS * CU_YIELD_STRIDE * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&h->chain_tickets, 2 * 256 * sizeof(int)));
+    HIPCHK(hipMemset(h->chain_tickets, 0, 2 * 256 * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&h->hpin, RED_SLOTS * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     *out = h;
@@ -76,6 +78,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     if (h->red) (void)hipFree(h->red);
     if (h->dinfo) (void)hipFree(h->dinfo);
     if (h->cu_yield) (void)hipFree(h->cu_yield);
+    if (h->chain_tickets) (void)hipFree(h->chain_tickets);
     if (h->panel_w) (void)hipFree(h->panel_w);
     if (h->panel_ws) (void)hipFree(h->panel_ws);
     if (h->vec) (void)hipFree(h->vec);
@@ -146,6 +149,9 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "potri_kminor")) { h->potri_kminor = value ? 1 : 0; return 0; }
     if (!strcmp(key, "update_reserve")) { h->update_reserve = (int)value; return 0; }
     if (!strcmp(key, "leaf_yield")) { h->leaf_yield = (int)value; return 0; }
+    if (!strcmp(key, "chain_yield")) { h->chain_yield = (int)value; return 0; }
+    if (!strcmp(key, "chain_loop")) { if (value < 0) return -3; h->chain_loop = (int)value; return 0; }
+    if (!strcmp(key, "update_stagger")) { if (value != 0 && value != 2 && value != 4 && value != 8) return -3; h->update_stagger = (int)value; return 0; }
     if (!strcmp(key, "panel_square")) { h->panel_square = (int)value; return 0; }
     if (!strcmp(key, "panel_square_rows")) { h->panel_square_rows = value; return 0; }
     if (!strcmp(key, "outer_block_small")) { if (value < 0 || value % TILE) return -3; h->outer_block_small = value; return 0; }
@@ -573,7 +579,9 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             // (2) side: factor the next panel as soon as (1) is done ...
             HIPCHK(hipStreamWaitEvent(sideS, h->ev_cols, 0));
             h->stream = sideS;
+            h->chain_contended = np - Nend >= 4096;      // the rest of this panel's update runs beside the chain
             rc = panel_factor_square(h, A, n, np, lda, Jend, Nend);
+            h->chain_contended = false;
             h->stream = mainS;
             if (rc) return rc;
             HIPCHK(hipEventRecord(h->ev_panel, sideS));

@@ -11,6 +11,16 @@ constexpr int TILE = FVGP_TILE;        // 128: tile edge of every kernel and the
 constexpr int LEAF_DOUBLES = TILE * TILE;
 constexpr int CU_YIELD_STRIDE = 32;    // ints between two compute units' yield counters (one 128-byte line each)
 constexpr int CU_YIELD_KEYS = 8 * 256;   // XCC id (3 bits) << 8 | HW_ID[15:8] (CU, SH, SE)
+#if defined(__HIPCC__)
+// this compute unit's yield counter (fvgp_handle::cu_yield): raised by the latency-bound kernels of the panel chain while one
+// of their workgroups runs here, polled by the trailing update's waves (gemm.hip, YIELD)
+__device__ __forceinline__ int *cu_yield_slot(int *base) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 8, 8)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    return base + ((xcc << 8 | hw) * CU_YIELD_STRIDE);
+}
+#endif
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -79,7 +89,12 @@ struct fvgp_handle {
     // runs under look-ahead raises its CU's counter; the trailing-update waves of that CU poll it once per K step with a scalar
     // load and sleep while it is up (fp64 MFMA and the vector ALU share a pipe: beside an MFMA stream every dependent instruction
     // of the latency-bound leaf waits for a 64-cycle MFMA -- 3.5 to 6.7 times the standalone time).  Option "leaf_yield".
-    int *cu_yield = nullptr; int leaf_yield = 1;
+    int *cu_yield = nullptr; int leaf_yield = 1, chain_yield = 1;
+    // chunk loops of the chain's many-workgroup kernels under look-ahead (gemm.hip, chain_grid): ring of {ticket, finished} pairs,
+    // `chain_loop` = the 60 of G = sqrt(60 chunks) (0: off), `chain_contended` set by the drivers around a chain that runs under a
+    // trailing update
+    int *chain_tickets = nullptr; unsigned chain_ticket_next = 0; int chain_loop = 0; bool chain_contended = false;   // measured: N=12k +2 %, N=20k +0.8 %, N=50k +-0 with 60 -- off
+    int update_stagger = 0;           // phases (0, 2, 4, 8) the first wave of a trailing update's workgroups starts in (gemm.hip)
     // square-first panels (potrf_driver, panel_factor_square): the inverse of the panel's square + T scratch, and the compact copy of
     // the rows below it
     double *panel_w = nullptr; size_t panel_w_cap = 0;

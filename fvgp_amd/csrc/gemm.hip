@@ -54,6 +54,7 @@ struct GemmArgs {
     int ls, lo;
     int bcr, bcb, bco;                // B rows in all-gather (block-cyclic) order, see GemmDesc
     int rev;                          // tile rows enumerated last to first
+    int stagger;                      // trailing update: phases the first wave of workgroups starts in (0 / 1: all at once), see the kernel
     long K;
     long kb0, kbi, kbj, ke0, kei, kej;
     long ntiles;
@@ -63,6 +64,9 @@ struct GemmArgs {
     int ny;                           // strided batch (ksplit == 0, gridDim.y > 1): problem (y, z) = (blockIdx.y % ny, blockIdx.y / ny)
     long ab1, ab2, bb1, bb2, cb1, cb2;   // takes its operands at A + y ab1 + z ab2, B + .., C + ..
     const int *yield;                 // trailing update (ROLE 1): per-CU counters raised by a co-resident leaf (common.h, cu_yield)
+    int *raise;                       // chain kernels (small tiles, K = 128): raise this CU's counter while a workgroup runs (nullptr: no)
+    int *ticket; int nvb;             // K = 128 kernels under look-ahead: fewer workgroups than chunks, each pulls chunk numbers
+                                      // 0 .. nvb-1 from ticket[0] (ticket[1] counts finished workgroups; the last one zeroes both)
 };
 
 // linear index -> (ti, tj).  Tiles are enumerated in super-tiles of 8 x SN (SN = min(8, tiles_n)),
@@ -263,6 +267,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     const int nk = kend > kbeg ? (int)((kend - kbeg) / BK) : 0;
 
+    // Staggered start (the trailing update).  All tiles of a launch take the same time, so the 512 resident workgroups retire
+    // together, round after round, and a kernel of the panel chain that arrives in between (look-ahead) waits for the end of
+    // the round whatever its priority: half a tile time on average, per dependent kernel (rocprofv3: a 4-workgroup TRSM of the
+    // chain 150 us under the update, 12 us alone).  The first wave of workgroups (blocks 0 .. 511) therefore starts in
+    // `stagger` phases spread over one tile time; blocks b and b + 256 share a compute unit and start half a tile apart, so
+    // the partner's MFMAs fill the sleeper's pipe time (the launch loses nothing measurable) and slots come free `stagger`
+    // times per tile time for the rest of the launch.
+    if constexpr (ROLE == 1 && !PERSIST && DBG == 0) {
+        if (g.stagger > 1 && blockIdx.x < 512 && gridDim.x > 1024) {
+            const int ph = ((int)blockIdx.x >> 8) * (g.stagger >> 1) + (((int)blockIdx.x >> 5) & ((g.stagger >> 1) - 1));
+            // a K step of this tile takes ~3.4 us (two workgroups per CU): phase ph starts ph / stagger of a tile late
+            for (int i = (nk * ph) / g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+
     const long m0 = (long)ti * 128, n0 = (long)tj * 128;
     long nb0 = n0;                    // first row of this tile's B block
     if (!BNM) { const int idx = tj + g.bco; nb0 = ((long)(idx % g.bcr) * g.bcb + idx / g.bcr) * 128; }
@@ -409,10 +428,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const int *yp = nullptr;
         int ybudget = 256;
         if constexpr (YIELD) {
-            unsigned hw, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 8, 8)" : "=s"(hw));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-            yp = g.yield + ((xcc << 8 | hw) * CU_YIELD_STRIDE);
+            yp = cu_yield_slot(const_cast<int *>(g.yield));
         }
         auto kstep = [&](auto curc, const bool more) {
             constexpr int CUR = decltype(curc)::value;
@@ -658,6 +674,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
     if (g.lower == 1 && n0 / 128 > m0 / 128) return;   // whole 128-tiles on / below the diagonal, as the ABI says
     if (g.lower == 2 && n0 / 128 > (m0 / 128) * g.ls + g.lo) return;        // row-sharded trailing update: this rank's block rows
     const int tid = threadIdx.x;
+    int *yflag = nullptr;             // a latency-bound step of the chain: the co-resident trailing-update workgroup sleeps meanwhile
+    if (g.raise && tid == 0) { yflag = cu_yield_slot(g.raise); atomicAdd(yflag, 1); }
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 15, q = lane >> 4;
@@ -760,6 +778,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 cbase[(i * 16 + 4 * v) * g.ldc + j * 16] = alpha * acc[i][j][v] + (beta != 0.0 ? beta * old[i][v][j] : 0.0);
+    if (yflag) atomicAdd(yflag, -1);
 }
 
 // K = 128 in ONE stage, for the two products every 128-column step of the panel chain waits for (TRSM by the inverted
@@ -772,13 +791,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_small_kernel(GemmArgs g) {
 // trailing-update workgroup frees.  <64>: results that alias no operand; <128>: the in-place TRSM (the workgroup has read
 // all of its rows before it writes them).
 template <int TN>
-__global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
+__device__ __forceinline__ void k128_chunk(const GemmArgs &g, const int vb, double *sA, double *sB) {
     constexpr int LDS_ = 130, NPH = TN / 32, TM = 32;
-    __shared__ double sA[TM * LDS_];
-    __shared__ double sB[32 * LDS_];
-    __builtin_amdgcn_s_setprio(3);        // a step of the chain: ahead of the trailing-update waves it shares its SIMDs with
     const int tn = (g.tiles_n * 128) / TN;
-    const int ti = blockIdx.x / tn, tj = blockIdx.x % tn;
+    const int ti = vb / tn, tj = vb % tn;
     const long m0 = (long)ti * TM, n0 = (long)tj * TN;
     if (g.lower == 1 && n0 / 128 > m0 / 128) return;
     if (g.lower == 2 && n0 / 128 > (m0 / 128) * g.ls + g.lo) return;
@@ -843,6 +859,42 @@ __global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
             cbase[(4 * v) * g.ldc + ph * 32] = alpha * acc[ph][v] + (beta != 0.0 ? beta * old[ph][v] : 0.0);
 }
 
+// Chunk loop of the chain's many-workgroup kernels under look-ahead.  Beside a trailing update that fills the chip, a chain
+// kernel's workgroups only start as update workgroups retire -- about three slots a microsecond -- and one that has run its
+// 10 us hands its slot back to whoever is next, usually the update: 590 workgroups took 200 us to all get their turn
+// (tools/chain_stamps.py).  So a contended launch brings about sqrt(60 chunks) workgroups, and each keeps its slot and
+// pulls chunk numbers from a ticket counter until none are left; the next ticket is in flight during a chunk.
+template <typename Body>
+__device__ __forceinline__ void chunk_loop(int *ticket, const int nvb, int *s_vb, Body body) {
+    const int tid = threadIdx.x;
+    if (!ticket) { body((int)blockIdx.x); return; }
+    int nxt = 0;
+    if (tid == 0) nxt = atomicAdd(ticket, 1);
+    for (;;) {
+        if (tid == 0) *s_vb = nxt;
+        __syncthreads();
+        const int vb = *s_vb;
+        if (vb >= nvb) break;
+        if (tid == 0) nxt = atomicAdd(ticket, 1);
+        body(vb);
+        __syncthreads();                  // the LDS images and s_vb are free again
+    }
+    if (tid == 0 && atomicAdd(ticket + 1, 1) == (int)gridDim.x - 1) { atomicExch(ticket, 0); atomicExch(ticket + 1, 0); }
+}
+
+template <int TN>
+__global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
+    constexpr int LDS_ = 130, TM = 32;
+    __shared__ double sA[TM * LDS_];
+    __shared__ double sB[32 * LDS_];
+    __shared__ int s_vb;
+    __builtin_amdgcn_s_setprio(3);        // a step of the chain: ahead of the trailing-update waves it shares its SIMDs with
+    int *yflag = nullptr;                 // the co-resident trailing-update workgroup sleeps while this one runs (10 us instead of 53)
+    if (g.raise && threadIdx.x == 0) { yflag = cu_yield_slot(g.raise); atomicAdd(yflag, 1); }
+    chunk_loop(g.ticket, g.nvb, &s_vb, [&](const int vb) { k128_chunk<TN>(g, vb, sA, sB); });
+    if (yflag) atomicAdd(yflag, -1);
+}
+
 // The chain's panel TRSM without the inverse of the 128 x 128 diagonal block: X = A inv(L)^T by substitution over the eight
 // 16-column tiles,  X_t = (A_t - sum_{s<t} X_s L[t,s]^T) inv(L_tt)^T,  with the inverses of the 16 x 16 diagonal tiles only
 // (what the leaf computes anyway; its triangular inverse of the whole block was 19 of its 103 thousand cycles, on ONE
@@ -851,20 +903,15 @@ __global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
 // product's B operand: R^T = A_t^T - sum L[t,s] X_s^T accumulates in the MFMA D layout, X_t^T = inv(L_tt) R^T takes it as
 // it is.  L passes through LDS in four phases of 32 rows (all of it is fetched into registers up front); 67 KB of LDS.
 struct TrsmTilesArgs { double *A; long lda; const double *L; long ldl; const double *dinv;
-                       unsigned long long *stamps; int seq; };      // diagnostics (option "chain_stamps"): per-workgroup start / end times
+                       unsigned long long *stamps; int seq; int *raise; int *ticket; int nvb; };      // diagnostics (option "chain_stamps"): per-workgroup start / end times
 
-// at most 256 registers: under look-ahead a workgroup must fit beside the ONE trailing-update wave (224) a SIMD keeps when the other
-// update workgroup of its compute unit retires (with 362 the kernel waited for the whole update to drain: 5 ms at 20k rows)
-__global__ __launch_bounds__(128, 2) void trsm_tiles_kernel(TrsmTilesArgs g) {
+__device__ __forceinline__ void trsm_tiles_chunk(const TrsmTilesArgs &g, const int vb, double *sX, double *sL) {
     constexpr int LDS_ = 130;
-    __shared__ double sX[32 * LDS_];
-    __shared__ double sL[32 * LDS_];
-    __builtin_amdgcn_s_setprio(3);        // a step of the chain: ahead of the trailing-update waves it shares its SIMDs with
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     unsigned long long t_start = 0;
     if (g.stamps && tid == 0) t_start = __builtin_amdgcn_s_memrealtime();
-    double *Arows = g.A + (long)blockIdx.x * 32 * g.lda;
+    double *Arows = g.A + (long)vb * 32 * g.lda;
     // every global load of the kernel goes out at once (the phases would otherwise each wait a memory round trip):
     // the workgroup's 32 rows of A, all 128 rows of L (four phases of 32), the eight tile inverses
     // (two of the four phases of L up front, the other two as soon as a phase's registers have gone to LDS -- a phase computes
@@ -942,13 +989,27 @@ __global__ __launch_bounds__(128, 2) void trsm_tiles_kernel(TrsmTilesArgs g) {
 #pragma unroll
     for (int p = 0; p < 16; ++p)
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]), a_src, vo, (2 * p + wave_u) * arow, 0);
-    if (g.stamps && tid == 0) {           // {launch number, workgroup, start, end} in 100 MHz ticks
+    if (g.stamps && tid == 0) {           // {launch number, chunk, start, end} in 100 MHz ticks
         const unsigned long long i = atomicAdd(g.stamps, 1ull);
         if (i < (1ull << 20)) {
             unsigned long long *e = g.stamps + 8 + 4 * i;
-            e[0] = (unsigned long long)g.seq; e[1] = blockIdx.x; e[2] = t_start; e[3] = __builtin_amdgcn_s_memrealtime();
+            e[0] = (unsigned long long)g.seq; e[1] = vb; e[2] = t_start; e[3] = __builtin_amdgcn_s_memrealtime();
         }
     }
+}
+
+// at most 256 registers: under look-ahead a workgroup must fit beside the ONE trailing-update wave (224) a SIMD keeps when the other
+// update workgroup of its compute unit retires (with 362 the kernel waited for the whole update to drain: 5 ms at 20k rows)
+__global__ __launch_bounds__(128, 2) void trsm_tiles_kernel(TrsmTilesArgs g) {
+    constexpr int LDS_ = 130;
+    __shared__ double sX[32 * LDS_];
+    __shared__ double sL[32 * LDS_];
+    __shared__ int s_vb;
+    __builtin_amdgcn_s_setprio(3);        // a step of the chain: ahead of the trailing-update waves it shares its SIMDs with
+    int *yflag = nullptr;                 // the co-resident trailing-update workgroup sleeps while this one runs (10 us instead of 53)
+    if (g.raise && threadIdx.x == 0) { yflag = cu_yield_slot(g.raise); atomicAdd(yflag, 1); }
+    chunk_loop(g.ticket, g.nvb, &s_vb, [&](const int vb) { trsm_tiles_chunk(g, vb, sX, sL); });
+    if (yflag) atomicAdd(yflag, -1);
 }
 
 // LDS-free variant for the (M,K) x (N,K) layout (the trailing update): every wave loads its own MFMA operands straight
@@ -1211,6 +1272,19 @@ bool gemm_takes_small_tiles(const fvgp_handle *h, const GemmDesc &d) {
            d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && h->gemm_direct < 2;
 }
 
+// grid of a chain kernel of `nvb` chunks: all of them at once, or -- under a trailing update that fills the chip
+// (fvgp_handle::chain_contended) -- about sqrt(60 nvb) workgroups that pull chunk numbers from a ticket (chunk_loop above:
+// slots come at ~3 per microsecond, a chunk takes ~10 us; G/6 + 10 nvb/G is least at G = sqrt(60 nvb))
+static void chain_grid(fvgp_handle *h, int nvb, int **ticket, int *nvb_out, unsigned *grid) {
+    *ticket = nullptr; *nvb_out = nvb; *grid = (unsigned)nvb;
+    if (!h->chain_contended || !h->chain_loop || !h->chain_tickets || nvb < 128) return;
+    int G = (int)__builtin_sqrt((double)h->chain_loop * (double)nvb);
+    if (G < 64) G = 64;
+    if (G >= nvb) return;
+    *ticket = h->chain_tickets + 2 * (h->chain_ticket_next++ % 256);
+    *grid = (unsigned)G;
+}
+
 int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     if (d.M <= 0 || d.N <= 0) return 0;
     if (d.M % 128 || d.N % 128 || d.K % BK || d.K < 0) { fvgp_set_error("gemm: M,N must be multiples of 128 and K of 16"); return -5; }
@@ -1224,14 +1298,14 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.A = d.A; g.B = d.B; g.C = d.C; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
     g.alpha = d.alpha; g.beta = d.beta; g.K = d.K;
     g.tiles_m = (int)(d.M / 128); g.tiles_n = (int)(d.N / 128); g.lower = d.lower; g.ls = d.lower_scale; g.lo = d.lower_off;
-    g.bcr = d.bc_ranks; g.bcb = d.bc_blocks; g.bco = d.bc_off; g.rev = d.rev_m;
+    g.bcr = d.bc_ranks; g.bcb = d.bc_blocks; g.bco = d.bc_off; g.rev = d.rev_m; g.stagger = d.role == 1 ? h->update_stagger : 0;
 
     if (d.rev_m && d.lower) { fvgp_set_error("gemm: rev_m is for full (non-triangular) tile grids"); return -3; }
     if (d.bc_ranks < 1) return -7;
     if ((d.bc_ranks > 1 || d.bc_off) && d.b_nmajor) { fvgp_set_error("gemm: block-cyclic B needs the (N, K) layout"); return -7; }
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
-    g.tab = nullptr; g.queue = nullptr; g.ksplit = 0; g.csplit = 0; g.yield = h->cu_yield;
+    g.tab = nullptr; g.queue = nullptr; g.ksplit = 0; g.csplit = 0; g.yield = h->cu_yield; g.raise = (h->chain_yield && d.role != 1) ? h->cu_yield : nullptr; g.ticket = nullptr; g.nvb = 0;
     g.ny = 0; g.ab1 = g.ab2 = g.bb1 = g.bb2 = g.cb1 = g.cb2 = 0;
     const bool plain_k = d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && d.kei == 0 && d.kej == 0;
     if (h->tile_tables && plain_k && !d.rev_m && !d.probe && g.tiles_m < 32768 && g.tiles_n < 32768 &&
@@ -1271,11 +1345,14 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         const dim3 sg((unsigned)(t128 * 4));
         if (!d.b_nmajor) {
             const bool one_stage = d.K == 128 && h->k128_kernels;
-            if ((const double *)d.C == d.A || (const double *)d.C == d.B) {       // in place: a workgroup owns whole rows
-                if (one_stage) hipLaunchKernelGGL((gemm_f64_k128_kernel<128>), sg, block, 0, h->stream, g);
+            const bool in_place = (const double *)d.C == d.A || (const double *)d.C == d.B;
+            dim3 kg(in_place ? sg.x : (unsigned)(t128 * 8));
+            if (one_stage) chain_grid(h, (int)kg.x, &g.ticket, &g.nvb, &kg.x);
+            if (in_place) {                                                        // in place: a workgroup owns whole rows
+                if (one_stage) hipLaunchKernelGGL((gemm_f64_k128_kernel<128>), kg, block, 0, h->stream, g);
                 else hipLaunchKernelGGL((gemm_f64_small_kernel<32, 128, 0>), sg, block, 0, h->stream, g);
             } else {
-                if (one_stage) hipLaunchKernelGGL((gemm_f64_k128_kernel<64>), dim3((unsigned)(t128 * 8)), block, 0, h->stream, g);
+                if (one_stage) hipLaunchKernelGGL((gemm_f64_k128_kernel<64>), kg, block, 0, h->stream, g);
                 else hipLaunchKernelGGL((gemm_f64_small_kernel<64, 64, 0>), sg, block, 0, h->stream, g);
             }
         } else {
@@ -1323,8 +1400,10 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
 int launch_trsm_tiles(fvgp_handle *h, double *A, int64_t lda, int64_t rows, const double *L, int64_t ldl, const double *dinv) {
     if (rows <= 0) return 0;
     if (rows % 32 || (lda & 1) || (ldl & 1) || ((uintptr_t)A & 15) || ((uintptr_t)L & 15)) { fvgp_set_error("trsm_tiles: rows % 32, even leading dimensions, 16-byte alignment"); return -2; }
-    TrsmTilesArgs g{A, (long)lda, L, (long)ldl, dinv, h->chain_stamps, h->chain_seq++};
-    hipLaunchKernelGGL(trsm_tiles_kernel, dim3((unsigned)(rows / 32)), dim3(128), 0, h->stream, g);
+    TrsmTilesArgs g{A, (long)lda, L, (long)ldl, dinv, h->chain_stamps, h->chain_seq++, h->chain_yield ? h->cu_yield : nullptr, nullptr, 0};
+    unsigned grid = 0;
+    chain_grid(h, (int)(rows / 32), &g.ticket, &g.nvb, &grid);
+    hipLaunchKernelGGL(trsm_tiles_kernel, dim3(grid), dim3(128), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -190,10 +190,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
     // this compute unit is the leaf's while it runs: the co-resident trailing-update workgroup sleeps (gemm.hip, YIELD)
     int *yflag = nullptr;
     if (g.yield && tid == 0) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 8, 8)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-        yflag = g.yield + ((xcc << 8 | hw) * CU_YIELD_STRIDE);
+        yflag = cu_yield_slot(g.yield);
         atomicAdd(yflag, 1);
     }
 #define FVGP_STAMP() do { if (g.stamps && tid == 0) g.stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
