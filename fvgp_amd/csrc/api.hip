@@ -150,6 +150,8 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "update_reserve")) { h->update_reserve = (int)value; return 0; }
     if (!strcmp(key, "leaf_yield")) { h->leaf_yield = (int)value; return 0; }
     if (!strcmp(key, "chain_yield")) { h->chain_yield = (int)value; return 0; }
+    if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
+    if (!strcmp(key, "update_atomic_k")) { h->update_atomic_k = value; return 0; }
     if (!strcmp(key, "chain_loop")) { if (value < 0) return -3; h->chain_loop = (int)value; return 0; }
     if (!strcmp(key, "update_stagger")) { if (value != 0 && value != 2 && value != 4 && value != 8) return -3; h->update_stagger = (int)value; return 0; }
     if (!strcmp(key, "panel_square")) { h->panel_square = (int)value; return 0; }
@@ -692,17 +694,26 @@ static int trsm_fwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl
 // with K split over enough workgroups to fill the chip (deterministic two-pass reduction).  A right-looking sweep has
 // (rows/128) x (remaining blocks) tiles of K = NB per step instead: 1192, 1128, .. tiles on 512 slots lose a quarter of
 // the time to partly filled rounds (measured at N = 20k, P = 1000: 7.3 ms for 3.9e11 flops); here every launch is one round.
-static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt) {
+// `slots`: the workgroups one launch should bring (512 = the whole chip; 256 when two halves of the rows run side by side on two
+// streams, trsm_fwd_gemm_t below); scratch: trsm_fwd_scratch(rows, slots) doubles.
+static int64_t trsm_fwd_scratch(int64_t rows, int64_t slots) {
+    const int64_t NB = 1024, tiles = (rows / TILE) * (NB / TILE);
+    const int64_t want = tiles >= slots ? 1 : slots / tiles;
+    return rows * NB + want * rows * NB;
+}
+
+// one outer block [J0, J0 + 1024) of the sweep for `rows` rows of BT
+static int trsm_fwd_gemm_t_block(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt,
+                                 int64_t slots, double *scratch, int64_t J0) {
     const int64_t np = pad128(n), NB = 1024;
     const bool winv = h->block_inverses != 0;
-    int rc = winv ? ensure_winv(h, L, n, ldl) : ensure_linv(h, L, n, ldl); if (rc) return rc;
+    int rc = 0;
     // scratch: tmp (rows x NB: block J with everything to its left applied) and the split-K partials behind it
     const int64_t tiles = (rows / TILE) * (NB / TILE);
-    const int64_t want = tiles >= 512 ? 1 : 512 / tiles;                  // workgroups per output tile that fill the chip
-    const int64_t tmp_d = rows * NB, ws_d = want * rows * NB;
-    rc = ensure_scratch(h, (tmp_d + ws_d + 7) / 8); if (rc) return rc;
-    double *tmp = h->vec, *ws = h->vec + tmp_d;
-    for (int64_t J0 = 0; J0 < np; J0 += NB) {
+    const int64_t want = tiles >= slots ? 1 : slots / tiles;              // workgroups per output tile that fill the launch's share of the chip
+    const int64_t tmp_d = rows * NB;
+    double *tmp = scratch, *ws = scratch + tmp_d;
+    {
         const int64_t Jend = (J0 + NB < np) ? J0 + NB : np, w = Jend - J0;
         bool in_tmp = false;
         if (J0 > 0) {
@@ -726,8 +737,7 @@ static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t l
             int64_t split = want;
             if (split > w / TILE) split = w / TILE;
             if (split > 1) { d.split = (int)split; d.split_ws = ws; }
-            rc = launch_gemm(h, d); if (rc) return rc;
-            continue;
+            return launch_gemm(h, d);
         }
         for (int64_t k0 = J0; k0 < Jend; k0 += TILE) {
             GemmDesc d{};   // X_k^T = B_k^T inv(L_kk)^T, in place (a workgroup owns whole rows)
@@ -742,6 +752,39 @@ static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t l
             rc = launch_gemm(h, u); if (rc) return rc;
         }
     }
+    return 0;
+}
+
+// With 512 or more rows (posterior covariance at P >= 512 points) the rows are cut in two halves that run the same sweep side
+// by side on the two streams of the handle, each with launches of 256 workgroups: a step of the sweep is three dependent
+// launches with two reductions between them (~66 us of fixed cost per 1024-block, 20 blocks at N = 20k), and the other half's
+// product fills the chip while they run.
+static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt) {
+    const bool winv = h->block_inverses != 0;
+    int rc = winv ? ensure_winv(h, L, n, ldl) : ensure_linv(h, L, n, ldl); if (rc) return rc;
+    const bool halves = h->posterior_halves && winv && rows >= 512 && rows <= 1024 && rows % 256 == 0;    // (2048 rows: +3 %)
+    const int64_t np = pad128(n);
+    if (!halves) {
+        rc = ensure_scratch(h, (trsm_fwd_scratch(rows, 512) + 7) / 8); if (rc) return rc;
+        for (int64_t J0 = 0; J0 < np && !rc; J0 += 1024) rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT, rows, ldbt, 512, h->vec, J0);
+        return rc;
+    }
+    const int64_t r2 = rows / 2, sc = trsm_fwd_scratch(r2, 256);
+    rc = ensure_scratch(h, (2 * sc + 7) / 8); if (rc) return rc;
+    rc = fvgp_ensure_side(h); if (rc) return rc;
+    hipStream_t mainS = h->stream, sideS = h->side;
+    HIPCHK(hipEventRecord(h->ev_cols, mainS));
+    HIPCHK(hipStreamWaitEvent(sideS, h->ev_cols, 0));
+    for (int64_t J0 = 0; J0 < np && !rc; J0 += 1024) {          // the two halves are enqueued block by block (a launch costs the host ~17 us)
+        rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT, r2, ldbt, 256, h->vec, J0);
+        if (rc) break;
+        h->stream = sideS;
+        rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT + r2 * ldbt, r2, ldbt, 256, h->vec + sc, J0);
+        h->stream = mainS;
+    }
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->ev_panel, sideS));
+    HIPCHK(hipStreamWaitEvent(mainS, h->ev_panel, 0));
     return 0;
 }
 

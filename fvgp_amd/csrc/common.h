@@ -94,6 +94,8 @@ struct fvgp_handle {
     // `chain_loop` = the 60 of G = sqrt(60 chunks) (0: off), `chain_contended` set by the drivers around a chain that runs under a
     // trailing update
     int *chain_tickets = nullptr; unsigned chain_ticket_next = 0; int chain_loop = 0; bool chain_contended = false;   // measured: N=12k +2 %, N=20k +0.8 %, N=50k +-0 with 60 -- off
+    int posterior_halves = 1;         // posterior covariance at >= 512 points: two halves of the points side by side on two streams (api.hip)
+    int64_t update_atomic_k = 0;      // trailing updates with K <= this add their tiles with atomics instead of the C read-modify-write
     int update_stagger = 0;           // phases (0, 2, 4, 8) the first wave of a trailing update's workgroups starts in (gemm.hip)
     // square-first panels (potrf_driver, panel_factor_square): the inverse of the panel's square + T scratch, and the compact copy of
     // the rows below it

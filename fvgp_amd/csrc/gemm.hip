@@ -54,6 +54,7 @@ struct GemmArgs {
     int ls, lo;
     int bcr, bcb, bco;                // B rows in all-gather (block-cyclic) order, see GemmDesc
     int rev;                          // tile rows enumerated last to first
+    int atom;                         // trailing update: add the tile with fire-and-forget atomics (beta == 1), see update_atomic_k
     int stagger;                      // trailing update: phases the first wave of workgroups starts in (0 / 1: all at once), see the kernel
     long K;
     long kb0, kbi, kbj, ke0, kei, kej;
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // the persistent form adds its tile with fire-and-forget atomics (beta == 1 there): no registers for the old values, so the
     // addressing it keeps alive across tiles fits beside the accumulators
     constexpr bool ATOM = PERSIST || (DBG & 4096) || (DBG == 0 && FVGP_GEMM_ATOMIC_DEFAULT);
-    if (ATOM && (PERSIST || g.beta == 1.0)) atomic_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha);
+    if ((ATOM || (ROLE == 1 && DBG == 0 && g.atom)) && (PERSIST || g.beta == 1.0)) atomic_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha);
     else store_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
     if constexpr (!PERSIST) return;
   }
@@ -1298,7 +1299,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.A = d.A; g.B = d.B; g.C = d.C; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
     g.alpha = d.alpha; g.beta = d.beta; g.K = d.K;
     g.tiles_m = (int)(d.M / 128); g.tiles_n = (int)(d.N / 128); g.lower = d.lower; g.ls = d.lower_scale; g.lo = d.lower_off;
-    g.bcr = d.bc_ranks; g.bcb = d.bc_blocks; g.bco = d.bc_off; g.rev = d.rev_m; g.stagger = d.role == 1 ? h->update_stagger : 0;
+    g.bcr = d.bc_ranks; g.bcb = d.bc_blocks; g.bco = d.bc_off; g.rev = d.rev_m; g.stagger = d.role == 1 ? h->update_stagger : 0; g.atom = (d.role == 1 && d.K <= h->update_atomic_k) ? 1 : 0;
 
     if (d.rev_m && d.lower) { fvgp_set_error("gemm: rev_m is for full (non-triangular) tile grids"); return -3; }
     if (d.bc_ranks < 1) return -7;

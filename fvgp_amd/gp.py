@@ -680,7 +680,7 @@ class GP(ValidationMixin):
             S = H.empty(Pp, Pp) if want_cov else None
             H.posterior(self._native.kernel_id, self._x_dev, hps, L, alpha, ncol, xp, kx, mean, None, S)
             H.sync()
-            return mean.cpu().numpy(), (None if S is None else S[:P, :P].cpu().numpy())
+            return mean.cpu().numpy(), (None if S is None else H.to_host(S[:P, :P]))
         # slow path: host cross-covariances, device solves
         kx.zero_()
         kx[:n, :P] = H.to_device(self._host_kernel(self.x_data, x_pred, hps))
