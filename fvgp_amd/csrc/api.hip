@@ -1330,7 +1330,8 @@ int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, cons
     g.M = M; g.N = N; g.K = K; g.alpha = -1.0; g.beta = 1.0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     if (h->reserve_rows < 0 || M * scale <= h->reserve_rows) g.reserve_cus = h->update_reserve;
-    if (!h->profile || gemm_takes_small_tiles(h, g)) return launch_gemm(h, g);      // only launches of the kernel the roofline names are timed
+    // only launches of the kernel the roofline names are timed, and no more than 8192 of them between two get_profile calls
+    if (!h->profile || gemm_takes_small_tiles(h, g) || h->rs_used >= 2 * 8192) return launch_gemm(h, g);
     // timed with events on the launch stream; algorithmic flops = the tiles with tj <= ti * scale + off
     while (h->rs_ev.size() < h->rs_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->rs_ev.push_back(e); }
     double tiles = 0.0;

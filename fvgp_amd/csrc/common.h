@@ -36,7 +36,7 @@ struct TileTabKey {
         return lo < o.lo;
     }
 };
-struct TileTab { int *dev; long grid; };
+struct TileTab { int *dev; long grid; int *host; };      // host: pinned staging copy (the upload reads it from a copy stream)
 
 struct fvgp_handle {
     int device = 0;
@@ -116,6 +116,8 @@ struct fvgp_handle {
     double prof_kmat_ms = 0, prof_kmat_bytes = 0, prof_tail_ms = 0;   // fused evaluation: assembly, everything after the factorisation
     hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};
     // row-sharded trailing updates timed since the last get_profile (option "profile")
+    hipStream_t copy_stream = nullptr;   // uploads of tile tables: the host waits for this stream only, never for the compute streams
+    size_t tile_tab_bytes = 0;           // device bytes held by tile_tabs (capped, gemm.hip)
     std::vector<hipEvent_t> rs_ev;
     std::vector<double> rs_flops;
     size_t rs_used = 0;

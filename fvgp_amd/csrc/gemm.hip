@@ -19,6 +19,7 @@
 //     super-tiles to the same XCD (blocks b, b+8, .. share an L2), so the row/column slabs
 //     of L21 a super-tile needs are fetched into that XCD's L2 once.
 #include "common.h"
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -1209,10 +1210,16 @@ long gemm_debug_tile_map(int tiles_m, int tiles_n, int lower, int ls, int lo, in
 // <= 100, +6-25 % on the row-sharded (lower == 2) grids of an 8-rank run.  The table keeps the same super-tile walk (the 64
 // tiles of a super-tile run together on one L2) but cuts the sequence of REAL tiles into eight equal contiguous runs, one per
 // XCD (block b -> XCD b % 8, entry b / 8 of its run).  Built on the host once per launch shape, kept on the device.
-void gemm_release_tables(fvgp_handle *h) {
-    for (auto &kv : h->tile_tabs) (void)hipFree(kv.second.dev);
+static void drop_tile_tables(fvgp_handle *h) {
+    for (auto &kv : h->tile_tabs) { (void)hipFree(kv.second.dev); if (kv.second.host) (void)hipHostFree(kv.second.host); }
     h->tile_tabs.clear();
+    h->tile_tab_bytes = 0;
+}
+
+void gemm_release_tables(fvgp_handle *h) {
+    drop_tile_tables(h);
     if (h->tile_queue) { (void)hipFree(h->tile_queue); h->tile_queue = nullptr; }
+    if (h->copy_stream) { (void)hipStreamDestroy(h->copy_stream); h->copy_stream = nullptr; }
 }
 
 static std::vector<int> build_tile_table(int tm, int tn, int lower, int ls, int lo) {
@@ -1251,10 +1258,24 @@ static int tile_table(fvgp_handle *h, int tm, int tn, int lower, int ls, int lo,
     auto it = h->tile_tabs.find(key);
     if (it == h->tile_tabs.end()) {
         const std::vector<int> tab = build_tile_table(tm, tn, lower, ls, lo);
-        TileTab tt{nullptr, (long)tab.size()};
+        TileTab tt{nullptr, (long)tab.size(), nullptr};
+        const size_t bytes = (size_t)tt.grid * sizeof(int);
+        // a process that keeps growing its problem (active learning: np + 128 per step) meets new launch shapes for ever: the
+        // cache is dropped as a whole beyond 256 MB (every queued launch has finished with its table after the device sync)
+        if (h->tile_tab_bytes + bytes > ((size_t)256 << 20)) {
+            HIPCHK(hipDeviceSynchronize());
+            drop_tile_tables(h);
+        }
         if (tt.grid > 0) {
-            HIPCHK(hipMalloc((void **)&tt.dev, (size_t)tt.grid * sizeof(int)));
-            HIPCHK(hipMemcpy(tt.dev, tab.data(), (size_t)tt.grid * sizeof(int), hipMemcpyHostToDevice));
+            // uploaded from pinned memory on a stream of its own, and the host waits for THAT stream: no null-stream copy that
+            // would join the compute streams (look-ahead, the enqueue-only entry points)
+            if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+            HIPCHK(hipMalloc((void **)&tt.dev, bytes));
+            HIPCHK(hipHostMalloc((void **)&tt.host, bytes, hipHostMallocDefault));
+            memcpy(tt.host, tab.data(), bytes);
+            HIPCHK(hipMemcpyAsync(tt.dev, tt.host, bytes, hipMemcpyHostToDevice, h->copy_stream));
+            HIPCHK(hipStreamSynchronize(h->copy_stream));
+            h->tile_tab_bytes += bytes;
         }
         it = h->tile_tabs.emplace(key, tt).first;
     }
@@ -1268,6 +1289,10 @@ bool gemm_takes_small_tiles(const fvgp_handle *h, const GemmDesc &d) {
     const long t128 = (long)(d.M / 128) * (d.N / 128);
     const bool few = d.role == 1 ? (t128 <= h->small_tile_max_update) : (t128 <= h->small_tile_max && d.K <= 512);
     if (d.b_nmajor && ((const double *)d.C == d.A || ((const double *)d.C == d.B && d.M != 128))) return false;
+    // (N,K) layout in place: a small-tile workgroup owns 32 whole rows of C.  C == B would overwrite rows of B that other
+    // workgroups still read as their operand, and C == A is only safe when those rows are ALL of the tile's columns (N == 128)
+    if (!d.b_nmajor && (const double *)d.C == d.B) return false;
+    if (!d.b_nmajor && (const double *)d.C == d.A && d.N != 128) return false;
     if (d.b_nmajor && (d.lower == 2 || d.bc_ranks != 1 || d.bc_off != 0)) return false;
     return !d.probe && !d.a_kmajor && !d.rev_m && few &&
            d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && h->gemm_direct < 2;

@@ -73,6 +73,23 @@ def test_gemm_layouts(H, akm, bnm, lower):
 
 
 @pytest.mark.parametrize("one_stage", [1, 0])
+def test_gemm_in_place_over_the_nk_operand(H, one_stage):
+    """(M,K) x (N,K) with C == B, M = N = K = 128 (a public-ABI call nobody inside makes): a small-tile workgroup owns 32 rows
+    of C, which are rows of B the other workgroups still read, so this aliasing must stay on the one-workgroup 128-tile."""
+    rng = np.random.default_rng(77)
+    a = rng.standard_normal((128, 128)); b = rng.standard_normal((128, 128))
+    H.set_option("k128_kernels", one_stage)
+    try:
+        A = H.to_device(a); B = H.to_device(b)
+        H.gemm(0, 0, 0, 128, 128, 128, 1.0, A, B, 0.0, B)
+        H.sync()
+    finally:
+        H.set_option("k128_kernels", 1)
+    ref = a @ b.T
+    assert np.max(np.abs(B.cpu().numpy() - ref) / (np.abs(a) @ np.abs(b.T))) < 8 * EPS
+
+
+@pytest.mark.parametrize("one_stage", [1, 0])
 @pytest.mark.parametrize("lower", [0, 1])
 def test_gemm_k128_chain_products(H, lower, one_stage):
     """The two K = 128 products of a panel-chain step on the small-tile kernels (one-stage fetch or eight double-buffered
