@@ -78,6 +78,8 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     if (h->red) (void)hipFree(h->red);
     if (h->dinfo) (void)hipFree(h->dinfo);
     if (h->cu_yield) (void)hipFree(h->cu_yield);
+    if (h->sweep_gran) (void)hipFree(h->sweep_gran);
+    if (h->sweep_ticket) (void)hipFree(h->sweep_ticket);
     if (h->chain_tickets) (void)hipFree(h->chain_tickets);
     if (h->panel_w) (void)hipFree(h->panel_w);
     if (h->panel_ws) (void)hipFree(h->panel_ws);
@@ -150,6 +152,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "update_reserve")) { h->update_reserve = (int)value; return 0; }
     if (!strcmp(key, "leaf_yield")) { h->leaf_yield = (int)value; return 0; }
     if (!strcmp(key, "chain_yield")) { h->chain_yield = (int)value; return 0; }
+    if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
     if (!strcmp(key, "update_atomic_k")) { h->update_atomic_k = value; return 0; }
     if (!strcmp(key, "chain_loop")) { if (value < 0) return -3; h->chain_loop = (int)value; return 0; }
@@ -643,6 +646,7 @@ static int potrs_vec(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, do
         // forward result lives in Y (np x C); copy back to B
         return launch_copy_cols(h, Y, C, B, ldb, np, c, np, c);
     }
+    if (h->bwd_sweep && c == 1) return launch_bwd_sweep(h, L, ldl, np, h->linv, Y, B, ldb, c);        // one launch for the whole sweep
     for (int64_t k0 = np - TILE; k0 >= 0; k0 -= TILE) {
         rc = launch_bwd_step(h, L, ldl, np, k0, h->linv + (k0 / TILE) * LEAF_DOUBLES, Y, B, ldb, c);
         if (rc) return rc;
@@ -1123,6 +1127,8 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
         if (rc) return rc;
         if (alpha) {
             rc = launch_copy_cols(h, alpha, ncol, alpha, ncol, 0, 0, np, ncol); if (rc) return rc;
+            if (h->bwd_sweep && ncol == 1) { rc = launch_bwd_sweep(h, KV, ld, np, h->linv, h->vec, alpha, ncol, ncol); if (rc) return rc; }
+            else
             for (int64_t k0 = np - TILE; k0 >= 0; k0 -= TILE) {
                 rc = launch_bwd_step(h, KV, ld, np, k0, h->linv + (k0 / TILE) * LEAF_DOUBLES, h->vec, alpha, ncol, ncol);
                 if (rc) return rc;

@@ -12,6 +12,13 @@ constexpr int LEAF_DOUBLES = TILE * TILE;
 constexpr int CU_YIELD_STRIDE = 32;    // ints between two compute units' yield counters (one 128-byte line each)
 constexpr int CU_YIELD_KEYS = 8 * 256;   // XCC id (3 bits) << 8 | HW_ID[15:8] (CU, SH, SE)
 #if defined(__HIPCC__)
+// a wave-uniform pointer moved into SGPRs (readfirstlane returns int: widen each half as UNSIGNED)
+__device__ __forceinline__ const double *uniform_ptr(const double *p) {
+    const uintptr_t v = (uintptr_t)p;
+    const uintptr_t lo = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffu));
+    const uintptr_t hi = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<const double *>(lo | (hi << 32));
+}
 // this compute unit's yield counter (fvgp_handle::cu_yield): raised by the latency-bound kernels of the panel chain while one
 // of their workgroups runs here, polled by the trailing update's waves (gemm.hip, YIELD)
 __device__ __forceinline__ int *cu_yield_slot(int *base) {
@@ -94,6 +101,9 @@ struct fvgp_handle {
     // `chain_loop` = the 60 of G = sqrt(60 chunks) (0: off), `chain_contended` set by the drivers around a chain that runs under a
     // trailing update
     int *chain_tickets = nullptr; unsigned chain_ticket_next = 0; int chain_loop = 0; bool chain_contended = false;   // measured: N=12k +2 %, N=20k +0.8 %, N=50k +-0 with 60 -- off
+    // backward sweep in one launch (solve.hip, bwd_sweep_kernel): granules of {value, tag}, the launch counter the tags come from,
+    // the column ticket; option "bwd_sweep"
+    double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1;
     int posterior_halves = 1;         // posterior covariance at >= 512 points: two halves of the points side by side on two streams (api.hip)
     int64_t update_atomic_k = 0;      // trailing updates with K <= this add their tiles with atomics instead of the C read-modify-write
     int update_stagger = 0;           // phases (0, 2, 4, 8) the first wave of a trailing update's workgroups starts in (gemm.hip)
@@ -212,6 +222,7 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
 
 int launch_fwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,
                     double *B, int64_t ldb, double *Y, int c);
+int launch_bwd_sweep(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, const double *linv, const double *Yres, double *X, int64_t ldx, int c);
 int launch_bwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,
                     double *Yres, double *X, int64_t ldx, int c);
 int launch_diag_logsum(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *out_dev);

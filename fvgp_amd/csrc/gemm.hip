@@ -139,13 +139,6 @@ __host__ __device__ inline long xcd_remap(long b, long nwg, int tiles_n) {
     return full * per + (k >= 0 ? k : 0);
 }
 
-// a wave-uniform pointer moved into SGPRs (readfirstlane returns int: widen each half as UNSIGNED)
-__device__ __forceinline__ const double *uniform_ptr(const double *p) {
-    const uintptr_t v = (uintptr_t)p;
-    const uintptr_t lo = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffu));
-    const uintptr_t hi = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return reinterpret_cast<const double *>(lo | (hi << 32));
-}
 
 // epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile.  The read-modify-write of C
 // is done in two batches of 32 loads per lane, all issued before the first use, so a tile pays two

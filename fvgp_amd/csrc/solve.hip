@@ -166,6 +166,131 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const double *L, long ldl
     }
 }
 
+// The whole backward sweep in ONE launch (one right-hand side).  The per-block launches above are a chain of N/128 dependent
+// kernels of 7-11 us each (x_k by everybody, one read of the row panel, one boundary); here workgroup c owns the 128 columns of
+// block c for the whole sweep: it keeps y_c in LDS, walks down the column of L below its block -- the next 128 x 128 block is in
+// flight before the x it meets has arrived -- and, once the block right under the diagonal is in, multiplies by the inverse of
+// its diagonal block (fetched like one more block of the column) and PUBLISHES x_c to the workgroups left of it.  The hand-off
+// is the one form that needs neither fence nor flag (MI355X_MICROARCH.md, inter-workgroup visibility, "granule"): every
+// published double travels as ONE naturally aligned 16-byte {value, tag} written by one sc1 (write-through) store and polled by
+// sc1 loads until its tag is this launch's -- a stale line shows an old tag and is read again, so nothing depends on when
+// another compute unit's caches notice the store.  The tag is a per-handle launch counter, never reused.  Columns are handed out
+// by a ticket in the order the workgroups start (c = nb - 1 - ticket), so a workgroup only ever waits for workgroups that started
+// before it: no assumption on the dispatch order, no need for the whole grid to be resident.  Every sum is formed in the order
+// the step kernels use (four row quarters of a block, ((0+1)+(2+3)); two halves of the inverse), so the results are
+// bit-identical to theirs -- which is how the tests would see a stale read.  Spins are bounded (seconds): a workgroup that gives
+// up publishes NaN.
+struct BwdSweepArgs {
+    const double *L; long ldl; long np;
+    const double *linv;           // 128 x 128 inverses of the diagonal blocks, block b at linv + b * 128 * 128 (row-major, zeros above)
+    const double *Y;              // np residuals y = L^-1 b
+    double *X; long ldx;
+    double *gran;                 // np granules of {value, tag} (16 bytes each)
+    unsigned long long tag;
+    int *ticket;                  // {next column ticket, finished workgroups}; the last workgroup zeroes both
+};
+
+__global__ __launch_bounds__(256) void bwd_sweep_kernel(BwdSweepArgs g) {      // 1 workgroup per CU: the next block is in flight beside the current one
+    __shared__ double sy[128];
+    __shared__ double sx[128];
+    __shared__ double sxv[2][128];
+    __shared__ double sp[4][128];
+    __shared__ int s_c, s_fail;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = (int)(g.np / 128);
+    if (tid == 0) { s_c = nb - 1 - atomicAdd(g.ticket, 1); s_fail = 0; }
+    __syncthreads();
+    const int c = s_c;
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(g.gran, 0, 0xffffffff, 0x00020000);
+    // (a buffer descriptor per block, the lane's 16 bytes as the only vector offset, the row as a scalar offset: 32 64-bit
+    // addresses would cost as many registers as the data)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int rowb = (int)(g.ldl * 8);
+    u32x4 l2[32];
+    auto load_block = [&](const int I) {
+        const double *base = uniform_ptr(g.L + ((long)I * 128 + wave_u * 32) * g.ldl + (long)c * 128);
+        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) l2[u] = __builtin_amdgcn_raw_buffer_load_b128(src, 16 * lane, u * rowb, 0);
+    };
+    // the inverse of the diagonal block is the last "block" of the column: thread (i, half) takes half of column i of inv(L_cc)
+    // (coalesced across i) into the same registers, while the x right under the diagonal is still on its way
+    auto load_inv = [&]() {
+        const double *inv = g.linv + (long)c * 128 * 128 + (tid >> 7) * 64 * 128 + (tid & 127);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const double2_t v = {inv[(2 * u) * 128], inv[(2 * u + 1) * 128]};
+            __builtin_memcpy(&l2[u], &v, 16);
+        }
+    };
+    if (c < nb - 1) load_block(nb - 1); else load_inv();
+    if (tid < 128) sy[tid] = g.Y[(long)c * 128 + tid];
+    __syncthreads();
+    for (int I = nb - 1; I > c; --I) {
+        // ---- x_I: a thread per granule ------------------------------------------------------------------------------------
+        if (tid < 128) {
+            const int off = (int)(((long)I * 128 + tid) * 16);
+            u32x4 v;
+            int spins = 0;
+            for (;;) {
+                v = __builtin_amdgcn_raw_buffer_load_b128(gsrc, off, 0, 16);          // sc1: served past this CU's L1
+                const unsigned long long t = (unsigned long long)v[2] | ((unsigned long long)v[3] << 32);
+                if (t == g.tag) break;
+                if (++spins > (1 << 22)) { s_fail = 1; break; }
+                // only the workgroup right behind the frontier is waited for: the further left, the rarer the polls (every
+                // poll is a trip past the L1 that the producer's store and the critical poll share the fabric with)
+                __builtin_amdgcn_s_sleep(2);
+                for (int k = I - 1 - c < 24 ? I - 1 - c : 24; k > 0; --k) __builtin_amdgcn_s_sleep(6);
+                asm volatile("" ::: "memory");
+            }
+            const unsigned long long bits = (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
+            double xv;
+            __builtin_memcpy(&xv, &bits, 8);
+            sx[tid] = xv;
+        }
+        __syncthreads();
+        // ---- y_c -= L[I, c]^T x_I: this wave's 32 rows of the block, two adjacent columns per lane ----------------------
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const double xv = sx[wave * 32 + u];
+            double2_t lv;
+            __builtin_memcpy(&lv, &l2[u], 16);
+            a0 = fma(lv[0], xv, a0);
+            a1 = fma(lv[1], xv, a1);
+        }
+        if (I - 1 > c) load_block(I - 1); else load_inv();      // the next block of the column is on its way while the partial sums are combined
+        sp[wave][2 * lane] = a0; sp[wave][2 * lane + 1] = a1;
+        __syncthreads();
+        if (tid < 128) sy[tid] -= (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
+        __syncthreads();
+    }
+    // ---- x_c = inv(L_cc)^T y_c : thread (i, half) walks half of column i of the inverse ---------------------------------------
+    {
+        const int i = tid & 127, half = tid >> 7;
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            double2_t lv;
+            __builtin_memcpy(&lv, &l2[u], 16);
+            acc = fma(lv[0], sy[half * 64 + 2 * u], acc);
+            acc = fma(lv[1], sy[half * 64 + 2 * u + 1], acc);
+        }
+        sxv[half][i] = acc;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const double xv = s_fail ? __builtin_nan("") : sxv[0][tid] + sxv[1][tid];
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &xv, 8);
+        const u32x4 v = {(unsigned)bits, (unsigned)(bits >> 32), (unsigned)g.tag, (unsigned)(g.tag >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, gsrc, (int)(((long)c * 128 + tid) * 16), 0, 16);      // one sc1 store per granule
+        g.X[((long)c * 128 + tid) * g.ldx] = xv;
+    }
+    if (tid == 0 && atomicAdd(g.ticket + 1, 1) == (int)gridDim.x - 1) { atomicExch(g.ticket, 0); atomicExch(g.ticket + 1, 0); }
+}
+
 __global__ void diag_logsum_kernel(const double *L, long n, long ldl, double *out) {
     __shared__ double sw[16];
     double s = 0.0;
@@ -582,6 +707,27 @@ int launch_bwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, in
     else if (c <= 2) bwd_go<2>(h, L, ldl, np, k0, linv_k, Yres, X, ldx, c);
     else if (c <= 4) bwd_go<4>(h, L, ldl, np, k0, linv_k, Yres, X, ldx, c);
     else bwd_go<8>(h, L, ldl, np, k0, linv_k, Yres, X, ldx, c);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// the whole backward sweep in one launch (bwd_sweep_kernel, one right-hand side); Yres is only read
+int launch_bwd_sweep(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, const double *linv, const double *Yres, double *X, int64_t ldx, int c) {
+    if (c != 1) { fvgp_set_error("bwd_sweep: one right-hand side"); return -9; }
+    const size_t need = (size_t)np * 2;                              // doubles: 16 bytes per granule
+    if (need > h->sweep_gran_cap) {
+        if (h->sweep_gran) HIPCHK(hipFree(h->sweep_gran));
+        h->sweep_gran = nullptr; h->sweep_gran_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->sweep_gran, need * sizeof(double)));
+        HIPCHK(hipMemset(h->sweep_gran, 0, need * sizeof(double)));
+        h->sweep_gran_cap = need;
+    }
+    if (!h->sweep_ticket) {
+        HIPCHK(hipMalloc((void **)&h->sweep_ticket, 2 * sizeof(int)));
+        HIPCHK(hipMemset(h->sweep_ticket, 0, 2 * sizeof(int)));
+    }
+    BwdSweepArgs g{L, (long)ldl, (long)np, linv, Yres, X, (long)ldx, h->sweep_gran, ++h->sweep_tag, h->sweep_ticket};
+    hipLaunchKernelGGL(bwd_sweep_kernel, dim3((unsigned)(np / 128)), dim3(256), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -72,6 +72,45 @@ def test_gemm_layouts(H, akm, bnm, lower):
         assert np.max(np.abs(got - ref) / scale) < 8 * EPS
 
 
+@pytest.mark.parametrize("n", [300, 3333, 8200, 36000])
+def test_backward_sweep_in_one_launch_matches_the_step_kernels(H, n):
+    """fvgp_hip_potrs with one right-hand side: the single-launch backward sweep (workgroups hand x_k to each other through
+    tagged 16-byte granules) must give the bits of the per-block launches -- every sum is formed in the same order, so a stale
+    or torn hand-off would show.  36000 rows = 282 workgroups, more than the 256 that are resident at once."""
+    from fvgp_amd._lib import pad128
+    import torch
+    rng = np.random.default_rng(n)
+    npad = pad128(n)
+    A = H.empty(npad, npad)
+    A.zero_()
+    # a well-conditioned lower factor without a factorisation: unit-ish diagonal, small entries below
+    g = torch.Generator(device=A.device); g.manual_seed(n)
+    blk = 4096
+    for r0 in range(0, npad, blk):
+        r1 = min(npad, r0 + blk)
+        A[r0:r1, :r1] = 0.02 * torch.randn(r1 - r0, r1, dtype=torch.float64, device=A.device, generator=g) / np.sqrt(npad)
+    A.diagonal().copy_(1.0 + torch.rand(npad, dtype=torch.float64, device=A.device, generator=g))
+    A[n:, :] = 0.0
+    A.diagonal()[n:] = 1.0
+    H.invalidate_factor()
+    rhs = rng.standard_normal((n, 1))
+    out = {}
+    for mode in (0, 1, 1):
+        H.set_option("bwd_sweep", mode)
+        B = _padded(H, rhs, cols_pad=1, fill=3.0)
+        H.potrs(A, n, B, 1)
+        H.sync()
+        got = B.cpu().numpy()[:n, 0]
+        assert np.all(np.isfinite(got))
+        out.setdefault(mode, []).append(got)
+    H.set_option("bwd_sweep", 1)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[1][0], out[1][1])
+    if n <= 8200:
+        L = np.tril(A.cpu().numpy()[:n, :n])
+        ref = sla.solve_triangular(L.T, sla.solve_triangular(L, rhs[:, 0], lower=True), lower=False)
+        assert np.max(np.abs(out[1][0] - ref)) / np.max(np.abs(ref)) < 1e-11
+
+
 @pytest.mark.parametrize("one_stage", [1, 0])
 def test_gemm_in_place_over_the_nk_operand(H, one_stage):
     """(M,K) x (N,K) with C == B, M = N = K = 128 (a public-ABI call nobody inside makes): a small-tile workgroup owns 32 rows

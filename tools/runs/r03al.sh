@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03ax; mkdir -p $O
+O=gpurun_out/r03bm; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/tr20k -o trace -- python3 $GRAFT_REPO_ROOT/tools/eval_trace.py run 20000 > $GRAFT_REPO_ROOT/$O/run.log 2>&1
 cd $GRAFT_REPO_ROOT
