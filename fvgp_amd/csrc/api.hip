@@ -152,6 +152,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "update_reserve")) { h->update_reserve = (int)value; return 0; }
     if (!strcmp(key, "leaf_yield")) { h->leaf_yield = (int)value; return 0; }
     if (!strcmp(key, "chain_yield")) { h->chain_yield = (int)value; return 0; }
+    if (!strcmp(key, "panel_fit")) { h->panel_fit = (int)value; return 0; }
     if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
     if (!strcmp(key, "update_atomic_k")) { h->update_atomic_k = value; return 0; }
@@ -537,6 +538,20 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
         // N=12k -3 %, N=20k +-0 with 512 throughout)
         int64_t w = (h->outer_block_big > NB && np - J0 > h->big_threshold) ? h->outer_block_big : NB;
         if (h->outer_block_small > 0 && h->outer_block_small < w && np - J0 <= h->small_threshold) w = h->outer_block_small;
+        // `panel_fit`: a boundary may move by one block column either way so that the big update it starts -- the lower tiles of
+        // the rows below it, in rounds of 2 x n_cus workgroups of equal length -- ends on a (nearly) full round: T (T + 1) / 2
+        // tiles change by ~T per block column, more than half a round down to T = 256
+        if (h->panel_fit && w >= 4 * TILE && J0 + w + TILE < np && np - (J0 + w) >= 4096) {
+            const int64_t slots = 2 * (int64_t)h->n_cus;
+            int64_t best = w; double best_fill = -1.0;
+            for (int64_t cand = w - TILE; cand <= w + TILE; cand += TILE) {
+                const int64_t T = (np - (J0 + cand)) / TILE, tiles = T * (T + 1) / 2;
+                const int64_t rem = tiles % slots;
+                const double fill = rem == 0 ? 1.0 : (double)rem / (double)slots;
+                if (fill > best_fill + (cand == w ? -1e-9 : 0.05)) { best_fill = fill; best = cand; }     // the nominal width unless another one is clearly better
+            }
+            w = best;
+        }
         J0 = (J0 + w < np) ? J0 + w : np;
     }
     bnd.push_back(np);

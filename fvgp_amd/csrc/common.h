@@ -104,6 +104,7 @@ struct fvgp_handle {
     // backward sweep in one launch (solve.hip, bwd_sweep_kernel): granules of {value, tag}, the launch counter the tags come from,
     // the column ticket; option "bwd_sweep"
     double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1;
+    int panel_fit = 0;                // panel boundaries moved by one block column for full last rounds of the trailing update: measured +0.1 ... +1 % (the chain fills the partly empty rounds)
     int posterior_halves = 1;         // posterior covariance at >= 512 points: two halves of the points side by side on two streams (api.hip)
     int64_t update_atomic_k = 0;      // trailing updates with K <= this add their tiles with atomics instead of the C read-modify-write
     int update_stagger = 0;           // phases (0, 2, 4, 8) the first wave of a trailing update's workgroups starts in (gemm.hip)
