@@ -59,7 +59,7 @@ struct fvgp_handle {
     double *winv = nullptr;
     size_t winv_cap = 0;
     bool winv_ok = false;
-    int64_t leaf_tiles_rows = 8192;   //   ... while at most this many rows lie below the block
+    int64_t leaf_tiles_rows = 4096;   //   ... while at most this many rows lie below the block
     int panel_recursive = 1;          // option: panels are factored by recursive halving (0: 128-column steps inside `inner_block` sub-panels)
     int leaf_tiles = 1;               // option: the leaf leaves the inverses of its 16x16 diagonal tiles only, the chain's TRSM substitutes
     int k128_kernels = 1;             // option: K = 128 products of the panel chain fetch their operands in one stage
