@@ -447,6 +447,33 @@ def test_loglik_matches_oracle_medium(H):
     np.testing.assert_allclose(ll, ref, rtol=1e-10)
 
 
+def test_scheduling_mechanisms_do_not_change_a_bit(H):
+    """N = 9000 (look-ahead on, the chain runs under the trailing update): the cooperative yield of the update's waves to the
+    leaf / the chain's K = 128 kernels, and the single-launch backward sweep, only change WHEN things run -- log-likelihood,
+    log-determinant, quadratic form and alpha must come out bit-identical with each of them off."""
+    from fvgp_amd import _lib
+    n = 9000
+    x, y = synth(n, 3)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    npad = _lib.pad128(n)
+    xd = H.to_device(x); vd = H.to_device(np.full(n, 0.01))
+    ymd = H.zeros(npad, 1); ymd[:n, 0] = H.to_device(y - np.mean(y))
+    KV = H.empty(npad, npad); alpha = H.empty(npad, 1)
+    out = []
+    try:
+        for ly, cy, bs in ((1, 1, 1), (0, 0, 1), (1, 0, 0), (1, 1, 1)):
+            H.set_option("leaf_yield", ly); H.set_option("chain_yield", cy); H.set_option("bwd_sweep", bs)
+            ll, logdet, quad, info = H.loglik(0, xd, theta, vd, ymd, KV, alpha)
+            H.sync()
+            assert info == 0
+            out.append((ll, logdet, quad, alpha[:n, 0].cpu().numpy().copy()))
+    finally:
+        H.set_option("leaf_yield", 1); H.set_option("chain_yield", 1); H.set_option("bwd_sweep", 1)
+    for o in out[1:]:
+        assert o[:3] == out[0][:3]
+        assert np.array_equal(o[3], out[0][3])
+
+
 # ---- row-sharded building blocks (fvgp_amd/dist.py) ------------------------------------------------
 
 @pytest.mark.parametrize("ranks,off,b_off", [(1, 0, 0), (3, 2, 4), (2, -3, 1)])
