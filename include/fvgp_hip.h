@@ -74,7 +74,13 @@ int fvgp_hip_stream_destroy(void *stream);
  *       "outer_block_big" / "big_threshold" (optional wider panels while more rows than the threshold remain),
  *       "inner_block" (sub-panel width inside panels wider than it: a third block size; 0 = off),
  *       "lookahead" (0/1: factor the next panel on a high-priority side stream under the trailing update),
- *       "profile" (0/1: time the trailing-update launches with HIP events -> fvgp_hip_get_profile) */
+ *       "outer_block_small" / "small_threshold" (narrower panels, default 512, for the last `small_threshold` rows),
+ *       "leaf_yield" / "chain_yield" (0/1, default 1: the trailing update's waves sleep while a leaf / a K = 128 kernel of the
+ *       panel chain shares their compute unit), "bwd_sweep" (0/1, default 1: the backward vector sweep in one launch),
+ *       "posterior_halves" (0/1, default 1: posterior covariance at 512-1024 points as two halves on two streams),
+ *       "profile" (0/1: time the trailing-update launches with HIP events -> fvgp_hip_get_profile);
+ *       further tuning / diagnostic keys, all with defaults: INTEGRATION.md section 4.  None of them changes a result bit
+ *       except the panel widths (a different, equally valid summation order). */
 int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value);
 /* out[0] = number of trailing-update launches of the last potrf, out[1] = their summed
  * duration in ms, out[2] = their summed algorithmic flops, out[3] = whole-potrf ms; of the last fused
