@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         // scalar load (no vector-ALU work: issued behind the step's LDS reads, long landed when the step's MFMAs are through)
         // and sleeps while it is up -- the CU is the leaf's for its 37 us, this workgroup loses those instead of sharing its
         // pipes for 250.  Bounded: a wave sleeps at most ~1 ms per tile whatever the counter says.
-        constexpr bool YIELD = ROLE == 1 && !PERSIST && DBG == 0 && FVGP_GEMM_YIELD_DEFAULT;
+        constexpr bool YIELD = ROLE == 1 && DBG == 0 && FVGP_GEMM_YIELD_DEFAULT;
         const int *yp = nullptr;
         int ybudget = 256;
         if constexpr (YIELD) {

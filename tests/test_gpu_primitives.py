@@ -569,11 +569,12 @@ def test_panel_potrf_dev_tall_panel(H, w, extra, n_valid):
         np.testing.assert_allclose(got[w:], sla.solve_triangular(L, Pm.T, lower=True).T, rtol=1e-9, atol=1e-11)
 
 
-@pytest.mark.parametrize("n,P", [(2700, 300), (1024, 130), (3200, 5), (1300, 8200)])
+@pytest.mark.parametrize("n,P", [(2700, 300), (1024, 130), (3200, 5), (1300, 8200), (2700, 900), (3200, 700)])
 def test_posterior_block_inverse_substitution(H, n, P):
     """The many-point posterior substitutes with the inverted 1024 x 1024 diagonal blocks (doubling from the 128-block
     inverses; n = 2700 leaves a last block of 5 x 128, n = 1024 a single full one; P = 8200 has enough output tiles per
-    block that nothing is split over K): against the oracle's cho_solve
+    block that nothing is split over K; P = 900 / 700 pad to 1024 / 768 rows, which run as two halves on two streams):
+    against the oracle's cho_solve
     (gp_posterior.py:120-136,229-288) and against the 128-step substitution (option block_inverses = 0)."""
     from fvgp_amd import _lib
     x, y = synth(n, 3)
