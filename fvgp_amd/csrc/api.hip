@@ -72,7 +72,6 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     gemm_release_tables(h);
     (void)fvgp_hip_comm_destroy(h);
     if (h->side) (void)hipStreamDestroy(h->side);
-    if (h->low) { (void)hipStreamDestroy(h->low); (void)hipEventDestroy(h->ev_low); }
     if (h->linv) (void)hipFree(h->linv);
     if (h->winv) (void)hipFree(h->winv);
     if (h->logdet_parts) (void)hipFree(h->logdet_parts);
@@ -153,7 +152,6 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "update_reserve")) { h->update_reserve = (int)value; return 0; }
     if (!strcmp(key, "leaf_yield")) { h->leaf_yield = (int)value; return 0; }
     if (!strcmp(key, "chain_yield")) { h->chain_yield = (int)value; return 0; }
-    if (!strcmp(key, "update_low")) { h->update_low = (int)value; return 0; }
     if (!strcmp(key, "panel_fit")) { h->panel_fit = (int)value; return 0; }
     if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
@@ -502,23 +500,6 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     int rc = ensure_blocks(h, nblk);
     if (rc) return rc;
     h->winv_ok = false; h->linv_L = nullptr;
-    // experiment (option "update_low"): the whole factorisation's main stream is a LOW-priority stream of the handle, the chain
-    // stays on the high-priority one -- does the queue priority gap change how fast the chain's kernels get their slots?
-    hipStream_t callerS = h->stream;
-    const bool low = h->update_low && h->lookahead && np >= 6144;
-    if (low) {
-        rc = fvgp_ensure_side(h); if (rc) return rc;
-        if (!h->low) {
-            int lo = 0, hi = 0;
-            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIPCHK(hipStreamCreateWithPriority(&h->low, hipStreamNonBlocking, lo));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_low, hipEventDisableTiming));
-        }
-        HIPCHK(hipEventRecord(h->ev_low, callerS));
-        HIPCHK(hipStreamWaitEvent(h->low, h->ev_low, 0));
-        h->stream = h->low;
-    }
-    struct Restore { fvgp_handle *h; hipStream_t s; bool on; ~Restore() { if (on) { (void)hipEventRecord(h->ev_low, h->low); (void)hipStreamWaitEvent(s, h->ev_low, 0); h->stream = s; } } } restore{h, callerS, low};
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
     const int64_t NB = h->outer_block;
     size_t nev = 0;

@@ -105,7 +105,6 @@ struct fvgp_handle {
     // the column ticket; option "bwd_sweep"
     double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1;
     int panel_fit = 0;                // panel boundaries moved by one block column for full last rounds of the trailing update: measured +0.1 ... +1 % (the chain fills the partly empty rounds)
-    hipStream_t low = nullptr; hipEvent_t ev_low = nullptr; int update_low = 0;      // experiment: low-priority main stream (potrf_driver)
     int posterior_halves = 1;         // posterior covariance at >= 512 points: two halves of the points side by side on two streams (api.hip)
     int64_t update_atomic_k = 0;      // trailing updates with K <= this add their tiles with atomics instead of the C read-modify-write
     int update_stagger = 0;           // phases (0, 2, 4, 8) the first wave of a trailing update's workgroups starts in (gemm.hip)
