@@ -107,6 +107,12 @@ def lib():
         raise HipExtensionError(
             f"{LIB_PATH} not found. The HIP extension is the product path and has no fallback; "
             f"build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {CSRC}`.")
+    # torch first: libfvgp_hip.so must bind to the HIP runtime torch has loaded (its own copy), not bring /opt/rocm's in
+    # beside it -- two runtimes in one process, and the one loaded first sees "no ROCm-capable device" once the other owns it
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:
