@@ -188,11 +188,8 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
     double *linv = g.linv + (long)blockIdx.x * g.linv_stride;
     int nst = 0;
     // this compute unit is the leaf's while it runs: the co-resident trailing-update workgroup sleeps (gemm.hip, YIELD)
-    int *yflag = nullptr;
-    if (g.yield && tid == 0) {
-        yflag = cu_yield_slot(g.yield);
-        atomicAdd(yflag, 1);
-    }
+    int *const yslot = g.yield ? cu_yield_slot(g.yield) : nullptr;      // wave-uniform: lives in scalar registers
+    if (yslot && tid == 0) atomicAdd(yslot, 1);
 #define FVGP_STAMP() do { if (g.stamps && tid == 0) g.stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
     FVGP_STAMP();
 
@@ -340,7 +337,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
             linv[wave * 256 + a * 16 + r] = d;
         }
         FVGP_STAMP();
-        if (yflag) atomicAdd(yflag, -1);
+        if (yslot && tid == 0) atomicAdd(yslot, -1);
         return;
     }
     // ---- block column `wave` of inv(L), kept in registers in MFMA B-operand layout -----------------------
@@ -402,7 +399,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
         }
     }
     FVGP_STAMP();
-    if (yflag) atomicAdd(yflag, -1);
+    if (yslot && tid == 0) atomicAdd(yslot, -1);
 #undef FVGP_STAMP
 }
 

@@ -4,7 +4,6 @@ C=$GRAFT_REPO_ROOT/fvgp_amd/csrc/libfvgp_hip.so
 for i in 1 2; do
 for lib in $C $V; do
   echo "lib=$lib"
-  for n in 8000 12000 20000; do FVGP_HIP_LIB=$lib python tools/eval_trace.py run $n 2>&1 | grep "^N" | awk '{print $1,$2,$(NF-2),$(NF-1),$NF}'; done
+  for n in 4000 8000 12000; do FVGP_HIP_LIB=$lib python tools/eval_trace.py run $n 2>&1 | grep "^N" | awk '{print $1,$2,$(NF-2),$(NF-1),$NF}'; done
 done
 done
-for lib in $C $V; do echo "lib=$lib"; FVGP_HIP_LIB=$lib timeout -k 10 300 python tools/shard_emulate.py --world 8 --n 50000 2>&1 | grep "^world"; done
