@@ -72,7 +72,7 @@ def test_gemm_layouts(H, akm, bnm, lower):
         assert np.max(np.abs(got - ref) / scale) < 8 * EPS
 
 
-@pytest.mark.parametrize("n", [300, 3333, 8200, 36000])
+@pytest.mark.parametrize("n", [100, 128, 300, 3333, 8200, 36000])
 def test_backward_sweep_in_one_launch_matches_the_step_kernels(H, n):
     """fvgp_hip_potrs with one right-hand side: the single-launch backward sweep (workgroups hand x_k to each other through
     tagged 16-byte granules) must give the bits of the per-block launches -- every sum is formed in the same order, so a stale
