@@ -444,38 +444,54 @@ static int block_inverse(fvgp_handle *h, const double *Lsq, int64_t ldl, const d
 // under look-ahead every workgroup of the chain waits for a slot one retiring trailing-update tile frees (about two per
 // microsecond), which is what made a panel at 20k rows take 4.6 ms.  Backward error ~ eps cond(L_sq) instead of
 // eps cond(128-block) -- the bound the posterior's and POTRI's 1024-block inverses already work under.
-static int panel_factor_square(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+// the chain's part (the panel's square, its inverse); returns in *square whether the rows below are still to be done by
+// panel_square_below (false: the ordinary chain has factored the whole panel)
+static int panel_square_chain(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend, bool *square) {
     const int64_t w = Jend - J0, below = np - Jend;
     bool pow2 = w >= 2 * TILE;
     for (int64_t t = w / TILE; t > 1; t >>= 1) if (t & 1) pow2 = false;
-    if (!h->panel_square || below <= h->panel_square_rows || !pow2) return panel_factor_nested(h, A, n, np, lda, J0, Jend);
+    *square = h->panel_square && below > h->panel_square_rows && pow2;
+    if (!*square) return panel_factor_nested(h, A, n, np, lda, J0, Jend);
     int rc = panel_factor_nested(h, A, n, Jend, lda, J0, Jend);          // the chain, confined to the square
     if (rc) return rc;
     const size_t need_w = (size_t)w * w + (size_t)w * w / 4, need_ws = (size_t)below * w;
     if (need_w > h->panel_w_cap) {
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipDeviceSynchronize());
         if (h->panel_w) HIPCHK(hipFree(h->panel_w));
         h->panel_w = nullptr; h->panel_w_cap = 0;
         HIPCHK(hipMalloc((void **)&h->panel_w, need_w * sizeof(double)));
         h->panel_w_cap = need_w;
     }
     if (need_ws > h->panel_ws_cap) {
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipDeviceSynchronize());
         if (h->panel_ws) HIPCHK(hipFree(h->panel_ws));
         h->panel_ws = nullptr; h->panel_ws_cap = 0;
         HIPCHK(hipMalloc((void **)&h->panel_ws, need_ws * sizeof(double)));
         h->panel_ws_cap = need_ws;
     }
-    double *W = h->panel_w, *T = W + (size_t)w * w, *P = h->panel_ws;
+    double *W = h->panel_w, *T = W + (size_t)w * w;
     const double *linv0 = h->linv + (J0 / TILE) * LEAF_DOUBLES;
     rc = launch_leaf_inverse_batched(h, A + J0 * lda + J0, lda, w / TILE, const_cast<double *>(linv0)); if (rc) return rc;
-    rc = block_inverse(h, A + J0 * lda + J0, lda, linv0, w, W, T); if (rc) return rc;
-    rc = launch_copy_panel(h, A + Jend * lda + J0, lda, P, w, below, w); if (rc) return rc;
+    return block_inverse(h, A + J0 * lda + J0, lda, linv0, w, W, T);
+}
+
+// the rows below the square: L[below, panel] = A[below, panel] inv(L_sq)^T, from a compact copy (a tile reads the columns to its left)
+static int panel_square_below(fvgp_handle *h, double *A, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+    const int64_t w = Jend - J0, below = np - Jend;
+    double *W = h->panel_w, *P = h->panel_ws;
+    int rc = launch_copy_panel(h, A + Jend * lda + J0, lda, P, w, below, w); if (rc) return rc;
     GemmDesc t{};
     t.a_kmajor = 0; t.b_nmajor = 0; t.lower = 0; t.M = below; t.N = w; t.K = w; t.alpha = 1.0; t.beta = 0.0;
     t.A = P; t.lda = w; t.B = W; t.ldb = w; t.C = A + Jend * lda + J0; t.ldc = lda;
     t.kb0 = 0; t.ke0 = TILE; t.kej = TILE;                                // W is lower triangular: k < 128 (tj + 1)
     return launch_gemm(h, t);
+}
+
+static int panel_factor_square(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+    bool square = false;
+    int rc = panel_square_chain(h, A, n, np, lda, J0, Jend, &square);
+    if (rc || !square) return rc;
+    return panel_square_below(h, A, np, lda, J0, Jend);
 }
 
 static double lower_flops(int64_t M, int64_t N, int64_t K) {     // algorithmic flops of a lower-tile update
@@ -600,7 +616,12 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             HIPCHK(hipStreamWaitEvent(sideS, h->ev_cols, 0));
             h->stream = sideS;
             h->chain_contended = np - Nend >= 4096;      // the rest of this panel's update runs beside the chain
-            rc = panel_factor_square(h, A, n, np, lda, Jend, Nend);
+            // panel_square == 2: the chain stream only factors the panel's square (small kernels, which start at once beside a
+            // PERSISTENT update: a launch with pending workgroups holds up the dispatch of everybody else's); the one big
+            // product for the rows below follows on the main stream, on the whole chip
+            bool split = false;
+            if (h->panel_square == 2) rc = panel_square_chain(h, A, n, np, lda, Jend, Nend, &split);
+            else rc = panel_factor_square(h, A, n, np, lda, Jend, Nend);
             h->chain_contended = false;
             h->stream = mainS;
             if (rc) return rc;
@@ -609,6 +630,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             if (np > Nend) { rc = timed_update(J0, Jend, Nend, np); if (rc) return rc; }
             // the next iteration's updates use panel J+1: wait for its factorisation
             HIPCHK(hipStreamWaitEvent(mainS, h->ev_panel, 0));
+            if (split) { rc = panel_square_below(h, A, np, lda, Jend, Nend); if (rc) return rc; }
         }
     }
     if (h->leaf_tiles) {

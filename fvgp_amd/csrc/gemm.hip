@@ -195,7 +195,10 @@ template <int AKM, int BNM, int ROLE, int DBG = 0, int PERSIST = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // 76 KB, a little more than the 72 KB of operand images: the look-ahead leaf kernel (73 KB) must fit
     // into the LDS range one retiring workgroup of this kernel frees
-    __shared__ double smem[2][2][IMG + 128 + ((DBG & 1024) ? 640 : 0)];
+#ifndef FVGP_UPDATE_ONE_PER_CU
+#define FVGP_UPDATE_ONE_PER_CU 0          // experiment: pad the trailing update's LDS so that only ONE of its workgroups fits a compute unit
+#endif
+    __shared__ double smem[2][2][IMG + 128 + ((DBG & 1024) ? 640 : 0) + ((ROLE == 1 && DBG == 0 && FVGP_UPDATE_ONE_PER_CU) ? 320 : 0)];
 
     // XCD-aware remap: hardware deals block b to XCD b%8.  Blocks b, b+8, b+16, .. (one XCD) walk whole
     // super-tiles: the 8*SN tiles of a super-tile run together on one L2, and super-tiles are dealt
