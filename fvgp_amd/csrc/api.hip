@@ -33,7 +33,9 @@ int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred) {
         const int64_t cand[3] = {np * 256 + 1024, (1 + want) * pp * 1024 + 64, swant * pp * pp + 64};
         for (int64_t c : cand) if (c > vec) vec = c;
     }
-    return (nblk * LEAF_DOUBLES + nblk + (npred > 0 ? vec : np * 8) + winv + RED_SLOTS) * (int64_t)sizeof(double) + (int64_t)sizeof(int);
+    // + the per-CU yield counters, the chain's ticket ring, the backward sweep's granules (16 bytes per row) and ticket
+    const int64_t round3 = (int64_t)CU_YIELD_KEYS * CU_YIELD_STRIDE * (int64_t)sizeof(int) + 2 * 256 * (int64_t)sizeof(int) + np * 16 + 2 * (int64_t)sizeof(int);
+    return (nblk * LEAF_DOUBLES + nblk + (npred > 0 ? vec : np * 8) + winv + RED_SLOTS) * (int64_t)sizeof(double) + (int64_t)sizeof(int) + round3;
 }
 
 int64_t fvgp_hip_padded_dim(int64_t n) { return pad128(n); }
