@@ -649,6 +649,134 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   }
 }
 
+// PROBE: the 256 x 128 macro-tile the round-2 review asked about.  One workgroup of EIGHT waves (4 x 2, each 64 x 64 as in the
+// shipped kernel) per compute unit instead of two workgroups of four: the same sixteen MFMA waves' worth of work per K step
+// reads 256 + 128 operand rows instead of 2 x (128 + 128) (-25 % of the global -> LDS traffic), at the price of ONE barrier
+// domain per CU (nobody computes while the eight waves meet).  Same loop as the shipped kernel otherwise (swizzled unpadded
+// images, LDS-DMA staging, all sixteen fragment reads before the MFMAs, no vector-ALU work).  (M,K) x (N,K) layout, full tile
+// grids, M % 256 == 0; option gemm_probe = 9000.  Measured: tools/gemm_ab.py 0 9000, profiles/r03_macro_tile.txt.
+__global__ __launch_bounds__(512, 2) void gemm_f64_macro_kernel(GemmArgs g) {
+    constexpr int ROWS = 256 + 128;
+    __shared__ double smem[3][ROWS * 16];                 // three stages of 48 KB: one workgroup per CU, the DMA two K steps ahead
+    const int tid = threadIdx.x;
+    const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
+    int ti, tj;
+    tile_of(t, g.tiles_m, g.tiles_n, false, ti, tj);       // tiles_m counts 256-row tiles here
+    if (ti >= g.tiles_m || tj >= g.tiles_n) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+    const int nk = (int)(g.K / BK);
+    const long m0 = (long)ti * 256, n0 = (long)tj * 128;
+    auto swz = [](int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); };
+    const double *abase = uniform_ptr(g.A + m0 * g.lda);
+    const double *bbase = uniform_ptr(g.B + n0 * g.ldb);
+    const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(abase), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(bbase), 0, 0xffffffff, 0x00020000);
+    // LDS-DMA: a wave instruction fills eight whole rows (lane l lands 16 l bytes behind the wave's base)
+    int voa[4], vob[2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = p * 64 + wave * 8 + (lane >> 3), kc = ((lane & 7) ^ swz(row)) * 2;
+        voa[p] = (int)(((long)row * g.lda + kc) * 8);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = p * 64 + wave * 8 + (lane >> 3), kc = ((lane & 7) ^ swz(row)) * 2;
+        vob[p] = (int)(((long)row * g.ldb + kc) * 8);
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_step = [&](auto bufc, int so) {
+        constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_src, (lds_void *)&smem[BUF][(p * 64 + wave_u * 8) * 16], 16, voa[p], so, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_src, (lds_void *)&smem[BUF][(256 + p * 64 + wave_u * 8) * 16], 16, vob[p], so, 0, 0);
+    };
+    int fa[4], fa1[4], fb[4], fb1[4];
+    {
+        const int c0 = (2 * q) ^ swz(r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = (wm * 64 + i * 16 + r) * 16 + 2 * c0; fa1[i] = (wm * 64 + i * 16 + r) * 16 + 2 * (c0 ^ 1);
+            fb[i] = (256 + wn * 64 + i * 16 + r) * 16 + 2 * c0; fb1[i] = (256 + wn * 64 + i * 16 + r) * 16 + 2 * (c0 ^ 1);
+        }
+    }
+    double4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    if (nk > 0) dma_step(std::integral_constant<int, 0>{}, 0);
+    if (nk > 1) dma_step(std::integral_constant<int, 1>{}, BK * 8);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stage 0 has landed
+    __syncthreads();
+    int soff = BK * 8;
+    // one barrier domain: a K step's MFMAs are split around its barrier -- the second half's fragments are read before the first
+    // half's MFMAs, the next step's first-half fragments right behind the barrier and before the second half's MFMAs, so no wave
+    // arrives at or leaves the barrier with nothing to issue
+    double2_t f0a[4], f0b[4], f1a[4], f1b[4];
+    if (nk > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f0a[i] = *reinterpret_cast<const double2_t *>(&smem[0][fa[i]]);
+            f0b[i] = *reinterpret_cast<const double2_t *>(&smem[0][fb[i]]);
+        }
+    }
+    // step s computes on stage s % 3, its DMA fetches step s + 2 into stage (s + 2) % 3 (read last in step s - 1: everybody
+    // has passed that step's barrier), and the wait in front of the barrier only asks for step s + 1's six loads
+    auto kstep = [&](auto curc, const bool more, const bool more2) {
+        constexpr int CUR = decltype(curc)::value;
+        if (more2) { soff += BK * 8; dma_step(std::integral_constant<int, (CUR + 2) % 3>{}, soff); }
+        const double *ps = &smem[CUR][0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f1a[i] = *reinterpret_cast<const double2_t *>(ps + fa1[i]);
+            f1b[i] = *reinterpret_cast<const double2_t *>(ps + fb1[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0a[i][s2], f0b[j][s2], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (more) {
+            const double *pn = &smem[(CUR + 1) % 3][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f0a[i] = *reinterpret_cast<const double2_t *>(pn + fa[i]);
+                f0b[i] = *reinterpret_cast<const double2_t *>(pn + fb[i]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1a[i][s2], f1b[j][s2], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 3) {
+        kstep(std::integral_constant<int, 0>{}, true, true);
+        kstep(std::integral_constant<int, 1>{}, true, kt + 3 < nk);
+        kstep(std::integral_constant<int, 2>{}, kt + 3 < nk, kt + 4 < nk);
+    }
+    if (kt < nk) kstep(std::integral_constant<int, 0>{}, kt + 1 < nk, false);
+    if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, false, false);
+    store_tile(acc, g.C + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
+}
+
 // Small-tile variant for the latency-bound steps of the panel chain (TRSM by the inverted diagonal block, in-panel
 // update with K = 128) when a launch has too few 128 x 128 tiles to fill the chip: TM x TN tiles of a quarter the size,
 // so four times the workgroups share the same product and a K = 128 tile is 16 MFMAs per wave instead of 64.
@@ -1351,6 +1479,17 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         if (split || d.probe || d.batch_y < 1 || d.batch_z < 1) { fvgp_set_error("gemm: a strided batch excludes split-K and probes"); return -3; }
         g.ny = d.batch_y; g.ab1 = d.a_by; g.ab2 = d.a_bz; g.bb1 = d.b_by; g.bb2 = d.b_bz; g.cb1 = d.c_by; g.cb2 = d.c_bz;
         grid.y = (unsigned)(d.batch_y * d.batch_z);
+    }
+    if (d.probe == 9000) {            // the 256 x 128 macro-tile probe
+        if (d.a_kmajor || d.b_nmajor || d.lower || !plain_k || split || batched || d.M % 256 || d.rev_m || d.bc_ranks != 1 || d.bc_off ||
+            d.lda >= (1L << 20) || d.ldb >= (1L << 20)) {          // 256 rows within a 32-bit byte offset
+            fvgp_set_error("gemm probe 9000: (M,K) x (N,K), full grid, M % 256 == 0"); return -3;
+        }
+        g.tiles_m = (int)(d.M / 256); g.tab = nullptr;
+        const long nt = gemm_grid_tiles(g.tiles_m, g.tiles_n, false);
+        hipLaunchKernelGGL(gemm_f64_macro_kernel, dim3((unsigned)nt), dim3(512), 0, h->stream, g);
+        HIPCHK(hipGetLastError());
+        return 0;
     }
     if (d.probe) {
         // timing probes of the K loop with parts of it removed (results are meaningless unless noted): 1 no global
