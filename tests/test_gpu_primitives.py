@@ -111,6 +111,31 @@ def test_backward_sweep_in_one_launch_matches_the_step_kernels(H, n):
         assert np.max(np.abs(out[1][0] - ref)) / np.max(np.abs(ref)) < 1e-11
 
 
+def test_macro_tile_probe_is_bit_identical(H):
+    """The 256 x 128 macro-tile probe kernel (one eight-wave workgroup per CU, option gemm_probe = 9000; measured and not
+    adopted) contracts k in the shipped kernel's order: same bits (33, 65 and 129 K steps: every tail of
+    its three-stage ring)."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    for (M, N, K) in ((512, 384, 528), (768, 128, 1040), (256, 256, 2064)):      # K > 512: the shipped path takes its 128-tile kernel too
+        A = torch.randn(M, K, dtype=torch.float64, device="cuda", generator=g)
+        B = torch.randn(N, K, dtype=torch.float64, device="cuda", generator=g)
+        C0 = torch.randn(M, N, dtype=torch.float64, device="cuda", generator=g)
+        out = {}
+        try:
+            for v in (0, 9000):
+                H.set_option("gemm_probe", v)
+                C = C0.clone()
+                H.gemm(0, 0, 0, M, N, K, -0.75, A, B, 1.25, C)
+                H.sync()
+                out[v] = C
+        finally:
+            H.set_option("gemm_probe", 0)
+        assert torch.equal(out[0], out[9000])
+        ref = -0.75 * A @ B.T + 1.25 * C0
+        assert float((out[9000] - ref).abs().max()) < 1e-11 * K
+
+
 @pytest.mark.parametrize("one_stage", [1, 0])
 def test_gemm_in_place_over_the_nk_operand(H, one_stage):
     """(M,K) x (N,K) with C == B, M = N = K = 128 (a public-ABI call nobody inside makes): a small-tile workgroup owns 32 rows
