@@ -309,12 +309,21 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
     //      transposed, into the tile's (unused) strict upper half, the diagonal is srd -------------------
     double x[16];
     {
+        // lane c solves L x = e_c (column c of the inverse) by a COLUMN sweep: a finished x[k] goes into every later row at once
+        // (independent FMAs; L[i][k] is a broadcast LDS read), so the dependent path is 16 x (scale, one FMA) -- the row-by-row
+        // form waited for a k-term chain of FMAs fed by two readlanes each, 6.3 of the leaf's 86 thousand cycles.  Every sum
+        // receives its terms in the same order (k ascending): same bits.
         const int c = lane & 15;
-        double a[16], rd[16];
         const double *Tw = &sT[tix(wave, wave)];
+        double sv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { a[k] = (k <= c) ? Tw[el(c, k)] : 0.0; rd[k] = srd[16 * wave + k]; }
-        InvRow<0>::step(a, rd, x, c);
+        for (int i = 0; i < 16; ++i) sv[i] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            x[k] = sv[k] * srd[16 * wave + k];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (i > k) sv[i] = fma(-Tw[el(i, k)], x[k], sv[i]);
+        }
         if (lane < 16) {
             double *Tm = &sT[tix(wave, wave)];
 #pragma unroll
