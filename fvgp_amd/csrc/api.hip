@@ -35,7 +35,7 @@ int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred) {
     }
     // + the per-CU yield counters, the chain's ticket ring, the backward sweep's granules (16 bytes per row) and ticket
     const int64_t round3 = (int64_t)CU_YIELD_KEYS * CU_YIELD_STRIDE * (int64_t)sizeof(int) + 2 * 256 * (int64_t)sizeof(int) + np * 16 + 2 * (int64_t)sizeof(int);
-    return (nblk * LEAF_DOUBLES + nblk + (npred > 0 ? vec : np * 8) + winv + RED_SLOTS) * (int64_t)sizeof(double) + (int64_t)sizeof(int) + round3;
+    return (nblk * LEAF_DOUBLES + nblk * TILE + (npred > 0 ? vec : np * 8) + winv + RED_SLOTS) * (int64_t)sizeof(double) + (int64_t)sizeof(int) + round3;
 }
 
 int64_t fvgp_hip_padded_dim(int64_t n) { return pad128(n); }
@@ -223,7 +223,7 @@ static int ensure_blocks(fvgp_handle *h, int64_t nblk) {
     if ((size_t)nblk > h->logdet_cap) {
         if (h->logdet_parts) HIPCHK(hipFree(h->logdet_parts));
         h->logdet_parts = nullptr; h->logdet_cap = 0;
-        HIPCHK(hipMalloc((void **)&h->logdet_parts, (size_t)nblk * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&h->logdet_parts, (size_t)nblk * TILE * sizeof(double)));
         h->logdet_cap = (size_t)nblk;
     }
     return 0;
@@ -331,7 +331,7 @@ static int panel_factor(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_
         // block (19 of 103 thousand cycles) and the TRSM substitutes with the 16 x 16 tile inverses; with many rows the
         // product with the full inverse is the cheaper TRSM and the leaf is hidden under the trailing update anyway
         const int tiles = (h->leaf_tiles && R <= h->leaf_tiles_rows) ? 1 : 0;
-        rc = launch_leaf(h, A + k0 * lda + k0, lda, h->linv + kb * LEAF_DOUBLES, h->logdet_parts + kb, (int)k0, 1,
+        rc = launch_leaf(h, A + k0 * lda + k0, lda, h->linv + kb * LEAF_DOUBLES, h->logdet_parts + kb * TILE, (int)k0, 1,
                          nv >= TILE ? TILE : (nv > 0 ? (int)nv : 0), tiles);
         if (rc) return rc;
         if (R <= 0) continue;
@@ -1150,7 +1150,7 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     if (info_host) *info_host = info;
     if (info != 0) { out_host[0] = out_host[1] = out_host[2] = NAN; return 0; }
     if (h->profile) HIPCHK(hipEventRecord(h->ev_stage[2], h->stream));
-    rc = launch_sum(h, h->logdet_parts, np / TILE, h->red); if (rc) return rc;
+    rc = launch_neg_log_sum(h, h->logdet_parts, np, h->red); if (rc) return rc;       // sum log L_ii from the leaves' 1 / L_ii
     if (fused) {
         rc = launch_rowsumsq(h, KV, ld, n, ncol, n, h->red + 1); if (rc) return rc;
         const int C = ncol <= 1 ? 1 : ncol <= 2 ? 2 : ncol <= 4 ? 4 : 8;

@@ -40,7 +40,7 @@ __device__ __forceinline__ int el(int a, int b) { return a * 16 + (b ^ (((a >> 1
 struct LeafArgs {
     double *A; long lda;          // block origin
     double *linv;                 // 128*128 out
-    double *logdet_part;          // 1 double out (may be null)
+    double *logdet_part;          // 128 doubles out: 1 / L_ii of the block's valid rows, 1 for padding (may be null)
     int *info; int info_base;
     int do_factor;
     int nvalid;                   // rows of this block that count for log-det and info (rest is padding)
@@ -178,7 +178,6 @@ __device__ __forceinline__ int diag_factor(double *sT, double *srd, int lane) {
 __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
     __shared__ double sT[NT * TSZ];      // 73,728 B
     __shared__ double srd[128];          // 1 / L_aa
-    __shared__ double slog[8];
     // the leaf sits on the critical path of the panel chain and shares its SIMDs with trailing-update waves
     // (look-ahead): its instructions go first
     __builtin_amdgcn_s_setprio(3);
@@ -289,16 +288,9 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
                 if (ti != tj || r <= a) A[(long)(16 * ti + a) * g.lda + 16 * tj + r] = T[el(a, r)];
             }
         }
-        // ---- the log-diagonal sum ------------------------------------------------------------------------------------
-        if (g.logdet_part != nullptr) {
-            double s = 0.0;
-            if (tid < g.nvalid) s = -log(srd[tid]);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            if (lane == 0) slog[wave] = s;
-            __syncthreads();
-            if (tid == 0) g.logdet_part[blockIdx.x] = slog[0] + slog[1];
-        }
+        // ---- the reciprocal diagonal, for the log-determinant: the logarithms are taken once, by one kernel over all blocks
+        //      (neg_log_sum_kernel), not 128 at a time behind a barrier on the chain's critical path (1.4 thousand cycles) ------
+        if (g.logdet_part != nullptr && tid < 128) g.logdet_part[(long)blockIdx.x * 128 + tid] = tid < g.nvalid ? srd[tid] : 1.0;
         FVGP_STAMP();
     } else {
         if (tid < 128) srd[tid] = 1.0 / sT[tix(tid >> 4, tid >> 4) + el(tid & 15, tid & 15)];

@@ -311,6 +311,17 @@ __global__ void sum_kernel(const double *v, long n, double *out) {
     if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sw[w]; out[0] = t; }
 }
 
+// out[0] = -sum log v[i]  (v = the reciprocal diagonal the leaves leave: sum log L_ii), fixed order
+__global__ void neg_log_sum_kernel(const double *v, long n, double *out) {
+    __shared__ double sw[16];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s -= log(v[i]);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sw[w]; out[0] = t; }
+}
+
 // out[0] = sum_{i<n, cc<c} a[i*lda+cc] * b[i*ldb+cc]
 __global__ void dot_rows_kernel(const double *a, long lda, const double *b, long ldb, long n, int c, double *out) {
     __shared__ double sw[16];
@@ -740,6 +751,12 @@ int launch_diag_logsum(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, 
 
 int launch_sum(fvgp_handle *h, const double *v, int64_t n, double *out_dev) {
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, h->stream, v, (long)n, out_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_neg_log_sum(fvgp_handle *h, const double *v, int64_t n, double *out_dev) {
+    hipLaunchKernelGGL(neg_log_sum_kernel, dim3(1), dim3(1024), 0, h->stream, v, (long)n, out_dev);
     HIPCHK(hipGetLastError());
     return 0;
 }
