@@ -154,6 +154,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "update_reserve")) { h->update_reserve = (int)value; return 0; }
     if (!strcmp(key, "leaf_yield")) { h->leaf_yield = (int)value; return 0; }
     if (!strcmp(key, "chain_yield")) { h->chain_yield = (int)value; return 0; }
+    if (!strcmp(key, "lookahead_min")) { h->lookahead_min = value; return 0; }
     if (!strcmp(key, "panel_fit")) { h->panel_fit = (int)value; return 0; }
     if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
@@ -576,7 +577,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     const size_t npan = bnd.size() - 1;
     // a switch between the two streams costs ~12 us (event wait): below ~6k rows the panels are too short to pay for it
     // (measured: N=4000 2.78 ms with, 2.68 without; N=8000 7.48 / 7.58; N=12000 16.4 / 16.9)
-    const bool la = h->lookahead && npan > 2 && np >= 6144;
+    const bool la = h->lookahead && npan > 2 && np >= h->lookahead_min;
     if (!la) {
         for (size_t J = 0; J < npan; ++J) {
             rc = panel_factor_square(h, A, n, np, lda, bnd[J], bnd[J + 1]); if (rc) return rc;

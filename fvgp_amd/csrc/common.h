@@ -105,6 +105,7 @@ struct fvgp_handle {
     // the column ticket; option "bwd_sweep"
     double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1;
     int panel_fit = 0;                // panel boundaries moved by one block column for full last rounds of the trailing update: measured +0.1 ... +1 % (the chain fills the partly empty rounds)
+    int64_t lookahead_min = 4608;     // look-ahead from this many (padded) rows on (a stream switch costs ~12 us: N=4000 +5 % with it, N=4800 -2.5 %, N=6000 -5 %)
     int posterior_halves = 1;         // posterior covariance at >= 512 points: two halves of the points side by side on two streams (api.hip)
     int64_t update_atomic_k = 0;      // trailing updates with K <= this add their tiles with atomics instead of the C read-modify-write
     int update_stagger = 0;           // phases (0, 2, 4, 8) the first wave of a trailing update's workgroups starts in (gemm.hip)
