@@ -83,6 +83,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     if (h->sweep_gran) (void)hipFree(h->sweep_gran);
     if (h->sweep_ticket) (void)hipFree(h->sweep_ticket);
     if (h->chain_tickets) (void)hipFree(h->chain_tickets);
+    if (h->chain_flags) (void)hipFree(h->chain_flags);
     if (h->panel_w) (void)hipFree(h->panel_w);
     if (h->panel_ws) (void)hipFree(h->panel_ws);
     if (h->vec) (void)hipFree(h->vec);
@@ -156,6 +157,8 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "chain_yield")) { h->chain_yield = (int)value; return 0; }
     if (!strcmp(key, "lookahead_min")) { h->lookahead_min = value; return 0; }
     if (!strcmp(key, "panel_fit")) { h->panel_fit = (int)value; return 0; }
+    if (!strcmp(key, "panel_chain")) { h->panel_chain = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "panel_chain_min")) { h->panel_chain_min = value; return 0; }
     if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
     if (!strcmp(key, "update_atomic_k")) { h->update_atomic_k = value; return 0; }
@@ -491,6 +494,7 @@ static int panel_square_below(fvgp_handle *h, double *A, int64_t np, int64_t lda
 }
 
 static int panel_factor_square(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+    if (h->panel_chain && np - J0 >= h->panel_chain_min) return launch_panel_chain(h, A, n, np, lda, J0, Jend);      // one resident kernel for the whole panel (chain.hip)
     bool square = false;
     int rc = panel_square_chain(h, A, n, np, lda, J0, Jend, &square);
     if (rc || !square) return rc;
@@ -636,7 +640,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             if (split) { rc = panel_square_below(h, A, np, lda, Jend, Nend); if (rc) return rc; }
         }
     }
-    if (h->leaf_tiles) {
+    if (h->leaf_tiles || h->panel_chain) {
         // the chain only needed the inverses of the 16 x 16 diagonal tiles; the 128 x 128 block inverses the sweeps, the
         // posterior and POTRI use come from one launch over all blocks (a few tens of microseconds on the whole chip
         // instead of 8 us per block on the chain's critical path)
@@ -652,6 +656,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     HIPCHK(hipMemcpyAsync(hinfo, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     int info = *hinfo;
+    if (info == 0x7fffffff) { fvgp_set_error("panel chain: a workgroup waited longer than 3 s for a hand-off and the launch was abandoned"); return 1999; }
     if (info > n) info = 0;   // cannot happen: the padding is an identity block
     if (info_host) *info_host = info;
     h->winv_ok = false; h->linv_L = A; h->linv_n = n; h->linv_ld = lda;
@@ -959,7 +964,8 @@ int fvgp_hip_panel_potrf_dev(fvgp_handle *h, double *T, int64_t w, int64_t rows,
     if (rc) return rc;
     h->winv_ok = false; h->linv_L = nullptr;
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
-    rc = panel_factor_nested(h, T, n_valid, rows, ldt, 0, w);   // leaf / TRSM of every row below / in-panel update per 128 columns, in sub-panels of `inner_block`
+    if (h->panel_chain) rc = launch_panel_chain(h, T, n_valid, rows, ldt, 0, w);      // one resident kernel for the whole panel (chain.hip)
+    else rc = panel_factor_nested(h, T, n_valid, rows, ldt, 0, w);   // leaf / TRSM of every row below / in-panel update per 128 columns, in sub-panels of `inner_block`
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     if (logdet_dev && n_valid > 0) return launch_diag_logsum(h, T, n_valid, ldt, logdet_dev);

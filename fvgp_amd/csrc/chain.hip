@@ -1,0 +1,418 @@
+// The panel chain as ONE resident kernel per panel.
+//
+// A panel of the blocked Cholesky (scipy.linalg.cho_factor -> dpotrf, fvgp/gp_lin_alg.py:245) is w = 128 n columns wide and
+// reaches from its diagonal square down to the last row of the matrix.  Per 128 columns the chain is: factor the diagonal
+// block (leaf), solve every block row below against it (TRSM), bring the rest of the panel up to date (K = 128 products).
+// As three launches per step every one of them waited 20-80 us for its first slot beside the trailing update that fills the
+// chip (look-ahead), 3 x n times per panel.  Here the whole panel is one launch whose workgroups take their slots ONCE and
+// hand results to each other through memory:
+//
+//   tickets 0 .. n-1   the block rows of the panel's SQUARE, right-looking: after leaf j row i solves its block (i, j) against
+//                      L_jj (substitution with the inverses of its 16 x 16 diagonal tiles, trsm_sub), publishes
+//                      row_done[i] = j + 1, and subtracts L[i,j] L[k,j]^T from its blocks (i, k), k = j+1 .. i, the one the next
+//                      step needs first; when its own diagonal block is final it runs that block's LEAF (leaf_body.h) and
+//                      publishes leaf_done = i + 1 -- the critical path never changes workgroup between the update of a
+//                      diagonal block and its factorisation;
+//   further tickets    the block rows BELOW the square, left-looking: column k of row r is A[r,k] - L[r,0:k] L[k,0:k]^T in ONE
+//                      product with K = 128 k (it waits for row_done[k] = k only), then the solve against L_kk.
+//
+// Roles are dealt by a start-order ticket, and a workgroup only ever waits for workgroups with a LOWER ticket -- which have
+// started: nothing
+// depends on dispatch order or on all workgroups being resident together.  Every wait is bounded (about 3 s): a workgroup
+// that gives up raises the abort word, everybody leaves, and the host reports an error instead of hanging the GPU.
+//
+// Hand-off form (MI355X_MICROARCH.md, inter-workgroup visibility): payload stored with sc1 (write-through) stores, every
+// storing wave waits vmcnt(0), workgroup barrier, ONE lane stores the flag with sc1; the consumer's lane 0 polls the flag
+// with sc1 loads, workgroup barrier, then every load of handed-off bytes is an sc1 load (buffer loads / LDS-DMA with
+// aux = sc1, which go past the compute unit's L1).  No fences: a release would write back the dirty lines the trailing
+// update keeps producing in the same L2.  Flags are 64-bit tags (launch base + progress), never reset.
+//
+// Resource shape: 512 threads at <= 128 registers and 73 KB of LDS -- what ONE retiring trailing-update workgroup frees, as
+// the leaf kernel -- so a workgroup starts beside a full update.
+#include "leaf_body.h"
+#include <type_traits>
+
+namespace {
+
+struct ChainArgs {
+    double *A; long lda;              // element (J0, J0): origin of the panel
+    int n;                            // 128-column blocks of the panel
+    int rows;                         // 128-row blocks from J0 to the end of the padded matrix (>= n)
+    int nvalid;                       // rows of the matrix proper from J0 on (the rest is identity padding)
+    double *linv;                     // inverses of the panel's diagonal blocks (n x 128 x 128)
+    double *logdet;                   // 1 / L_ii, 128 per block
+    int *info; int info_base;
+    unsigned long long *flags;        // 16 words (one 128-byte line) apart: ticket, leaf_done, abort, diag_ready[32], row_done[32]
+    unsigned long long tick0, tag0;
+    int *yield;
+    int yield_below;                  // the block rows below the square raise their compute unit's yield counter too
+    int leaf_factor, leaf_tiles;      // 1, 1 (run-time values: as constants they change the leaf's code, and its register allocation, for the worse)
+    unsigned long *leaf_stamps;       // diagnostics (option "leaf_stamps"): phase times of the runner's leaves
+    unsigned long long *stamps; int seq;      // diagnostics (option "chain_stamps"): {launch, code, ticket << 16 | row << 8 | step, 100 MHz time} per event
+};
+
+constexpr int FL = 16;                // 64-bit words between two flags
+constexpr int F_TICKET = 0, F_LEAF = 1, F_ABORT = 2, F_ROW = 3;
+constexpr int IMGD = 128 * 16;        // doubles of one operand image (128 rows x 16 k)
+
+__device__ __forceinline__ unsigned long long flag_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flag_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void chain_stamp(const ChainArgs &g, const int code, const int t, const int row, const int step) {
+    if (g.stamps && threadIdx.x == 0) {
+        const unsigned long long i = atomicAdd(g.stamps, 1ull);
+        if (i < (1ull << 20)) {
+            unsigned long long *e = g.stamps + 8 + 4 * i;
+            e[0] = (unsigned long long)g.seq; e[1] = (unsigned long long)code; e[2] = ((unsigned long long)t << 16) | ((unsigned long long)row << 8) | (unsigned long long)step;
+            e[3] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+}
+
+// lane 0 polls until *flag has reached `need`; false when the launch is being abandoned
+__device__ __forceinline__ bool chain_wait(const ChainArgs &g, const int flag, const unsigned long long need, int *s_ok) {
+    if (threadIdx.x == 0) {
+        int ok = 1, it = 0;
+        unsigned long long t0 = 0;
+        const unsigned long long *p = g.flags + (long)flag * FL;
+        while ((long long)(flag_load(p) - need) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++it & 127) == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+                if (t0 == 0) t0 = now;
+                if (now - t0 > 300000000ull || flag_load(g.flags + F_ABORT * FL) == g.tag0) {
+                    flag_store(g.flags + F_ABORT * FL, g.tag0);
+                    atomicCAS(g.info, 0, 0x7fffffff);
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    const int ok = *s_ok;
+    __syncthreads();
+    return ok != 0;
+}
+
+// every store of this workgroup has left, then one lane raises the flag
+__device__ __forceinline__ void chain_publish(const ChainArgs &g, const int flag, const unsigned long long value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) flag_store(g.flags + (long)flag * FL, value);
+}
+
+__device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }
+
+// acc (128 x 128 over eight waves, 2 x 4, 64 x 32 each) = sum_k Aop[row][k] Bop[col][k], k < 16 nk.  Both operands k-minor,
+// row-major; the K loop of the trailing update (gemm.hip): unpadded [128][16] images with XOR-swizzled 16-byte chunks filled
+// by LDS-DMA, lane group q owns k = 4q .. 4q+3 of a step, every address loop-invariant.  All loads sc1.
+// With C given the sum starts at -C (entries above the diagonal of a `lower` block at 0, never read): the caller stores -acc = C - sum.
+__device__ __forceinline__ void product(double4_t (&acc)[4][2], const double *Aop, const long lda, const double *Bop, const long ldb,
+                                        const int nk, double *smem, const double *C = nullptr, const long ldc = 0, const bool lower = false) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                  // opaque: the addressing of one product is not kept alive across the others
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(Aop)), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(Bop)), 0, 0xffffffff, 0x00020000);
+    int voa[2], vob[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = p * 64 + (tid >> 3), kc = ((tid & 7) ^ swz(row)) * 2;
+        voa[p] = (int)(((long)row * lda + kc) * 8);
+        vob[p] = (int)(((long)row * ldb + kc) * 8);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // fragment addresses: ONE register per operand and half-step, everything else (row tile, LDS buffer, operand image) is an
+    // immediate offset of the read
+    const int c0 = (2 * q) ^ swz(r);
+    const int fa0 = (wm * 64 + r) * 16 + 2 * c0, fa1 = (wm * 64 + r) * 16 + 2 * (c0 ^ 1);
+    const int fb0 = IMGD + (wn * 32 + r) * 16 + 2 * c0, fb1 = IMGD + (wn * 32 + r) * 16 + 2 * (c0 ^ 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    if (C) {
+        const double *cb = C + (long)(wm * 64 + q) * ldc + wn * 32 + r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = wm * 64 + i * 16 + q + 4 * v, col = wn * 32 + j * 16 + r;
+                    // (all 32 loads in flight together: a predicated load would wait for the one before it; what lies above
+                    // the diagonal is read and dropped)
+                    const double cv = ld_sc1(cb + (long)(i * 16 + 4 * v) * ldc + j * 16);
+                    acc[i][j][v] = (!lower || col <= row) ? -cv : 0.0;
+                }
+    }
+    auto dma = [&](auto bufc, const int soff) {
+        constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            lds_void *da = (lds_void *)&smem[(BUF * 2 + 0) * IMGD + (p * 64 + wave_u * 8) * 16];
+            lds_void *db = (lds_void *)&smem[(BUF * 2 + 1) * IMGD + (p * 64 + wave_u * 8) * 16];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_src, da, 16, voa[p], soff, 0, 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_src, db, 16, vob[p], soff, 0, 16);
+        }
+    };
+    int soff = 0;
+    auto kstep = [&](auto curc, const bool more) {
+        constexpr int CUR = decltype(curc)::value;
+        if (more) { soff += 128; dma(std::integral_constant<int, CUR ^ 1>{}, soff); }
+        const double *ps = &smem[CUR * 2 * IMGD];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            double2_t a2[4], b2[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a2[i] = *reinterpret_cast<const double2_t *>(ps + (hf ? fa1 : fa0) + i * 256);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b2[j] = *reinterpret_cast<const double2_t *>(ps + (hf ? fb1 : fb0) + j * 256);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i][s], b2[j][s], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next step's image has landed
+        __syncthreads();
+    };
+    dma(std::integral_constant<int, 0>{}, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        kstep(std::integral_constant<int, 0>{}, true);
+        kstep(std::integral_constant<int, 1>{}, kt + 2 < nk);
+    }
+    if (kt < nk) kstep(std::integral_constant<int, 0>{}, false);
+}
+
+template <bool SC1>
+__device__ __forceinline__ void st_out(double *p, double v) {
+    if constexpr (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// C = acc or (NEG) -acc; `lower`: the block is a diagonal block, only entries on / below its diagonal are written (the strict upper
+// triangle of the matrix is nobody's)
+template <bool NEG, bool SC1>
+__device__ __forceinline__ void epilogue(const double4_t (&acc)[4][2], double *C, const long ldc, const bool lower = false) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    double *cb = C + (long)(wm * 64 + q) * ldc + wn * 32 + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = wm * 64 + i * 16 + q + 4 * v, col = wn * 32 + j * 16 + r;
+                if (lower && col > row) continue;
+                st_out<SC1>(cb + (long)(i * 16 + 4 * v) * ldc + j * 16, NEG ? -acc[i][j][v] : acc[i][j][v]);
+            }
+}
+
+// X = A inv(L)^T in place for one 128 x 128 block A, by substitution over the eight 16-column tiles of the lower block L with the
+// inverses of L's diagonal tiles only (what the leaf leaves: `dinv`, 8 x 256 doubles, zeros above the diagonals) -- no
+// 128 x 128 inverse anywhere on the chain.  L's strictly lower tiles and the tile inverses sit in LDS as the leaf's 36 packed
+// tiles; a wave owns 16 rows of A and needs nobody else: X_t^T = inv(L_tt) (A_t^T - sum_{s<t} L_ts X_s^T), every X_s^T kept in
+// registers in the MFMA accumulator layout, which IS the next product's B operand.  The sixteen columns of a tile are dealt to
+// the accumulator rows by c = 4 (i mod 4) + i div 4, so that a lane holds four CONSECUTIVE columns of its row: A is read and X
+// written in 32-byte pieces, L's fragments are 16-byte LDS reads.
+template <bool SC1_STORE>
+__device__ __forceinline__ void trsm_sub(double *Ablk, const long lda, const double *L, const long ldl, const double *dinv, double *sT) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // this wave's rows of A: all sixteen 16-byte loads of a lane go out before anything else
+    const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(Ablk + (long)wave_u * 16 * lda)), 0, 0xffffffff, 0x00020000);
+    const int vo = (int)(((long)r * lda + 4 * q) * 8);
+    double4_t xt[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(a_src, vo, t * 128, 16);
+        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(a_src, vo, t * 128 + 16, 16);
+        double2_t d0, d1;
+        __builtin_memcpy(&d0, &lo, 16); __builtin_memcpy(&d1, &hi, 16);
+        xt[t] = (double4_t){d0[0], d0[1], d1[0], d1[1]};
+    }
+    {   // L's strictly lower tiles -> packed tiles (rows 16 .. 127; a thread takes one 16-byte piece of two rows per trip)
+        const __amdgpu_buffer_rsrc_t l_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(L)), 0, 0xffffffff, 0x00020000);
+        const int c2 = (tid & 63) * 2, tj = c2 >> 4, rb = tid >> 6;
+#pragma unroll 2
+        for (int it = 0; it < 14; ++it) {
+            const int row = 16 + rb + 8 * it, ti = row >> 4;
+            if (tj < ti) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(l_src, (int)(((long)row * ldl + c2) * 8), 0, 16);
+                *reinterpret_cast<u32x4 *>(&sT[tix(ti, tj) + el(row & 15, c2 & 15)]) = v;
+            }
+        }
+    }
+    {   // the diagonal tiles <- their inverses
+        const __amdgpu_buffer_rsrc_t d_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(dinv)), 0, 0xffffffff, 0x00020000);
+        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(d_src, tid * 32, 0, 16);
+        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(d_src, tid * 32 + 16, 0, 16);
+        const int t = tid >> 6, a = (tid >> 2) & 15, b = (tid & 3) * 4;
+        double *T = &sT[tix(t, t)];
+        *reinterpret_cast<u32x4 *>(&T[el(a, b)]) = lo;
+        *reinterpret_cast<u32x4 *>(&T[el(a, b + 2)]) = hi;
+    }
+    __syncthreads();
+    const int pr = 4 * (r & 3) + (r >> 2);           // the row of a 16 x 16 tile this lane supplies as MFMA row r
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        double4_t a0 = xt[t], a1 = {0.0, 0.0, 0.0, 0.0}, a2 = {0.0, 0.0, 0.0, 0.0}, a3 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < t; ++s) {
+            const double *T = &sT[tix(t, s)];
+            const double2_t l01 = *reinterpret_cast<const double2_t *>(&T[el(pr, 4 * q)]);
+            const double2_t l23 = *reinterpret_cast<const double2_t *>(&T[el(pr, 4 * q + 2)]);
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l01[0], xt[s][0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l01[1], xt[s][1], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l23[0], xt[s][2], a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l23[1], xt[s][3], a3, 0, 0, 0);
+        }
+        const double4_t rr = (a0 + a1) + (a2 + a3);
+        const double *D = &sT[tix(t, t)];
+        const double2_t d01 = *reinterpret_cast<const double2_t *>(&D[el(pr, 4 * q)]);
+        const double2_t d23 = *reinterpret_cast<const double2_t *>(&D[el(pr, 4 * q + 2)]);
+        double4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(d01[0], rr[0], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(d01[1], rr[1], x1, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(d23[0], rr[2], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(d23[1], rr[3], x1, 0, 0, 0);
+        xt[t] = x0 + x1;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        u32x4 lo, hi;
+        const double2_t d0 = {xt[t][0], xt[t][1]}, d1 = {xt[t][2], xt[t][3]};
+        __builtin_memcpy(&lo, &d0, 16); __builtin_memcpy(&hi, &d1, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(lo, a_src, vo, t * 128, SC1_STORE ? 16 : 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, a_src, vo, t * 128 + 16, SC1_STORE ? 16 : 0);
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
+    __shared__ double smem[NT * TSZ + 128];      // the leaf's packed triangle + 1 / L_aa (74,752 B); the products use the first 64 KB
+    __shared__ int s_i[2];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_i[0] = (int)(atomicAdd(g.flags + F_TICKET * FL, 1ull) - g.tick0);
+    __syncthreads();
+    const int t = s_i[0];
+    const int n = g.n;
+    const unsigned long long tag = g.tag0;
+    chain_stamp(g, 0, t, 0, 0);
+    double4_t acc[4][2];
+
+    if (t < n) {
+        // ---- block row t of the panel's square, right-looking, then the leaf of its own diagonal block (no loop around the
+        //      leaf: inside one the compiler keeps so much alive across it that it spills hundreds of registers) ----
+        const int row = t;
+        double *Ar = g.A + (long)row * 128 * g.lda;
+        int *yslot = nullptr;                      // on the critical path: the co-resident trailing-update workgroup sleeps meanwhile
+        if (row > 0 && g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
+        __builtin_amdgcn_s_setprio(2);
+        for (int j = 0; j < row; ++j) {
+            if (!chain_wait(g, F_LEAF, tag + j + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
+            chain_stamp(g, 3, t, row, j);
+            trsm_sub<true>(Ar + j * 128, g.lda, g.A + (long)j * 128 * g.lda + j * 128, g.lda, g.linv + (long)j * LEAF_DOUBLES, smem);
+            chain_publish(g, F_ROW + row, tag + j + 1);
+            chain_stamp(g, 4, t, row, j);
+            for (int k = (row == j + 1 ? row : j + 1); k <= row; ++k) {
+                if (k < row && !chain_wait(g, F_ROW + k, tag + j + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
+                product(acc, Ar + j * 128, g.lda, g.A + (long)k * 128 * g.lda + j * 128, g.lda, 8, smem, Ar + k * 128, g.lda, k == row);
+                epilogue<true, true>(acc, Ar + k * 128, g.lda, k == row);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        if (yslot) atomicAdd(yslot, -1);
+        chain_stamp(g, 1, t, row, row);
+        LeafArgs la;
+        la.A = g.A; la.lda = g.lda; la.linv = g.linv; la.logdet_part = g.logdet; la.info = g.info; la.info_base = g.info_base;
+        la.do_factor = g.leaf_factor; la.a_stride = 0; la.linv_stride = 0; la.stamps = g.leaf_stamps; la.tiles_only = g.leaf_tiles; la.yield = g.yield;
+        const int nv = g.nvalid - 128 * row;
+        la.nvalid = nv >= 128 ? 128 : (nv > 0 ? nv : 0);
+        leaf_body<true>(la, Ar + row * 128, g.linv + (long)row * LEAF_DOUBLES, g.logdet + row * 128, g.info_base + 128 * row,
+                        smem, smem + NT * TSZ, tid);
+        chain_publish(g, F_LEAF, tag + row + 1);
+        chain_stamp(g, 2, t, row, row);
+        return;
+    }
+
+    __builtin_amdgcn_s_setprio(2);
+    int *yslot = nullptr;
+    if (g.yield_below && g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
+    const int stride = (int)gridDim.x - n;
+    for (int row = t; row < g.rows; row += stride) {
+        // ---- a block row below the square, left-looking ----
+        double *Ar = g.A + (long)row * 128 * g.lda;
+        for (int k = 0; k < n; ++k) {
+            if (k > 0) {
+                if (!chain_wait(g, F_ROW + k, tag + k, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
+                chain_stamp(g, 6, t, row, k);
+                product(acc, Ar, g.lda, g.A + (long)k * 128 * g.lda, g.lda, 8 * k, smem, Ar + k * 128, g.lda);
+                epilogue<true, false>(acc, Ar + k * 128, g.lda);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            chain_stamp(g, 7, t, row, k);
+            if (!chain_wait(g, F_LEAF, tag + k + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
+            chain_stamp(g, 8, t, row, k);
+            trsm_sub<false>(Ar + k * 128, g.lda, g.A + (long)k * 128 * g.lda + k * 128, g.lda, g.linv + (long)k * LEAF_DOUBLES, smem);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            chain_stamp(g, 9, t, row, k);
+        }
+    }
+    if (yslot) atomicAdd(yslot, -1);
+}
+
+}  // namespace
+
+// One panel [J0, J0 + 128 n) of the padded np x np matrix A, every row from J0 down: factor, solve, update -- one launch.
+int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+    const int64_t w = Jend - J0;
+    if (w <= 0 || w % TILE || J0 % TILE || np % TILE || Jend > np || w / TILE > 32) { fvgp_set_error("panel chain: bad panel"); return -5; }
+    if (lda >= (1L << 21) || (lda & 1) || ((uintptr_t)A & 15)) { fvgp_set_error("panel chain: leading dimension / alignment"); return -4; }
+    if (!h->chain_flags) {
+        HIPCHK(hipMalloc((void **)&h->chain_flags, 80 * 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(h->chain_flags, 0, 80 * 16 * sizeof(unsigned long long)));
+        h->chain_tag = 0; h->chain_tick = 0;
+    }
+    ChainArgs g;
+    g.A = A + J0 * lda + J0; g.lda = (long)lda; g.n = (int)(w / TILE); g.rows = (int)((np - J0) / TILE);
+    g.nvalid = (int)(n_valid - J0 > 0 ? n_valid - J0 : 0);
+    g.linv = h->linv + (J0 / TILE) * LEAF_DOUBLES; g.logdet = h->logdet_parts + J0;
+    g.info = h->dinfo; g.info_base = (int)J0;
+    g.flags = h->chain_flags;
+    h->chain_tag += 64;
+    g.tag0 = h->chain_tag; g.tick0 = h->chain_tick;
+    g.yield = h->leaf_yield ? h->cu_yield : nullptr;
+    g.stamps = h->chain_stamps; g.seq = h->chain_seq++; g.leaf_stamps = h->leaf_stamps; g.leaf_factor = 1; g.leaf_tiles = 1; g.yield_below = h->chain_yield >= 2;
+    int grid = g.rows < 480 ? g.rows : 480;       // one block row per ticket (the first n: the square), the rows below dealt round-robin beyond 480
+    if (grid < g.n) grid = g.n;
+    h->chain_tick += (unsigned long long)grid;
+    hipLaunchKernelGGL(chain_kernel, dim3((unsigned)grid), dim3(512), 0, h->stream, g);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

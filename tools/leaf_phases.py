@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from fvgp_amd import _lib
 H = _lib.Handle(0)
+if len(sys.argv) > 1: H.set_option("panel_chain", int(sys.argv[1]))
+if len(sys.argv) > 2: H.set_option("leaf_tiles", int(sys.argv[2]))
 rng = np.random.default_rng(0)
 B = rng.standard_normal((256, 256)); M = B @ B.T + 256 * np.eye(256)
 A = H.to_device(np.tril(M))

@@ -8,7 +8,7 @@ from collections import defaultdict
 
 def short(name):
     for key in ("kmat_kernel", "leaf_kernel", "fwd_step", "bwd_step", "rhs_rows", "rowsumsq", "rows_to_vec", "pad_identity",
-                "sum_kernel", "copy_cols", "grad_trace", "copy_lower", "kt_alpha", "colsumsq", "panel_kernel", "bwd_sweep"):
+                "sum_kernel", "copy_cols", "grad_trace", "copy_lower", "kt_alpha", "colsumsq", "panel_kernel", "bwd_sweep", "chain_kernel"):
         if key in name:
             return key
     if "gemm_f64_kernel" in name:
