@@ -157,7 +157,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "chain_yield")) { h->chain_yield = (int)value; return 0; }
     if (!strcmp(key, "lookahead_min")) { h->lookahead_min = value; return 0; }
     if (!strcmp(key, "panel_fit")) { h->panel_fit = (int)value; return 0; }
-    if (!strcmp(key, "panel_chain")) { h->panel_chain = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "panel_chain")) { if (value < 0 || value > 2) return -3; h->panel_chain = (int)value; return 0; }
     if (!strcmp(key, "panel_chain_min")) { h->panel_chain_min = value; return 0; }
     if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
@@ -964,7 +964,7 @@ int fvgp_hip_panel_potrf_dev(fvgp_handle *h, double *T, int64_t w, int64_t rows,
     if (rc) return rc;
     h->winv_ok = false; h->linv_L = nullptr;
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
-    if (h->panel_chain) rc = launch_panel_chain(h, T, n_valid, rows, ldt, 0, w);      // one resident kernel for the whole panel (chain.hip)
+    if (h->panel_chain >= 2) rc = launch_panel_chain(h, T, n_valid, rows, ldt, 0, w);   // (the row-sharded driver's stacked panel: measured 3 % slower in the 8-rank emulation, off unless panel_chain = 2)
     else rc = panel_factor_nested(h, T, n_valid, rows, ldt, 0, w);   // leaf / TRSM of every row below / in-panel update per 128 columns, in sub-panels of `inner_block`
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));

@@ -46,6 +46,7 @@ struct ChainArgs {
     unsigned long long tick0, tag0;
     int *yield;
     int yield_below;                  // the block rows below the square raise their compute unit's yield counter too
+    int leaf_preloaded;
     int leaf_factor, leaf_tiles;      // 1, 1 (run-time values: as constants they change the leaf's code, and its register allocation, for the worse)
     unsigned long *leaf_stamps;       // diagnostics (option "leaf_stamps"): phase times of the runner's leaves
     unsigned long long *stamps; int seq;      // diagnostics (option "chain_stamps"): {launch, code, ticket << 16 | row << 8 | step, 100 MHz time} per event
@@ -234,18 +235,16 @@ __device__ __forceinline__ void epilogue(const double4_t (&acc)[4][2], double *C
 // registers in the MFMA accumulator layout, which IS the next product's B operand.  The sixteen columns of a tile are dealt to
 // the accumulator rows by c = 4 (i mod 4) + i div 4, so that a lane holds four CONSECUTIVE columns of its row: A is read and X
 // written in 32-byte pieces, L's fragments are 16-byte LDS reads.
-template <bool SC1_STORE>
-__device__ __forceinline__ void trsm_sub(double *Ablk, const long lda, const double *L, const long ldl, const double *dinv, double *sT) {
+// this wave's sixteen rows of a 128 x 128 block: lane (r, q) takes columns 16 t + 4 q .. + 3 of row r, t = 0 .. 7 (sc1 loads, all
+// sixteen in flight; issued BEFORE the wait for the leaf the solve depends on -- the block itself was final a step earlier)
+__device__ __forceinline__ void trsm_load(double4_t (&xt)[8], const double *Ablk, const long lda) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // this wave's rows of A: all sixteen 16-byte loads of a lane go out before anything else
+    const int lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(Ablk + (long)wave_u * 16 * lda)), 0, 0xffffffff, 0x00020000);
     const int vo = (int)(((long)r * lda + 4 * q) * 8);
-    double4_t xt[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(a_src, vo, t * 128, 16);
@@ -254,16 +253,36 @@ __device__ __forceinline__ void trsm_sub(double *Ablk, const long lda, const dou
         __builtin_memcpy(&d0, &lo, 16); __builtin_memcpy(&d1, &hi, 16);
         xt[t] = (double4_t){d0[0], d0[1], d1[0], d1[1]};
     }
-    {   // L's strictly lower tiles -> packed tiles (rows 16 .. 127; a thread takes one 16-byte piece of two rows per trip)
+}
+
+template <bool SC1_STORE>
+__device__ __forceinline__ void trsm_sub(double4_t (&xt)[8], double *Ablk, const long lda, const double *L, const long ldl, const double *dinv, double *sT) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(Ablk + (long)wave_u * 16 * lda)), 0, 0xffffffff, 0x00020000);
+    const int vo = (int)(((long)r * lda + 4 * q) * 8);
+    {   // L's 28 strictly lower tiles -> packed tiles by LDS-DMA: a wave instruction lands 1 KB = rows 8 u .. 8 u + 7 of one tile
+        // (lane l at 16 l bytes: row 8 u + (l >> 3), position l & 7 of the row's eight 16-byte pieces, which holds piece
+        // (l & 7) ^ ((row >> 1) & 7) of the tile's row: the tiles' own column swizzle); 56 instructions, 7 per wave, all in flight
+        // (as register loads two at a time the block took seven memory round trips)
+        typedef __attribute__((address_space(3))) void lds_void;
         const __amdgpu_buffer_rsrc_t l_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(L)), 0, 0xffffffff, 0x00020000);
-        const int c2 = (tid & 63) * 2, tj = c2 >> 4, rb = tid >> 6;
-#pragma unroll 2
-        for (int it = 0; it < 14; ++it) {
-            const int row = 16 + rb + 8 * it, ti = row >> 4;
-            if (tj < ti) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(l_src, (int)(((long)row * ldl + c2) * 8), 0, 16);
-                *reinterpret_cast<u32x4 *>(&sT[tix(ti, tj) + el(row & 15, c2 & 15)]) = v;
-            }
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int hx = wave_u + 8 * it;                      // half-tile 0 .. 55: strictly lower tile hx >> 1, rows 8 (hx & 1) ..
+            const int p = hx >> 1, u = hx & 1;
+            int ti = 1;
+            while (ti * (ti + 1) / 2 <= p) ++ti;                 // strictly lower tiles in row-major order: p = ti (ti - 1) / 2 + tj
+            const int tj = p - ti * (ti - 1) / 2;
+            const int a = 8 * u + (lane >> 3);
+            const int piece = (lane & 7) ^ ((a >> 1) & 7);
+            const int voff = (int)(((long)(16 * ti + a) * ldl + 16 * tj + 2 * piece) * 8);
+            lds_void *dst = (lds_void *)&sT[tix(ti, tj) + 8 * u * 16];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(l_src, dst, 16, voff, 0, 0, 16);
         }
     }
     {   // the diagonal tiles <- their inverses
@@ -275,6 +294,7 @@ __device__ __forceinline__ void trsm_sub(double *Ablk, const long lda, const dou
         *reinterpret_cast<u32x4 *>(&T[el(a, b)]) = lo;
         *reinterpret_cast<u32x4 *>(&T[el(a, b + 2)]) = hi;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA'd tiles have landed
     __syncthreads();
     const int pr = 4 * (r & 3) + (r >> 2);           // the row of a 16 x 16 tile this lane supplies as MFMA row r
 #pragma unroll
@@ -311,6 +331,93 @@ __device__ __forceinline__ void trsm_sub(double *Ablk, const long lda, const dou
     }
 }
 
+// D -= X X^T for the 128 x 128 diagonal block D (lower triangle) with X still in the registers trsm_sub left it in, the result
+// written straight into the leaf's packed LDS tiles: the last update of a diagonal block and its factorisation share a
+// workgroup, so the block never goes back to memory in between.  The waves exchange X through LDS in two halves of the k
+// range (a lane's 32 bytes per 16-column tile as it holds them: the accumulator layout of X^T is both MFMA operands of
+// X X^T); the 36 lower 16 x 16 tiles are dealt round-robin to the eight waves.
+// the diagonal block's 16 x 16 tiles this wave will update (diag_fused): 20 eight-byte sc1 loads per lane, all in flight at once and
+// issued before the solved row is published, so that their round trip hides under the publication
+__device__ __forceinline__ void diag_load(double4_t (&res)[5], const double *D, const long ldd) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t d_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(D)), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int p = wave_u + 8 * i;
+        if (p >= NT) p = NT - 1;                                 // (waves 4 .. 7 have four tiles: the fifth load is dropped)
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= p) ++a;
+        const int b = p - a * (a + 1) / 2;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {                            // (above the diagonal: read and dropped)
+            const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(d_src, (int)(((long)(q + 4 * v) * ldd + r) * 8), (int)(((long)(16 * a) * ldd + 16 * b) * 8), 16);
+            double d;
+            __builtin_memcpy(&d, &raw, 8);
+            res[i][v] = -d;
+        }
+    }
+}
+
+__device__ __forceinline__ void diag_fused(const ChainArgs &g, const double4_t (&xt)[8], double4_t (&res)[5], double *smem) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // tile coordinates live in scalar registers
+    int ta[5], tb[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int p = wave_u + 8 * i;
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= p) ++a;
+        ta[i] = a; tb[i] = p - a * (a + 1) / 2;
+    }
+    double2_t *XS = reinterpret_cast<double2_t *>(smem);          // [wave][t' < 4][half of the lane's 32 bytes][lane]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();                                          // the L tiles of the solve / the first half are no longer read
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            XS[((wave_u * 4 + t) * 2 + 0) * 64 + lane] = (double2_t){xt[4 * h + t][0], xt[4 * h + t][1]};
+            XS[((wave_u * 4 + t) * 2 + 1) * 64 + lane] = (double2_t){xt[4 * h + t][2], xt[4 * h + t][3]};
+        }
+        __syncthreads();
+        chain_stamp(g, 10 + h, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (wave_u + 8 * i < NT) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double2_t a01 = XS[((ta[i] * 4 + t) * 2 + 0) * 64 + lane], a23 = XS[((ta[i] * 4 + t) * 2 + 1) * 64 + lane];
+                    const double2_t b01 = XS[((tb[i] * 4 + t) * 2 + 0) * 64 + lane], b23 = XS[((tb[i] * 4 + t) * 2 + 1) * 64 + lane];
+                    res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b01[0], res[i], 0, 0, 0);
+                    res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b01[1], res[i], 0, 0, 0);
+                    res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b23[0], res[i], 0, 0, 0);
+                    res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b23[1], res[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    chain_stamp(g, 12, 0, 0, 0);
+    __syncthreads();                                              // everybody has read the exchange buffer: the tiles may land
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if (wave_u + 8 * i < NT) {
+            double *T = &smem[tix(ta[i], tb[i])];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ii = q + 4 * v;
+                T[el(ii, r)] = (ta[i] == tb[i] && r > ii) ? 0.0 : -res[i][v];
+            }
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
     __shared__ double smem[NT * TSZ + 128];      // the leaf's packed triangle + 1 / L_aa (74,752 B); the products use the first 64 KB
     __shared__ int s_i[2];
@@ -331,13 +438,24 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
         int *yslot = nullptr;                      // on the critical path: the co-resident trailing-update workgroup sleeps meanwhile
         if (row > 0 && g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
         __builtin_amdgcn_s_setprio(2);
+        double4_t xt[8];
         for (int j = 0; j < row; ++j) {
+            trsm_load(xt, Ar + j * 128, g.lda);
             if (!chain_wait(g, F_LEAF, tag + j + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
             chain_stamp(g, 3, t, row, j);
-            trsm_sub<true>(Ar + j * 128, g.lda, g.A + (long)j * 128 * g.lda + j * 128, g.lda, g.linv + (long)j * LEAF_DOUBLES, smem);
+            trsm_sub<true>(xt, Ar + j * 128, g.lda, g.A + (long)j * 128 * g.lda + j * 128, g.lda, g.linv + (long)j * LEAF_DOUBLES, smem);
+            if (j + 1 == row) {                    // the step the next leaf waits for: its diagonal block straight into the leaf's tiles
+                double4_t res[5];
+                diag_load(res, Ar + row * 128, g.lda);
+                chain_publish(g, F_ROW + row, tag + j + 1);
+                chain_stamp(g, 4, t, row, j);
+                diag_fused(g, xt, res, smem);
+                chain_stamp(g, 5, t, row, j);
+                break;
+            }
             chain_publish(g, F_ROW + row, tag + j + 1);
             chain_stamp(g, 4, t, row, j);
-            for (int k = (row == j + 1 ? row : j + 1); k <= row; ++k) {
+            for (int k = j + 1; k <= row; ++k) {
                 if (k < row && !chain_wait(g, F_ROW + k, tag + j + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
                 product(acc, Ar + j * 128, g.lda, g.A + (long)k * 128 * g.lda + j * 128, g.lda, 8, smem, Ar + k * 128, g.lda, k == row);
                 epilogue<true, true>(acc, Ar + k * 128, g.lda, k == row);
@@ -349,7 +467,7 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
         chain_stamp(g, 1, t, row, row);
         LeafArgs la;
         la.A = g.A; la.lda = g.lda; la.linv = g.linv; la.logdet_part = g.logdet; la.info = g.info; la.info_base = g.info_base;
-        la.do_factor = g.leaf_factor; la.a_stride = 0; la.linv_stride = 0; la.stamps = g.leaf_stamps; la.tiles_only = g.leaf_tiles; la.yield = g.yield;
+        la.do_factor = g.leaf_factor; la.a_stride = 0; la.linv_stride = 0; la.stamps = g.leaf_stamps; la.tiles_only = g.leaf_tiles; la.yield = g.yield; la.preloaded = row > 0 ? g.leaf_preloaded : 0;
         const int nv = g.nvalid - 128 * row;
         la.nvalid = nv >= 128 ? 128 : (nv > 0 ? nv : 0);
         leaf_body<true>(la, Ar + row * 128, g.linv + (long)row * LEAF_DOUBLES, g.logdet + row * 128, g.info_base + 128 * row,
@@ -363,6 +481,7 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
     int *yslot = nullptr;
     if (g.yield_below && g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
     const int stride = (int)gridDim.x - n;
+    double4_t xt[8];
     for (int row = t; row < g.rows; row += stride) {
         // ---- a block row below the square, left-looking ----
         double *Ar = g.A + (long)row * 128 * g.lda;
@@ -376,9 +495,10 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
                 __syncthreads();
             }
             chain_stamp(g, 7, t, row, k);
+            trsm_load(xt, Ar + k * 128, g.lda);
             if (!chain_wait(g, F_LEAF, tag + k + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
             chain_stamp(g, 8, t, row, k);
-            trsm_sub<false>(Ar + k * 128, g.lda, g.A + (long)k * 128 * g.lda + k * 128, g.lda, g.linv + (long)k * LEAF_DOUBLES, smem);
+            trsm_sub<false>(xt, Ar + k * 128, g.lda, g.A + (long)k * 128 * g.lda + k * 128, g.lda, g.linv + (long)k * LEAF_DOUBLES, smem);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             chain_stamp(g, 9, t, row, k);
@@ -408,7 +528,7 @@ int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, i
     h->chain_tag += 64;
     g.tag0 = h->chain_tag; g.tick0 = h->chain_tick;
     g.yield = h->leaf_yield ? h->cu_yield : nullptr;
-    g.stamps = h->chain_stamps; g.seq = h->chain_seq++; g.leaf_stamps = h->leaf_stamps; g.leaf_factor = 1; g.leaf_tiles = 1; g.yield_below = h->chain_yield >= 2;
+    g.stamps = h->chain_stamps; g.seq = h->chain_seq++; g.leaf_stamps = h->leaf_stamps; g.leaf_factor = 1; g.leaf_tiles = 1; g.leaf_preloaded = 1; g.yield_below = h->chain_yield >= 2;
     int grid = g.rows < 480 ? g.rows : 480;       // one block row per ticket (the first n: the square), the rows below dealt round-robin beyond 480
     if (grid < g.n) grid = g.n;
     h->chain_tick += (unsigned long long)grid;

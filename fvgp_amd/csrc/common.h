@@ -105,7 +105,7 @@ struct fvgp_handle {
     // the column ticket; option "bwd_sweep"
     double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1;
     // the panel chain as one resident kernel per panel (chain.hip): flag words, the launch tag and ticket bases; option "panel_chain"
-    unsigned long long *chain_flags = nullptr, chain_tag = 0, chain_tick = 0; int panel_chain = 1; int64_t panel_chain_min = 0;
+    unsigned long long *chain_flags = nullptr, chain_tag = 0, chain_tick = 0; int panel_chain = 1; int64_t panel_chain_min = 4096;   // ... for panels with at least this many rows from their first column down (below that the chain runs alone on the chip and the three launches per step are as fast)
     int panel_fit = 0;                // panel boundaries moved by one block column for full last rounds of the trailing update: measured +0.1 ... +1 % (the chain fills the partly empty rounds)
     int64_t lookahead_min = 4608;     // look-ahead from this many (padded) rows on (a stream switch costs ~12 us: N=4000 +5 % with it, N=4800 -2.5 %, N=6000 -5 %)
     int posterior_halves = 1;         // posterior covariance at >= 512 points: two halves of the points side by side on two streams (api.hip)

@@ -23,6 +23,7 @@ struct LeafArgs {
     long a_stride, linv_stride;   // batched mode: block b at A + b*a_stride
     unsigned long *stamps;        // diagnostics: s_memtime at the phase boundaries (nullptr in the product path)
     int tiles_only;               // linv <- the inverses of the eight 16x16 diagonal tiles only (8 x 256 doubles, lower, zeros above)
+    int preloaded;                // chain.hip: the block already sits in the packed LDS tiles (the load phase is skipped)
     int *yield;                   // per-CU counters the trailing update's waves poll (common.h, cu_yield); nullptr: nobody yields
 };
 
@@ -187,6 +188,7 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
 #define FVGP_STAMP() do { if (g.stamps && tid == 0) g.stamps[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
     FVGP_STAMP();
 
+    if (!(CHAIN && g.preloaded))
     // ---- load the lower triangle into packed tiles; strict upper of diagonal tiles <- 0 (kept inline: as a function of its own the
     //      same lines made the kernel spill 463 registers instead of 2) ----------
     {

@@ -303,11 +303,16 @@ def test_potrf_solve_logdet(H, n, outer):
                                    dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=0),
                                    dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles_rows=1024),
                                    dict(outer_block=256, outer_block_big=768, big_threshold=0, inner_block=256, lookahead=1, panel_recursive=0),
-                                   dict(outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0, panel_recursive=0)])
+                                   dict(outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0, panel_recursive=0),
+                                   dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, panel_chain=0),
+                                   dict(outer_block=512, outer_block_big=2048, big_threshold=1000, inner_block=512, lookahead=1, panel_chain=1, panel_chain_min=0),
+                                   dict(outer_block=256, outer_block_big=1024, big_threshold=24576, inner_block=512, lookahead=0, panel_chain=1, panel_chain_min=0, outer_block_small=128, small_threshold=1024)])
 def test_potrf_panel_schedules_agree(H, sched):
     """Every panel schedule (regular / wide panels, sub-panels of a third block size, with and without look-ahead; the
     chain's TRSM by the inverted 128-block, by substitution with the 16 x 16 tile inverses, or switching between the two
-    on the way down; panels by recursive halving (the default) or by 128-column steps inside sub-panels) is the same factorisation: compare with LAPACK on one matrix.  The third from last is the default."""
+    on the way down; panels by recursive halving (the default) or by 128-column steps inside sub-panels; the chain as three launches
+    per 128 columns or as ONE resident kernel per panel, chain.hip, for panels of 128 ... 2048 columns) is the same factorisation:
+    compare with LAPACK on one matrix."""
     from fvgp_amd._lib import pad128
     n = 3000
     M = _spd(n, 17)
@@ -332,7 +337,8 @@ def test_potrf_panel_schedules_agree(H, sched):
         assert np.max(np.abs(B.cpu().numpy()[:n, 0] - want)) / np.max(np.abs(want)) < 1e-9
     finally:
         for k, v in dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=1,
-                         leaf_tiles_rows=8192, panel_recursive=1).items():
+                         leaf_tiles_rows=8192, panel_recursive=1, panel_chain=1, panel_chain_min=4096, outer_block_small=512,
+                         small_threshold=12288).items():
             H.set_option(k, v)
 
 
@@ -475,7 +481,9 @@ def test_loglik_matches_oracle_medium(H):
 def test_scheduling_mechanisms_do_not_change_a_bit(H):
     """N = 9000 (look-ahead on, the chain runs under the trailing update): the cooperative yield of the update's waves to the
     leaf / the chain's K = 128 kernels, and the single-launch backward sweep, only change WHEN things run -- log-likelihood,
-    log-determinant, quadratic form and alpha must come out bit-identical with each of them off."""
+    log-determinant, quadratic form and alpha must come out bit-identical with each of them off.  The first and the last
+    configuration are the same: the resident panel kernel's in-launch hand-offs (chain.hip) give the same bits run after run;
+    with the panel kernel off (the three-launch chain: another order of the same sums) the results agree to rounding."""
     from fvgp_amd import _lib
     n = 9000
     x, y = synth(n, 3)
@@ -497,6 +505,15 @@ def test_scheduling_mechanisms_do_not_change_a_bit(H):
     for o in out[1:]:
         assert o[:3] == out[0][:3]
         assert np.array_equal(o[3], out[0][3])
+    try:
+        H.set_option("panel_chain", 0)
+        ll, logdet, quad, info = H.loglik(0, xd, theta, vd, ymd, KV, alpha)
+        H.sync()
+    finally:
+        H.set_option("panel_chain", 1)
+    assert info == 0
+    assert abs(ll - out[0][0]) <= 1e-12 * abs(ll) and abs(logdet - out[0][1]) <= 1e-12 * abs(logdet)
+    assert np.max(np.abs(alpha[:n, 0].cpu().numpy() - out[0][3])) <= 1e-9 * np.max(np.abs(out[0][3]))
 
 
 # ---- row-sharded building blocks (fvgp_amd/dist.py) ------------------------------------------------

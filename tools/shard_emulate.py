@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--panel", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (repeatable)")
     ap.add_argument("--stamps", action="store_true", help="per-workgroup start / end times of the chain's trsm_tiles launches (one evaluation)")
     args = ap.parse_args()
     import ctypes
@@ -50,6 +51,8 @@ def main():
 
     coll = _lib.Collectives(None, _lib.ALL_GATHER_FN(all_gather), _lib.ALL_REDUCE_FN(all_reduce))
     gp = ShardedGP(x, y, np.full(args.n, 0.01), kernel="rbf_ard", panel=args.panel, rank=args.rank, world=world, ops=ops, collectives=coll)
+    for kv in args.opt:
+        ops.H.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     theta = np.array([1.0, 0.3, 0.3, 0.3])
 
     host = []
