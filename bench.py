@@ -244,19 +244,21 @@ def sharded_main(args, x, y, world, rank, local, dist):
             err = f"the row-sharded evaluation's collectives did not complete within {args.sharded_timeout:.0f} s"
             rep = state["replicas"]
             if rank == 0:
-                if rep is not None:    # the replicas were measured first: a valid weak-scaling line, with what happened to the sharded one
-                    print(json.dumps({"metric": "log_marginal_likelihood_evals_per_sec", "value": rep["value"], "unit": "evals/s",
-                                      "n_gpus": world, "steps": rep["evals_per_gpu"], "warmup": 1, "ms_per_step": rep["ms_per_step"],
-                                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                                      "config": {"workload": f"N={n} d={d} RBF(ARD) log_likelihood(theta): K-assembly+noise, Cholesky, 2 triangular "
-                                                             f"solves, log-det", "n": n, "d": d, "kernel": "rbf_ard",
-                                                 "parallelism": f"{world} independent replicas (one theta stream per GPU)"},
-                                      "sharded_error": err + "; the line reports the replicas measured before it"}), flush=True)
-                else:
-                    print(json.dumps({"metric": "log_marginal_likelihood_evals_per_sec", "value": 0.0, "unit": "evals/s",
-                                      "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
-                                      "scaling": "strong", "error": err}), flush=True)
-            os._exit(0 if rep is not None else 3)      # every rank's watchdog fires: with a line to show the launcher sees a clean exit
+                # the headline of an N > 1 run is ONE evaluation sharded over the ranks: when that did not complete the line says
+                # value 0.0 + error, the replicas measured before it ride along as a side record, and the exit code is non-zero
+                line = {"metric": "log_marginal_likelihood_evals_per_sec", "value": 0.0, "unit": "evals/s",
+                        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                        "config": {"workload": f"N={n} d={d} RBF(ARD) log_likelihood(theta): K-assembly+noise, Cholesky, 2 triangular "
+                                               f"solves, log-det", "n": n, "d": d, "kernel": "rbf_ard",
+                                   "parallelism": f"one evaluation row-sharded over {world} GPUs (block-cyclic 128-row blocks)"},
+                        "error": err}
+                if rep is not None:
+                    line["replicas"] = {"value": rep["value"], "unit": "evals/s", "scaling": "weak", "evals_per_gpu": rep["evals_per_gpu"],
+                                        "ms_per_step": rep["ms_per_step"],
+                                        "parallelism": f"{world} independent replicas (one theta stream per GPU), measured before the sharded attempt"}
+                print(json.dumps(line), flush=True)
+            os._exit(3)                # a hung sharded evaluation is a failed run, whatever else was measured
 
     threading.Thread(target=watchdog, daemon=True).start()
     try:
@@ -515,6 +517,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if sharded_error is not None:
+        # the line above is the replicas record, NOT the sharded headline the launch asked for: the launcher must not read a clean exit
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

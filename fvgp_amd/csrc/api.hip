@@ -65,6 +65,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->side) (void)hipStreamSynchronize(h->side);      // the look-ahead / chain stream may still read the buffers freed below
     for (auto e : h->ev) (void)hipEventDestroy(e);
     if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
     for (auto e : h->ev_stage) if (e) (void)hipEventDestroy(e);

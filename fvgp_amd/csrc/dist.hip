@@ -73,7 +73,8 @@ int timed_collective(fvgp_handle *h, int kind, double bytes, hipStream_t stream,
         fvgp_set_error("no collectives bound to this handle: call fvgp_hip_comm_init first"); return 2003;
     }
     fvgp_handle::CollRec rec{kind, bytes, nullptr, nullptr};
-    if (h->profile) {
+    const bool timed = h->profile && h->coll_rec.size() < 65536;      // a caller that never polls fvgp_hip_comm_profile stops collecting events there
+    if (timed) {
         for (hipEvent_t *e : {&rec.e0, &rec.e1}) {
             if (!h->coll_ev_pool.empty()) { *e = h->coll_ev_pool.back(); h->coll_ev_pool.pop_back(); }
             else HIPCHK(hipEventCreate(e));
@@ -82,7 +83,7 @@ int timed_collective(fvgp_handle *h, int kind, double bytes, hipStream_t stream,
     }
     const int rc = kind == 0 ? h->coll.all_gather(h->coll.ctx, send, buf, count, stream) : h->coll.all_reduce_sum(h->coll.ctx, buf, count, stream);
     if (rc) return rc;
-    if (h->profile) { HIPCHK(hipEventRecord(rec.e1, stream)); h->coll_rec.push_back(rec); }
+    if (timed) { HIPCHK(hipEventRecord(rec.e1, stream)); h->coll_rec.push_back(rec); }
     return 0;
 }
 
@@ -160,6 +161,8 @@ int fvgp_hip_comm_unique_id(void *out128_host) {
 
 int fvgp_hip_comm_destroy(fvgp_handle *h) {
     if (!h) return -1;
+    if (h->side) (void)hipStreamSynchronize(h->side);         // the chain stream issues the collectives: it must be done with the communicator
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->rccl_comm) { (void)g_rccl.CommDestroy((ncclComm_t)h->rccl_comm); h->rccl_comm = nullptr; }
     h->coll = fvgp_collectives{nullptr, nullptr, nullptr};
     h->coll_rank = 0; h->coll_nranks = 1;
@@ -258,6 +261,12 @@ int fvgp_hip_loglik_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *
     HIPCHK(hipSetDevice(h->device));
     int rc = fvgp_ensure_side(h); if (rc) return rc;
     const fvgp_dist::Geom g = fvgp_dist::geometry(*d);
+    // everything that can be refused is refused BEFORE the first launch: a rank that returned early from the middle of the
+    // factorisation would leave its peers blocked in an all-gather
+    if (g.npan > 2048) { fvgp_set_error("loglik_dist: more than 2048 panels"); return -2; }
+    if (d->nranks > 1 && (!h->coll.all_gather || !h->coll.all_reduce_sum)) {
+        fvgp_set_error("no collectives bound to this handle: call fvgp_hip_comm_init first"); return 2003;
+    }
     HipBackend b{h, h->stream, h->side};
     HIPCHK(hipMemsetAsync(d->info_dev, 0, (size_t)g.npan * sizeof(int), b.mainS));
     HIPCHK(hipMemsetAsync(d->logdet_dev, 0, (size_t)g.npan * sizeof(double), b.mainS));
@@ -267,7 +276,6 @@ int fvgp_hip_loglik_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *
     // scalars: |z|^2 over the appended rows, the per-panel log-dets, the per-panel info -- one host round trip
     rc = launch_rowsumsq(h, d->A, g.ld, g.zrow, d->ncol, g.n, h->red + 1); if (rc) return rc;
     rc = launch_sum(h, d->logdet_dev, g.npan, h->red); if (rc) return rc;
-    if (g.npan > 2048) { fvgp_set_error("loglik_dist: more than 2048 panels"); return -2; }
     int *hinfo = reinterpret_cast<int *>(h->hpin + 1024);
     HIPCHK(hipMemcpyAsync(hinfo, d->info_dev, (size_t)g.npan * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     double r[2];

@@ -113,6 +113,9 @@ static int chain(B &b, const fvgp_dist_desc &d, const Geom &g, int J, const doub
     }
     // 2. this rank's rows at / below the panel, compact
     rc = b.copy2d(low, w, A + L0 * T128 * g.ld + J0, g.ld, kt, w); if (rc) return rc;
+    // (a panel narrower than P blocks: on some ranks the uniform first block L0 lies ABOVE the panel, rows whose entries in these
+    // columns were never assembled -- nobody reads what the solve makes of them, but they are solved and gathered: zeros, not stale memory)
+    if (la > L0) { rc = b.zero(low, (la - L0) * T128 * w); if (rc) return rc; }
     // 3. factor the tall panel
     rc = b.panel_potrf(T, w, w + kt, w, n_valid, info, ld); if (rc) return rc;
     // 4. the factored diagonal block stays replicated for the later solves

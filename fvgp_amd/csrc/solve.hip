@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const double *L, long ldl
 // is the one form that needs neither fence nor flag (MI355X_MICROARCH.md, inter-workgroup visibility, "granule"): every
 // published double travels as ONE naturally aligned 16-byte {value, tag} written by one sc1 (write-through) store and polled by
 // sc1 loads until its tag is this launch's -- a stale line shows an old tag and is read again, so nothing depends on when
-// another compute unit's caches notice the store.  The tag is a per-handle launch counter, never reused.  Columns are handed out
+// another compute unit's caches notice the store.  The tag is a per-handle launch counter, never reused; the stored word is the
+// tag XOR a hash of the value, so a granule whose halves come from two different stores does not pass either.  Columns are handed out
 // by a ticket in the order the workgroups start (c = nb - 1 - ticket), so a workgroup only ever waits for workgroups that started
 // before it: no assumption on the dispatch order, no need for the whole grid to be resident.  Every sum is formed in the order
 // the step kernels use (four row quarters of a block, ((0+1)+(2+3)); two halves of the inverse), so the results are
@@ -235,7 +236,10 @@ __global__ __launch_bounds__(256) void bwd_sweep_kernel(BwdSweepArgs g) {      /
             int spins = 0;
             for (;;) {
                 v = __builtin_amdgcn_raw_buffer_load_b128(gsrc, off, 0, 16);          // sc1: served past this CU's L1
-                const unsigned long long t = (unsigned long long)v[2] | ((unsigned long long)v[3] << 32);
+                // the second word is tag ^ mix(value bits): a granule torn between its 8-byte halves (new tag beside a stale value, or
+                // the other way round; never observed on gfx950, not promised by the ISA either) decodes to a wrong tag and is read again
+                const unsigned long long vb = (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
+                const unsigned long long t = ((unsigned long long)v[2] | ((unsigned long long)v[3] << 32)) ^ (vb * 0x9E3779B97F4A7C15ull);
                 if (t == g.tag) break;
                 if (++spins > (1 << 22)) { s_fail = 1; break; }
                 // only the workgroup right behind the frontier is waited for: the further left, the rarer the polls (every
@@ -284,7 +288,8 @@ __global__ __launch_bounds__(256) void bwd_sweep_kernel(BwdSweepArgs g) {      /
         const double xv = s_fail ? __builtin_nan("") : sxv[0][tid] + sxv[1][tid];
         unsigned long long bits;
         __builtin_memcpy(&bits, &xv, 8);
-        const u32x4 v = {(unsigned)bits, (unsigned)(bits >> 32), (unsigned)g.tag, (unsigned)(g.tag >> 32)};
+        const unsigned long long tw = g.tag ^ (bits * 0x9E3779B97F4A7C15ull);        // tag and value vouch for each other (torn granules)
+        const u32x4 v = {(unsigned)bits, (unsigned)(bits >> 32), (unsigned)tw, (unsigned)(tw >> 32)};
         __builtin_amdgcn_raw_buffer_store_b128(v, gsrc, (int)(((long)c * 128 + tid) * 16), 0, 16);      // one sc1 store per granule
         g.X[((long)c * 128 + tid) * g.ldx] = xv;
     }

@@ -479,6 +479,8 @@ class GP(ValidationMixin):
         """tril of the device factor (what np.tril(kv.Chol_factor) is in the reference)."""
         if self._sharded:
             return self._sh.factor_matrix()                                # gathered on request, replicated
+        if self._linalg_callables is not None:
+            return None                                                    # gp_kv.py:123: never set when linalg_mode is three callables
         self._H.sync()
         n = self.point_number
         return np.tril(self._L[:n, :n].cpu().numpy())
@@ -508,6 +510,13 @@ class GP(ValidationMixin):
     def neg_log_likelihood(self, hyperparameters=None):
         return -self.log_likelihood(hyperparameters=hyperparameters)
 
+    def _check_sharded_gradient(self):
+        """The row-sharded gradient re-evaluates dK/dtheta inside its trace kernel: with a kernel callable there is no device
+        formula, and the reference itself refuses a gradient in its distributed mode (gp_marginal_likelihood.py:240)."""
+        if self._sharded and self._native is None:
+            raise Exception("Can't compute neg_log_likelihood_gradient for a row-sharded GP with a kernel callable "
+                            "(use one of the named kernels, or a gradient-free training method such as 'mcmc' or 'global')")
+
     def neg_log_likelihood_gradient(self, hyperparameters=None, component=0):
         """fvgp/gp.py:1332-1353, gp_marginal_likelihood.py:224-309.
         g_i = 1/2 (tr(KV^-1 dKV_i) - b^T dKV_i b) - dm_i^T b, kernel term dropped where the mean term
@@ -515,6 +524,7 @@ class GP(ValidationMixin):
         the trace kernel, never stored."""
         H, n = self._H, self.point_number
         if self._sharded:
+            self._check_sharded_gradient()
             return self._gradient_sharded(hyperparameters, component)
         KV, aw = self._scratch()
         if self._work2 is None:
@@ -903,8 +913,17 @@ class GP(ValidationMixin):
         P = len(x_pred)
         Pp = _lib.pad128(P)
         k0 = self._cross_dev(x_pred, hps)
-        W = k0.clone()
-        H.potrs(self._L, n, W, Pp)                                   # KV^-1 k
+        if self._linalg_callables is not None:
+            # kv.solve through the user's f_solve on the kept factor object (gp_kv.py:697-698), as the posterior does: the
+            # device buffer holds K + V here, not a Cholesky factor
+            H.sync()
+            kh = k0[:n, :P].cpu().numpy()
+            Wh = np.zeros((self._np, Pp))
+            Wh[:n, :P] = np.asarray(self._linalg_callables[1](self._custom_obj, kh), dtype=np.float64).reshape(kh.shape)
+            W = H.to_device(Wh)
+        else:
+            W = k0.clone()
+            H.potrs(self._L, n, W, Pp)                               # KV^-1 k
         kk0 = self._kk_host(x_pred, hps)
         C = H.empty(Pp, Pp)
         eps = 1e-6
@@ -993,6 +1012,8 @@ class GP(ValidationMixin):
             warnings.warn("MCMC always optimizes the log marginal likelihood; "
                           "the user-defined objective_function is ignored.")
             objective_function = None
+        if not user_objective and method in ("local", "adam", "hgdl"):
+            self._check_sharded_gradient()                                 # up front, on every rank, not in the middle of the optimisation
         if user_objective and objective_function_gradient is None and method in ("local", "hgdl"):
             raise Exception("A gradient (and Hessian) of the objective function must be provided "
                             "for method='local' or method='hgdl'.")

@@ -231,6 +231,15 @@ def test_linalg_mode_callables_and_inv_on_the_facade():
     assert np.max(np.abs(gp.posterior_covariance(fx["x_pred"])["S"] - fx["pS"])) <= 1e-10
     assert calls["s"] >= 3
     np.testing.assert_allclose(gp.neg_log_likelihood_gradient(th), fx["grad"], rtol=1e-8, atol=1e-9 * np.max(np.abs(fx["grad"])))
+    # posterior_covariance_grad solves through f_solve too (the device buffer holds K + V in this mode, not a factor), and there is
+    # no Cholesky factor to hand out (gp_kv.py:123)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gpc = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function="rbf_ard")
+    xs = fx["x_pred"][:5]
+    np.testing.assert_allclose(gp.posterior_covariance_grad(xs, direction=1)["dS/dx"],
+                               gpc.posterior_covariance_grad(xs, direction=1)["dS/dx"], rtol=0, atol=2e-6)
+    assert gp.Chol_factor is None and gpc.Chol_factor is not None
     gp.set_hyperparameters(fx["thetas"][1])
     np.testing.assert_allclose(gp.log_likelihood(), fx["logliks"][1], rtol=1e-10)
     # "Inv": explicit inverse, variance-only fast path
