@@ -30,13 +30,53 @@ struct KArgs {
     double invl[FVGP_MAX_DIM];
 };
 
+// exp(-a) for a >= 0, a streaming kernel's version: Cody-Waite reduction a = n ln2 + r, |r| <= ln2 / 2, a degree-12 polynomial for
+// exp(-r) (max. relative error 2e-17 of the polynomial, below 1 ulp with the rounding of the Horner steps), the scaling by one
+// v_ldexp_f64 (which flushes through the subnormals to 0 by itself: no range checks).  17 fp64 operations, no comparison, no
+// select (the library call carries four of each for arguments that cannot occur here).
+__device__ __forceinline__ double exp_neg(const double a) {
+    const double n = __builtin_rint(a * 1.4426950408889634074);          // a / ln 2
+    double r = fma(n, -6.93147180369123816490e-01, a);                    // ln2 in two pieces: r = a - n ln2, exact product
+    r = fma(n, -1.90821492927058770002e-10, r);
+    const double x = -r;
+    double p = 2.08767569878680989792e-09;                                // 1 / 12!
+    p = fma(p, x, 2.50521083854417187751e-08);
+    p = fma(p, x, 2.75573192239858906526e-07);
+    p = fma(p, x, 2.75573192239858906526e-06);
+    p = fma(p, x, 2.48015873015873015873e-05);
+    p = fma(p, x, 1.98412698412698412698e-04);
+    p = fma(p, x, 1.38888888888888888889e-03);
+    p = fma(p, x, 8.33333333333333333333e-03);
+    p = fma(p, x, 4.16666666666666666667e-02);
+    p = fma(p, x, 1.66666666666666666667e-01);
+    p = fma(p, x, 0.5);
+    p = fma(p, x, 1.0);
+    p = fma(p, x, 1.0);
+    return __builtin_ldexp(p, -(int)n);
+}
+
+// sqrt(x) for x >= 0 from the hardware reciprocal square root: one coupled Newton (Goldschmidt) step on g ~ sqrt(x), h ~ 1 / (2 sqrt(x))
+// and one correction of g (the library's sqrt rescales for subnormal arguments, classifies its input and corrects twice: squared
+// scaled distances need none of it).  x is first raised to 1e-300, so the diagonal (x = 0) gives 1e-150, which every radial function
+// here maps to the same bits as 0.
+__device__ __forceinline__ double sqrt_pos(const double x0) {
+    const double x = __builtin_fmax(x0, 1e-300);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+
 template <int KIND>
-__device__ inline double radial(double r2, double sig) {
-    if (KIND == 0) return sig * exp(-0.5 * r2);
-    const double r = sqrt(r2);
-    if (KIND == 1) { const double a = SQRT3 * r; return sig * (1.0 + a) * exp(-a); }
+__device__ __forceinline__ double radial(double r2, double sig) {
+    if (KIND == 0) return sig * exp_neg(0.5 * r2);
+    const double r = sqrt_pos(r2);
+    if (KIND == 1) { const double a = SQRT3 * r; return sig * (1.0 + a) * exp_neg(a); }
     const double a = SQRT5 * r;
-    return sig * (1.0 + a + (5.0 / 3.0) * r2) * exp(-a);
+    return sig * fma(5.0 / 3.0, r2, 1.0 + a) * exp_neg(a);
 }
 
 template <int KIND, int D>   // D == 0: runtime dimension (<= FVGP_MAX_DIM)
@@ -69,6 +109,32 @@ __global__ __launch_bounds__(256) void kmat_kernel(KArgs a) {
     __syncthreads();
 
     const bool ok0 = c0 < a.n2, ok1 = c1 < a.n2;
+    // interior tiles (every row and column a real point, no diagonal entry): nothing but distance, radial function, store --
+    // the per-entry tests for padding, identity and the noise on the diagonal cost a third of the instructions of an entry
+    if (row0 + 128 <= a.n1 && col0 + 128 <= a.n2 && a.vec_ok && !(ti == tj && (a.vdiag != nullptr || a.pad == 1)) && row0 != col0) {
+        double *dst = a.K + (row0 + wave) * a.ldk + c0;
+        const long step = 4 * a.ldk;
+        for (int rb = wave; rb < 128; rb += 8, dst += 2 * step) {
+            double v[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int rr = rb + 4 * u;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < DD; ++k) {
+                    if (k < d) {
+                        const double xr = sx[rr * DD + k];
+                        const double e0 = (xr - u0[k]) * il[k], e1 = (xr - u1[k]) * il[k];
+                        s0 = fma(e0, e0, s0); s1 = fma(e1, e1, s1);
+                    }
+                }
+                v[u][0] = radial<KIND>(s0, a.sig); v[u][1] = radial<KIND>(s1, a.sig);
+            }
+            __builtin_nontemporal_store((double2_t){v[0][0], v[0][1]}, reinterpret_cast<double2_t *>(dst));
+            __builtin_nontemporal_store((double2_t){v[1][0], v[1][1]}, reinterpret_cast<double2_t *>(dst + step));
+        }
+        return;
+    }
     // two rows per trip: the second row's exp chain fills the latency of the first, and the stores go out
     // non-temporal (the matrix is written once and next read by another kernel: no reason to keep it in L2)
     for (int rb = wave; rb < 128; rb += 8) {
@@ -131,7 +197,17 @@ struct GArgs {
     long wcol0;               //   matrix column wcol0); grid = (tile rows, ntj)
 };
 
+// phi and the common factor cf such that dK/dl_k = cf * e2[k] * invl[k]  (e2 = D^2 / l^2), one exp and one square root per entry
 template <int KIND>
+__device__ __forceinline__ void radial_grad(const double r2, const double sig, double &phi, double &cf) {
+    if (KIND == 0) { phi = exp_neg(0.5 * r2); cf = sig * phi; return; }
+    const double r = sqrt_pos(r2);
+    if (KIND == 1) { const double ea = exp_neg(SQRT3 * r); phi = fma(SQRT3, r, 1.0) * ea; cf = 3.0 * sig * ea; return; }
+    const double ea = exp_neg(SQRT5 * r), t = fma(SQRT5, r, 1.0);
+    phi = fma(5.0 / 3.0, r2, t) * ea; cf = (5.0 / 3.0) * sig * t * ea;
+}
+
+template <int KIND, int D>   // D == 0: runtime dimension (<= FVGP_MAX_DIM); a 16-deep predicated loop per entry made d = 3 run at a tenth of the memory rate
 __global__ __launch_bounds__(256) void grad_trace_kernel(GArgs a) {
     int ti, tj;
     long pidx = blockIdx.x;
@@ -150,8 +226,8 @@ __global__ __launch_bounds__(256) void grad_trace_kernel(GArgs a) {
         tj = (int)(t - (long)ti * (ti + 1) / 2);
     }
 
-    constexpr int DD = FVGP_MAX_DIM;
-    const int d = a.d;
+    constexpr int DD = D ? D : FVGP_MAX_DIM;
+    const int d = D ? D : a.d;
     __shared__ double sx[128 * DD];
     __shared__ double sb[128];
     __shared__ double sred[4][DD + 1];
@@ -175,40 +251,56 @@ __global__ __launch_bounds__(256) void grad_trace_kernel(GArgs a) {
     __syncthreads();
 
     double gs = 0.0;          // d/dsig accumulator
-    double gl[DD];            // d/dl_k accumulators
+    double gl[DD];            // d/dl_k accumulators, WITHOUT the factor 1 / l_k (applied once at the end)
 #pragma unroll
     for (int k = 0; k < DD; ++k) gl[k] = 0.0;
 
-    for (int rr = wave; rr < 128; rr += 4) {
-        const long row = row0 + rr;
-        if (row >= a.n) break;
-        const double2_t w2 = *reinterpret_cast<const double2_t *>(a.W + row * a.ldw + (c0 - a.wcol0));
-        const double br = sb[rr];
+    // one entry: weight wt (0 for entries that do not count), row point rr, column point h
+    auto entry = [&](const int rr, const int h, const double wt) {
+        double e2[DD];
+        double r2 = 0.0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const long c = h ? c1 : c0;
-            if (c > row || c >= a.n) continue;
-            const double wt = (c == row ? 1.0 : 2.0) * ((h ? w2[1] : w2[0]) - br * (h ? bc1 : bc0));
-            double e2[DD];
-            double r2 = 0.0;
+        for (int k = 0; k < DD; ++k) {
+            if (k < d) {
+                const double e = (sx[rr * DD + k] - (h ? u1[k] : u0[k])) * il[k];
+                e2[k] = e * e; r2 += e2[k];
+            } else e2[k] = 0.0;
+        }
+        double phi, cf;
+        radial_grad<KIND>(r2, a.sig, phi, cf);
+        gs = fma(wt, phi, gs);
+        const double wc = wt * cf;
 #pragma unroll
-            for (int k = 0; k < DD; ++k) {
-                if (k < d) {
-                    const double e = (sx[rr * DD + k] - (h ? u1[k] : u0[k])) * il[k];
-                    e2[k] = e * e; r2 += e2[k];
-                } else e2[k] = 0.0;
+        for (int k = 0; k < DD; ++k) if (k < d) gl[k] = fma(wc, e2[k], gl[k]);
+    };
+    const double *Wp = a.W + (row0 + wave) * a.ldw + (c0 - a.wcol0);
+    if (row0 + 128 <= a.n && ti != tj) {
+        // interior tile strictly below the diagonal: every entry counts twice, two rows per trip (their loads of W and their
+        // exp / rsq chains interleave)
+        for (int rr = wave; rr < 128; rr += 8, Wp += 8 * a.ldw) {
+            const double2_t wa = *reinterpret_cast<const double2_t *>(Wp), wb = *reinterpret_cast<const double2_t *>(Wp + 4 * a.ldw);
+            const double bra = sb[rr], brb = sb[rr + 4];
+            entry(rr, 0, 2.0 * (wa[0] - bra * bc0));
+            entry(rr, 1, 2.0 * (wa[1] - bra * bc1));
+            entry(rr + 4, 0, 2.0 * (wb[0] - brb * bc0));
+            entry(rr + 4, 1, 2.0 * (wb[1] - brb * bc1));
+        }
+    } else {
+        for (int rr = wave; rr < 128; rr += 4, Wp += 4 * a.ldw) {
+            const long row = row0 + rr;
+            if (row >= a.n) break;
+            const double2_t w2 = *reinterpret_cast<const double2_t *>(Wp);
+            const double br = sb[rr];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long c = h ? c1 : c0;
+                if (c > row || c >= a.n) continue;
+                entry(rr, h, (c == row ? 1.0 : 2.0) * ((h ? w2[1] : w2[0]) - br * (h ? bc1 : bc0)));
             }
-            // phi and the common factor c such that dK/dl_k = cf * e2[k] * invl[k]  (e2 = D^2/l^2)
-            double phi, cf;
-            if (KIND == 0) { phi = exp(-0.5 * r2); cf = a.sig * phi; }
-            else if (KIND == 1) { const double r = sqrt(r2), ea = exp(-SQRT3 * r); phi = (1.0 + SQRT3 * r) * ea; cf = 3.0 * a.sig * ea; }
-            else { const double r = sqrt(r2), ea = exp(-SQRT5 * r); phi = (1.0 + SQRT5 * r + (5.0 / 3.0) * r2) * ea; cf = (5.0 / 3.0) * a.sig * (1.0 + SQRT5 * r) * ea; }
-            gs = fma(wt, phi, gs);
-            const double wc = wt * cf;
-#pragma unroll
-            for (int k = 0; k < DD; ++k) if (k < d) gl[k] = fma(wc, e2[k] * il[k], gl[k]);
         }
     }
+#pragma unroll
+    for (int k = 0; k < DD; ++k) gl[k] *= il[k];
     // wave reduce then block reduce
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -298,11 +390,22 @@ int launch_grad_trace(fvgp_handle *h, const GradDesc &g, int *nblocks_out) {
         nb = T * a.ntj;
     }
     *nblocks_out = (int)nb;
-    switch (g.k.kind) {
-        case 0: hipLaunchKernelGGL((grad_trace_kernel<0>), grid, block, 0, h->stream, a); break;
-        case 1: hipLaunchKernelGGL((grad_trace_kernel<1>), grid, block, 0, h->stream, a); break;
-        default: hipLaunchKernelGGL((grad_trace_kernel<2>), grid, block, 0, h->stream, a); break;
+#define GT(KIND, D) hipLaunchKernelGGL((grad_trace_kernel<KIND, D>), grid, block, 0, h->stream, a)
+#define GTD(KIND)                                   \
+    switch (a.d) {                                  \
+        case 1: GT(KIND, 1); break;                 \
+        case 2: GT(KIND, 2); break;                 \
+        case 3: GT(KIND, 3); break;                 \
+        case 4: GT(KIND, 4); break;                 \
+        default: GT(KIND, 0); break;                \
     }
+    switch (g.k.kind) {
+        case 0: GTD(0); break;
+        case 1: GTD(1); break;
+        default: GTD(2); break;
+    }
+#undef GTD
+#undef GT
     HIPCHK(hipGetLastError());
     return 0;
 }
