@@ -33,8 +33,8 @@ int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred) {
         const int64_t cand[3] = {np * 256 + 1024, (1 + want) * pp * 1024 + 64, swant * pp * pp + 64};
         for (int64_t c : cand) if (c > vec) vec = c;
     }
-    // + the per-CU yield counters, the chain's ticket ring, the backward sweep's granules (16 bytes per row) and ticket
-    const int64_t round3 = (int64_t)CU_YIELD_KEYS * CU_YIELD_STRIDE * (int64_t)sizeof(int) + 2 * 256 * (int64_t)sizeof(int) + np * 16 + 2 * (int64_t)sizeof(int);
+    // + the per-CU yield counters, the backward sweep's granules (16 bytes per row) and ticket, the resident panel kernel's flag words
+    const int64_t round3 = (int64_t)CU_YIELD_KEYS * CU_YIELD_STRIDE * (int64_t)sizeof(int) + np * 16 + 2 * (int64_t)sizeof(int) + 80 * 16 * (int64_t)sizeof(unsigned long long);
     return (nblk * LEAF_DOUBLES + nblk * TILE + (npred > 0 ? vec : np * 8) + winv + RED_SLOTS) * (int64_t)sizeof(double) + (int64_t)sizeof(int) + round3;
 }
 
@@ -53,8 +53,6 @@ int fvgp_hip_create(fvgp_handle **out, int device, void *stream) {
     HIPCHK(hipMalloc((void **)&h->dinfo, 64));
     HIPCHK(hipMalloc((void **)&h->cu_yield, (size_t)CU_YIELD_KEYS * CU_YIELD_STRIDE * sizeof(int)));
     HIPCHK(hipMemset(h->cu_yield, 0, (size_t)CU_YIELD_KEYS * CU_YIELD_STRIDE * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&h->chain_tickets, 2 * 256 * sizeof(int)));
-    HIPCHK(hipMemset(h->chain_tickets, 0, 2 * 256 * sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&h->hpin, RED_SLOTS * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     *out = h;
@@ -71,7 +69,6 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     for (auto e : h->ev_stage) if (e) (void)hipEventDestroy(e);
     for (auto e : h->rs_ev) (void)hipEventDestroy(e);
     if (h->ev_cols) (void)hipEventDestroy(h->ev_cols);
-    for (int i = 0; i < 2; ++i) { if (h->ev_pan2[i]) (void)hipEventDestroy(h->ev_pan2[i]); if (h->ev_big2[i]) (void)hipEventDestroy(h->ev_big2[i]); }
     gemm_release_tables(h);
     (void)fvgp_hip_comm_destroy(h);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -83,10 +80,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     if (h->cu_yield) (void)hipFree(h->cu_yield);
     if (h->sweep_gran) (void)hipFree(h->sweep_gran);
     if (h->sweep_ticket) (void)hipFree(h->sweep_ticket);
-    if (h->chain_tickets) (void)hipFree(h->chain_tickets);
     if (h->chain_flags) (void)hipFree(h->chain_flags);
-    if (h->panel_w) (void)hipFree(h->panel_w);
-    if (h->panel_ws) (void)hipFree(h->panel_ws);
     if (h->vec) (void)hipFree(h->vec);
     if (h->hpin) (void)hipHostFree(h->hpin);
     delete h;
@@ -136,8 +130,6 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
         h->outer_block_big = value; return 0;
     }
     if (!strcmp(key, "big_threshold")) { h->big_threshold = value; return 0; }
-    if (!strcmp(key, "gemm_probe")) { h->gemm_probe = (int)value; return 0; }
-    if (!strcmp(key, "gemm_direct")) { h->gemm_direct = (int)value; return 0; }
     if (!strcmp(key, "tile_tables")) { h->tile_tables = value ? 1 : 0; return 0; }
     if (!strcmp(key, "chain_stamps")) { h->chain_stamps = reinterpret_cast<unsigned long long *>((uintptr_t)value); h->chain_seq = 0; return 0; }
     if (!strcmp(key, "leaf_stamps")) { h->leaf_stamps = reinterpret_cast<unsigned long *>((uintptr_t)value); return 0; }
@@ -153,24 +145,15 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "k128_kernels")) { h->k128_kernels = value ? 1 : 0; return 0; }
     if (!strcmp(key, "block_inverses")) { h->block_inverses = value ? 1 : 0; return 0; }
     if (!strcmp(key, "potri_kminor")) { h->potri_kminor = value ? 1 : 0; return 0; }
-    if (!strcmp(key, "update_reserve")) { h->update_reserve = (int)value; return 0; }
     if (!strcmp(key, "leaf_yield")) { h->leaf_yield = (int)value; return 0; }
     if (!strcmp(key, "chain_yield")) { h->chain_yield = (int)value; return 0; }
     if (!strcmp(key, "lookahead_min")) { h->lookahead_min = value; return 0; }
-    if (!strcmp(key, "panel_fit")) { h->panel_fit = (int)value; return 0; }
     if (!strcmp(key, "panel_chain")) { if (value < 0 || value > 2) return -3; h->panel_chain = (int)value; return 0; }
     if (!strcmp(key, "panel_chain_min")) { h->panel_chain_min = value; return 0; }
     if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
-    if (!strcmp(key, "update_atomic_k")) { h->update_atomic_k = value; return 0; }
-    if (!strcmp(key, "chain_loop")) { if (value < 0) return -3; h->chain_loop = (int)value; return 0; }
-    if (!strcmp(key, "update_stagger")) { if (value != 0 && value != 2 && value != 4 && value != 8) return -3; h->update_stagger = (int)value; return 0; }
-    if (!strcmp(key, "panel_square")) { h->panel_square = (int)value; return 0; }
-    if (!strcmp(key, "panel_square_rows")) { h->panel_square_rows = value; return 0; }
     if (!strcmp(key, "outer_block_small")) { if (value < 0 || value % TILE) return -3; h->outer_block_small = value; return 0; }
     if (!strcmp(key, "small_threshold")) { h->small_threshold = value; return 0; }
-    if (!strcmp(key, "overlap_cols")) { h->overlap_cols = value ? 1 : 0; return 0; }
-    if (!strcmp(key, "reserve_rows")) { h->reserve_rows = value; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
     return -2;
 }
@@ -210,10 +193,6 @@ int fvgp_ensure_side(fvgp_handle *h) {
     HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
     HIPCHK(hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_cols, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) {
-        HIPCHK(hipEventCreateWithFlags(&h->ev_pan2[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_big2[i], hipEventDisableTiming));
-    }
     return 0;
 }
 
@@ -382,7 +361,6 @@ static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, i
     s.A = A + c0 * lda + J0; s.lda = lda;
     s.B = A + c0 * lda + J0; s.ldb = lda;
     s.C = A + c0 * lda + c0; s.ldc = lda;
-    if (role == 1 && (h->reserve_rows < 0 || np - c0 <= h->reserve_rows)) s.reserve_cus = h->update_reserve;
     if (big_kernel) *big_kernel = !gemm_takes_small_tiles(h, s);
     return launch_gemm(h, s);
 }
@@ -420,86 +398,11 @@ static int panel_factor_nested(fvgp_handle *h, double *A, int64_t n, int64_t np,
     return 0;
 }
 
-// inverse of ONE w x w diagonal block of L (w = 128 times a power of two) from its 128-block inverses, by the doubling of
-// ensure_winv: W (w x w, row stride w), T scratch of w*w/4 doubles
-static int block_inverse(fvgp_handle *h, const double *Lsq, int64_t ldl, const double *linv0, int64_t w, double *W, double *T) {
-    int rc = launch_winv_seed(h, linv0, w / TILE, W, w); if (rc) return rc;
-    for (int64_t hs = TILE; hs < w; hs *= 2) {
-        const int64_t ny = w / (2 * hs);
-        GemmDesc a{};   // T[y] = C inv(A)
-        a.a_kmajor = 0; a.b_nmajor = 1; a.lower = 0; a.M = hs; a.N = hs; a.K = hs; a.alpha = 1.0; a.beta = 0.0;
-        a.A = Lsq + hs * ldl; a.lda = ldl; a.B = W; a.ldb = w; a.C = T; a.ldc = hs;
-        a.batch_y = (int)ny; a.batch_z = 1;
-        a.a_by = 2 * hs * ldl + 2 * hs; a.b_by = 2 * hs * w + 2 * hs; a.c_by = hs * hs;
-        rc = launch_gemm(h, a); if (rc) return rc;
-        GemmDesc b{};   // W21[y] = -inv(B) T
-        b.a_kmajor = 0; b.b_nmajor = 1; b.lower = 0; b.M = hs; b.N = hs; b.K = hs; b.alpha = -1.0; b.beta = 0.0;
-        b.A = W + hs * w + hs; b.lda = w; b.B = T; b.ldb = hs; b.C = W + hs * w; b.ldc = w;
-        b.batch_y = (int)ny; b.batch_z = 1;
-        b.a_by = 2 * hs * w + 2 * hs; b.b_by = hs * hs; b.c_by = 2 * hs * w + 2 * hs;
-        rc = launch_gemm(h, b); if (rc) return rc;
-    }
-    return 0;
-}
-
-// Square-first panel.  The chain (leaf / TRSM / in-panel update per 128 columns) factors only the panel's w x w diagonal
-// square; the rows below it then follow in ONE product with the explicit inverse of the square,
-//     L[below, panel] = A[below, panel] inv(L_sq)^T       (w x w inverse by doubling from the 128-block inverses),
-// from a compact copy of those rows (a tile of the product reads the columns to its left, so it cannot run in place), on the
-// fast (M,K) x (N,K) loop with the triangular K range k < 128 (tj + 1).  Same flops as the chain's per-step TRSMs and in-panel
-// updates of those rows, in m/128 x w/128 tiles with K up to w instead of 2 w/128 launches of m/32 latency-bound workgroups:
-// under look-ahead every workgroup of the chain waits for a slot one retiring trailing-update tile frees (about two per
-// microsecond), which is what made a panel at 20k rows take 4.6 ms.  Backward error ~ eps cond(L_sq) instead of
-// eps cond(128-block) -- the bound the posterior's and POTRI's 1024-block inverses already work under.
-// the chain's part (the panel's square, its inverse); returns in *square whether the rows below are still to be done by
-// panel_square_below (false: the ordinary chain has factored the whole panel)
-static int panel_square_chain(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend, bool *square) {
-    const int64_t w = Jend - J0, below = np - Jend;
-    bool pow2 = w >= 2 * TILE;
-    for (int64_t t = w / TILE; t > 1; t >>= 1) if (t & 1) pow2 = false;
-    *square = h->panel_square && below > h->panel_square_rows && pow2;
-    if (!*square) return panel_factor_nested(h, A, n, np, lda, J0, Jend);
-    int rc = panel_factor_nested(h, A, n, Jend, lda, J0, Jend);          // the chain, confined to the square
-    if (rc) return rc;
-    const size_t need_w = (size_t)w * w + (size_t)w * w / 4, need_ws = (size_t)below * w;
-    if (need_w > h->panel_w_cap) {
-        HIPCHK(hipDeviceSynchronize());
-        if (h->panel_w) HIPCHK(hipFree(h->panel_w));
-        h->panel_w = nullptr; h->panel_w_cap = 0;
-        HIPCHK(hipMalloc((void **)&h->panel_w, need_w * sizeof(double)));
-        h->panel_w_cap = need_w;
-    }
-    if (need_ws > h->panel_ws_cap) {
-        HIPCHK(hipDeviceSynchronize());
-        if (h->panel_ws) HIPCHK(hipFree(h->panel_ws));
-        h->panel_ws = nullptr; h->panel_ws_cap = 0;
-        HIPCHK(hipMalloc((void **)&h->panel_ws, need_ws * sizeof(double)));
-        h->panel_ws_cap = need_ws;
-    }
-    double *W = h->panel_w, *T = W + (size_t)w * w;
-    const double *linv0 = h->linv + (J0 / TILE) * LEAF_DOUBLES;
-    rc = launch_leaf_inverse_batched(h, A + J0 * lda + J0, lda, w / TILE, const_cast<double *>(linv0)); if (rc) return rc;
-    return block_inverse(h, A + J0 * lda + J0, lda, linv0, w, W, T);
-}
-
-// the rows below the square: L[below, panel] = A[below, panel] inv(L_sq)^T, from a compact copy (a tile reads the columns to its left)
-static int panel_square_below(fvgp_handle *h, double *A, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
-    const int64_t w = Jend - J0, below = np - Jend;
-    double *W = h->panel_w, *P = h->panel_ws;
-    int rc = launch_copy_panel(h, A + Jend * lda + J0, lda, P, w, below, w); if (rc) return rc;
-    GemmDesc t{};
-    t.a_kmajor = 0; t.b_nmajor = 0; t.lower = 0; t.M = below; t.N = w; t.K = w; t.alpha = 1.0; t.beta = 0.0;
-    t.A = P; t.lda = w; t.B = W; t.ldb = w; t.C = A + Jend * lda + J0; t.ldc = lda;
-    t.kb0 = 0; t.ke0 = TILE; t.kej = TILE;                                // W is lower triangular: k < 128 (tj + 1)
-    return launch_gemm(h, t);
-}
-
-static int panel_factor_square(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
-    if (h->panel_chain && np - J0 >= h->panel_chain_min) return launch_panel_chain(h, A, n, np, lda, J0, Jend);      // one resident kernel for the whole panel (chain.hip)
-    bool square = false;
-    int rc = panel_square_chain(h, A, n, np, lda, J0, Jend, &square);
-    if (rc || !square) return rc;
-    return panel_square_below(h, A, np, lda, J0, Jend);
+// one panel, every row from its first column down: the resident panel kernel (chain.hip) while enough rows remain for a
+// trailing update to run beside it, else the three launches per 128 columns
+static int panel_factor_any(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+    if (h->panel_chain && np - J0 >= h->panel_chain_min) return launch_panel_chain(h, A, n, np, lda, J0, Jend);
+    return panel_factor_nested(h, A, n, np, lda, J0, Jend);
 }
 
 static double lower_flops(int64_t M, int64_t N, int64_t K) {     // algorithmic flops of a lower-tile update
@@ -562,20 +465,6 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
         // N=12k -3 %, N=20k +-0 with 512 throughout)
         int64_t w = (h->outer_block_big > NB && np - J0 > h->big_threshold) ? h->outer_block_big : NB;
         if (h->outer_block_small > 0 && h->outer_block_small < w && np - J0 <= h->small_threshold) w = h->outer_block_small;
-        // `panel_fit`: a boundary may move by one block column either way so that the big update it starts -- the lower tiles of
-        // the rows below it, in rounds of 2 x n_cus workgroups of equal length -- ends on a (nearly) full round: T (T + 1) / 2
-        // tiles change by ~T per block column, more than half a round down to T = 256
-        if (h->panel_fit && w >= 4 * TILE && J0 + w + TILE < np && np - (J0 + w) >= 4096) {
-            const int64_t slots = 2 * (int64_t)h->n_cus;
-            int64_t best = w; double best_fill = -1.0;
-            for (int64_t cand = w - TILE; cand <= w + TILE; cand += TILE) {
-                const int64_t T = (np - (J0 + cand)) / TILE, tiles = T * (T + 1) / 2;
-                const int64_t rem = tiles % slots;
-                const double fill = rem == 0 ? 1.0 : (double)rem / (double)slots;
-                if (fill > best_fill + (cand == w ? -1e-9 : 0.05)) { best_fill = fill; best = cand; }     // the nominal width unless another one is clearly better
-            }
-            w = best;
-        }
         J0 = (J0 + w < np) ? J0 + w : np;
     }
     bnd.push_back(np);
@@ -585,36 +474,13 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     const bool la = h->lookahead && npan > 2 && np >= h->lookahead_min;
     if (!la) {
         for (size_t J = 0; J < npan; ++J) {
-            rc = panel_factor_square(h, A, n, np, lda, bnd[J], bnd[J + 1]); if (rc) return rc;
+            rc = panel_factor_any(h, A, n, np, lda, bnd[J], bnd[J + 1]); if (rc) return rc;
             if (np > bnd[J + 1]) { rc = timed_update(bnd[J], bnd[J + 1], bnd[J + 1], np); if (rc) return rc; }
         }
     } else {
         rc = fvgp_ensure_side(h); if (rc) return rc;
         hipStream_t mainS = h->stream, sideS = h->side;
-        rc = panel_factor_square(h, A, n, np, lda, bnd[0], bnd[1]); if (rc) return rc;      // panel 0 on the main stream
-        if (h->overlap_cols && np >= 12288) {      // (measured: N = 8k +2.7 %, N = 20k -1.2 %, N = 50k -0.55 %)
-            // The update of the next panel's columns goes to the side stream too, in front of that panel's chain, and the big
-            // update of the rest starts on the main stream at the same time (they write disjoint columns): the small launch's
-            // last, partly filled round of tiles no longer stands between two big launches (about half a round of 512 tiles per
-            // panel), and the chain's first kernel follows it without a stream switch.
-            HIPCHK(hipEventRecord(h->ev_pan2[0], mainS));
-            for (size_t J = 0; J + 1 < npan; ++J) {
-                const int64_t J0 = bnd[J], Jend = bnd[J + 1], Nend = bnd[J + 2];
-                const int p = (int)(J & 1);
-                HIPCHK(hipStreamWaitEvent(sideS, h->ev_pan2[p], 0));                    // panel J is factored
-                if (J > 0) HIPCHK(hipStreamWaitEvent(sideS, h->ev_big2[p ^ 1], 0));     // the big update J-1 touched these columns
-                h->stream = sideS;
-                rc = timed_update(J0, Jend, Jend, Nend);
-                if (!rc) rc = panel_factor_square(h, A, n, np, lda, Jend, Nend);
-                h->stream = mainS;
-                if (rc) return rc;
-                HIPCHK(hipEventRecord(h->ev_pan2[p ^ 1], sideS));
-                HIPCHK(hipStreamWaitEvent(mainS, h->ev_pan2[p], 0));
-                if (np > Nend) { rc = timed_update(J0, Jend, Nend, np); if (rc) return rc; }
-                HIPCHK(hipEventRecord(h->ev_big2[p], mainS));
-            }
-            HIPCHK(hipStreamWaitEvent(mainS, h->ev_pan2[(npan - 1) & 1], 0));
-        } else
+        rc = panel_factor_any(h, A, n, np, lda, bnd[0], bnd[1]); if (rc) return rc;      // panel 0 on the main stream
         for (size_t J = 0; J + 1 < npan; ++J) {
             const int64_t J0 = bnd[J], Jend = bnd[J + 1], Nend = bnd[J + 2];           // next panel = [Jend, Nend)
             // (1) main: bring the next panel's block columns up to date with panel J
@@ -623,14 +489,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             // (2) side: factor the next panel as soon as (1) is done ...
             HIPCHK(hipStreamWaitEvent(sideS, h->ev_cols, 0));
             h->stream = sideS;
-            h->chain_contended = np - Nend >= 4096;      // the rest of this panel's update runs beside the chain
-            // panel_square == 2: the chain stream only factors the panel's square (small kernels, which start at once beside a
-            // PERSISTENT update: a launch with pending workgroups holds up the dispatch of everybody else's); the one big
-            // product for the rows below follows on the main stream, on the whole chip
-            bool split = false;
-            if (h->panel_square == 2) rc = panel_square_chain(h, A, n, np, lda, Jend, Nend, &split);
-            else rc = panel_factor_square(h, A, n, np, lda, Jend, Nend);
-            h->chain_contended = false;
+            rc = panel_factor_any(h, A, n, np, lda, Jend, Nend);
             h->stream = mainS;
             if (rc) return rc;
             HIPCHK(hipEventRecord(h->ev_panel, sideS));
@@ -638,7 +497,6 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             if (np > Nend) { rc = timed_update(J0, Jend, Nend, np); if (rc) return rc; }
             // the next iteration's updates use panel J+1: wait for its factorisation
             HIPCHK(hipStreamWaitEvent(mainS, h->ev_panel, 0));
-            if (split) { rc = panel_square_below(h, A, np, lda, Jend, Nend); if (rc) return rc; }
         }
     }
     if (h->leaf_tiles || h->panel_chain) {
@@ -1382,7 +1240,6 @@ int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, cons
     g.bc_ranks = b_ranks; g.bc_blocks = b_blocks; g.bc_off = b_off;
     g.M = M; g.N = N; g.K = K; g.alpha = -1.0; g.beta = 1.0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-    if (h->reserve_rows < 0 || M * scale <= h->reserve_rows) g.reserve_cus = h->update_reserve;
     // only launches of the kernel the roofline names are timed, and no more than 8192 of them between two get_profile calls
     if (!h->profile || gemm_takes_small_tiles(h, g) || h->rs_used >= 2 * 8192) return launch_gemm(h, g);
     // timed with events on the launch stream; algorithmic flops = the tiles with tj <= ti * scale + off
@@ -1454,7 +1311,6 @@ int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t
     GemmDesc g{};
     g.a_kmajor = a_kmajor; g.b_nmajor = b_nmajor; g.lower = lower; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-    g.probe = h->gemm_probe;
     return launch_gemm(h, g);
 }
 

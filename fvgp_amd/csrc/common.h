@@ -80,49 +80,29 @@ struct fvgp_handle {
     int64_t outer_block_big = 2048, big_threshold = 24576;   // wider panels while the trailing matrix is large
     int profile = 0;
     int64_t inner_block = 512;        // sub-panel width inside panels wider than this (0 = off)
-    int gemm_direct = 0;              // diagnostics: 1 trailing updates use the LDS-free kernel, 2 every (M,K) x (N,K) product
     int64_t small_tile_max_update = 512;   // trailing updates of at most this many 128-tiles also run on 64-tiles
     int64_t small_tile_max = 160;     // (M,K) x (N,K) products of at most this many 128-tiles and K <= 512 run on 64-tiles
     unsigned long long *chain_stamps = nullptr; int chain_seq = 0;   // diagnostics (option "chain_stamps"): trsm_tiles workgroup start / end times
     unsigned long *leaf_stamps = nullptr;   // diagnostics (option "leaf_stamps" = device pointer): phase timestamps of the leaf kernel
     std::map<TileTabKey, TileTab> tile_tabs;   // device-resident, freed with the handle
     int tile_tables = 1;              // plain launches of the 128-tile kernels take the XCD-balanced tile table instead of the formula map
-    // persistent trailing update: > 0 = the update launches 2 x (n_cus - update_reserve) workgroups that pull tiles from per-XCD
-    // queues, so `update_reserve` compute units' worth of slots stay free for the panel chain for the whole launch
-    int update_reserve = 0, n_cus = 256;
-    int64_t reserve_rows = 0;         // ... applied while at most this many rows remain to be updated (0: never, < 0: always)
-    int *tile_queue = nullptr; unsigned tile_queue_next = 0;
+    int n_cus = 256;
     // cooperative yield: one counter per compute unit (key = XCC id << 8 | HW_ID[15:8], a line of its own each).  A leaf that
     // runs under look-ahead raises its CU's counter; the trailing-update waves of that CU poll it once per K step with a scalar
     // load and sleep while it is up (fp64 MFMA and the vector ALU share a pipe: beside an MFMA stream every dependent instruction
     // of the latency-bound leaf waits for a 64-cycle MFMA -- 3.5 to 6.7 times the standalone time).  Option "leaf_yield".
-    int *cu_yield = nullptr; int leaf_yield = 1, chain_yield = 1;
-    // chunk loops of the chain's many-workgroup kernels under look-ahead (gemm.hip, chain_grid): ring of {ticket, finished} pairs,
-    // `chain_loop` = the 60 of G = sqrt(60 chunks) (0: off), `chain_contended` set by the drivers around a chain that runs under a
-    // trailing update
-    int *chain_tickets = nullptr; unsigned chain_ticket_next = 0; int chain_loop = 0; bool chain_contended = false;   // measured: N=12k +2 %, N=20k +0.8 %, N=50k +-0 with 60 -- off
+    int *cu_yield = nullptr; int leaf_yield = 1, chain_yield = 1;      // chain_yield 2: the resident panel kernel's block rows below the square raise it too
     // backward sweep in one launch (solve.hip, bwd_sweep_kernel): granules of {value, tag}, the launch counter the tags come from,
     // the column ticket; option "bwd_sweep"
     double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1;
     // the panel chain as one resident kernel per panel (chain.hip): flag words, the launch tag and ticket bases; option "panel_chain"
     unsigned long long *chain_flags = nullptr, chain_tag = 0, chain_tick = 0; int panel_chain = 1; int64_t panel_chain_min = 4096;   // ... for panels with at least this many rows from their first column down (below that the chain runs alone on the chip and the three launches per step are as fast)
-    int panel_fit = 0;                // panel boundaries moved by one block column for full last rounds of the trailing update: measured +0.1 ... +1 % (the chain fills the partly empty rounds)
     int64_t lookahead_min = 4608;     // look-ahead from this many (padded) rows on (a stream switch costs ~12 us: N=4000 +5 % with it, N=4800 -2.5 %, N=6000 -5 %)
     int posterior_halves = 1;         // posterior covariance at >= 512 points: two halves of the points side by side on two streams (api.hip)
-    int64_t update_atomic_k = 0;      // trailing updates with K <= this add their tiles with atomics instead of the C read-modify-write
-    int update_stagger = 0;           // phases (0, 2, 4, 8) the first wave of a trailing update's workgroups starts in (gemm.hip)
-    // square-first panels (potrf_driver, panel_factor_square): the inverse of the panel's square + T scratch, and the compact copy of
-    // the rows below it
-    double *panel_w = nullptr; size_t panel_w_cap = 0;
-    double *panel_ws = nullptr; size_t panel_ws_cap = 0;
-    int panel_square = 0; int64_t panel_square_rows = 0;   // measured away: N=8k +30 %, N=20k +2 %, N=50k +0.5 %
     int64_t outer_block_small = 512, small_threshold = 12288;   // panel width for the last `small_threshold` rows (potrf_driver)
-    int gemm_probe = 0;               // fvgp_hip_gemm launches a K-loop timing probe instead (diagnostics)
     int lookahead = 1;
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel
     hipEvent_t ev_panel = nullptr, ev_cols = nullptr;
-    hipEvent_t ev_pan2[2] = {nullptr, nullptr}, ev_big2[2] = {nullptr, nullptr};
-    int overlap_cols = 0;             // option (off: two overlapping update launches blur the per-launch timing the roofline is read from; -0.55 % at N = 50k when on): the next panel's columns are updated on the side stream, beside the big update of the rest
     // profile of the last potrf
     std::vector<hipEvent_t> ev;
     std::vector<double> ev_flops;
@@ -171,9 +151,6 @@ struct GemmDesc {
     // B (b_nmajor = 0 only) as an all-gather leaves it: `bc_ranks` chunks of `bc_blocks` 128-row blocks, chunk q
     // holding the blocks q, q + bc_ranks, ...; output tile column tj reads block tj + bc_off of that cyclic order
     int bc_ranks = 1, bc_blocks = 0, bc_off = 0;
-    int probe = 0;                    // timing probe variant of the K loop (diagnostics only)
-    int reserve_cus = 0;              // role 1: persistent launch that leaves this many compute units' worth of slots free
-    int direct = 0;                   // (M,K) x (N,K) only: operands straight from global memory into MFMA registers (no LDS)
     int rev_m = 0;                    // walk the tile rows from the last to the first (per-tile K grows with ti: longest first)
     // split-K for products with few output tiles and a long K (S -= V^T V of the posterior: 64 tiles, K = N): `split`
     // workgroups per tile, each over K/split, partial tiles into split_ws (split x M x N doubles), then one fixed-order
@@ -253,7 +230,6 @@ int launch_rows_sumsq_base(fvgp_handle *h, const double *KT, int64_t ldk, int64_
 int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M, int64_t N, int lower, const double *C, int64_t ldc, double beta,
                          double *out, int64_t ldo);
 int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W, int64_t w = 1024);
-int launch_copy_panel(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t rows, int64_t cols);
 int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D);
 int launch_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);
 int64_t kt_alpha_scratch_doubles(int64_t n, int64_t P, int ncol);

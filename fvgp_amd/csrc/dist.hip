@@ -130,10 +130,7 @@ struct HipBackend {
         return 0;
     }
     int panel_potrf(double *T, int64_t w, int64_t rows, int64_t ldt, int64_t n_valid, int *info_dev, double *logdet_dev) {
-        h->chain_contended = h->stream == chainS;          // beside the rank's trailing update (look-ahead): gemm.hip, chain_grid
-        const int rc = fvgp_hip_panel_potrf_dev(h, T, w, rows, ldt, n_valid, info_dev, logdet_dev);
-        h->chain_contended = false;
-        return rc;
+        return fvgp_hip_panel_potrf_dev(h, T, w, rows, ldt, n_valid, info_dev, logdet_dev);
     }
     int syrk(int64_t M, int64_t N, int64_t K, const double *A, int64_t lda, const double *Bm, int64_t ldb, double *C, int64_t ldc,
              int scale, int off, int b_ranks, int b_blocks, int b_off) {

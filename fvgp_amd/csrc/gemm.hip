@@ -2,48 +2,35 @@
 //
 // This is the kernel the metric lives in: the trailing update of the blocked Cholesky
 // (dsyrk/dgemm inside LAPACK dpotrf, reached from fvgp/gp_lin_alg.py:245) is
-//     A22 -= L21 * L21^T          (a_kmajor = 0, b_nmajor = 0, lower = 1)
-// and every other level-3 step of the path (TRSM by inverted diagonal blocks, POTRI,
-// posterior cross products) is one of the four operand layouts below.
+//     A22 -= L21 * L21^T          (a_kmajor = 0, b_nmajor = 0, lower = 1, ROLE 1)
+// and every other level-3 step of the path (panel products, POTRI, posterior cross products) is one of the four operand
+// layouts below.
 //
 // Design (CDNA4):
-//   * v_mfma_f64_16x16x4_f64; one 256-thread workgroup = 4 waves in a 2x2 grid, each wave
-//     owns 64x64 of C = 16 MFMA tiles = 64 fp64 accumulators per lane;
-//   * K is walked in steps of 16 through a double-buffered LDS image, global -> registers
-//     -> LDS, one barrier per step (the next step's loads are in flight during the MFMAs);
-//   * LDS images are padded so the ds_read_b64 fragment reads are bank-conflict free:
-//     k-minor operand [128][16+2], m-minor operand [16][128+16];
-//   * 2 workgroups per CU (<=256 VGPR, 72 KiB LDS each) so one workgroup's C read-modify-
-//     write epilogue hides under the other's MFMA stream;
-//   * blockIdx -> tile map walks the lower triangle in 8x8 super-tiles and deals consecutive
-//     super-tiles to the same XCD (blocks b, b+8, .. share an L2), so the row/column slabs
-//     of L21 a super-tile needs are fetched into that XCD's L2 once.
+//   * v_mfma_f64_16x16x4_f64; one 256-thread workgroup = 4 waves in a 2x2 grid, each wave owns 64x64 of C = 16 MFMA tiles =
+//     64 fp64 accumulators per lane; 2 workgroups per CU (<= 228 VGPR, 76 KB LDS each), so one workgroup's C read-modify-write
+//     epilogue hides under the other's MFMA stream;
+//   * K is walked in steps of 16 through a double-buffered LDS image, one barrier per step;
+//   * both operands k-minor ((M,K) x (N,K): the trailing update, every panel product, POTRI, the posterior substitution):
+//     unpadded [128][16] images whose 16-byte chunks are XOR-swizzled per row (bank-conflict free for ds_read_b128's lane
+//     groups), filled by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write), lane group q owns k = 4q .. 4q+3 of a
+//     step (one 16-byte read per fragment pair), all sixteen reads of a step issued before its first MFMA, every address
+//     loop-invariant (buffer descriptors with a constant lane offset and the K position in an SGPR, the loop unrolled over the
+//     two LDS buffers): no vector-ALU instruction in the loop (fp64 MFMA and the VALU share a pipe);
+//   * the other layouts ((K,M) and / or (K,N) operands) keep a plain loop: global -> registers -> LDS, padded images
+//     (k-minor [128][16+2], m-minor [16][128+16]), 8-byte fragment reads;
+//   * ROLE 1 (the trailing update) polls its compute unit's yield counter once per K step with a scalar load and sleeps while a
+//     workgroup of the panel chain runs there (common.h, cu_yield_slot);
+//   * blockIdx -> tile map: 8x8 super-tiles dealt to the XCDs (blocks b, b+8, .. share an L2), either by formula or from an
+//     XCD-balanced tile table built on the host per launch shape.
 #include "common.h"
 #include <cstring>
 #include <type_traits>
 
 namespace {
 
-#ifndef FVGP_GEMM_ATOMIC_DEFAULT
-#define FVGP_GEMM_ATOMIC_DEFAULT 0
-#endif
-#ifndef FVGP_GEMM_DMA_DEFAULT
-#define FVGP_GEMM_DMA_DEFAULT 1
-#endif
-#ifndef FVGP_GEMM_YIELD_DEFAULT
-#define FVGP_GEMM_YIELD_DEFAULT 1
-#endif
-#ifndef FVGP_GEMM_LEAN_DEFAULT
-#define FVGP_GEMM_LEAN_DEFAULT 1
-#endif
-#ifndef FVGP_GEMM_SWZ_DEFAULT
-#define FVGP_GEMM_SWZ_DEFAULT 1
-#endif
-#ifndef FVGP_GEMM_PIPE_DEFAULT
-#define FVGP_GEMM_PIPE_DEFAULT 0
-#endif
 constexpr int BK = 16;
-constexpr int LDK = 18;            // doubles per row of a k-minor LDS image  [128][18]
+constexpr int LDK = 18;            // doubles per row of a padded k-minor LDS image  [128][18]
 constexpr int LDM = 144;           // doubles per row of an m-minor LDS image [16][144]
 constexpr int IMG = 128 * LDK;     // == 16 * LDM == 2304 doubles per operand image
 
@@ -55,20 +42,15 @@ struct GemmArgs {
     int ls, lo;
     int bcr, bcb, bco;                // B rows in all-gather (block-cyclic) order, see GemmDesc
     int rev;                          // tile rows enumerated last to first
-    int atom;                         // trailing update: add the tile with fire-and-forget atomics (beta == 1), see update_atomic_k
-    int stagger;                      // trailing update: phases the first wave of workgroups starts in (0 / 1: all at once), see the kernel
     long K;
     long kb0, kbi, kbj, ke0, kei, kej;
     long ntiles;
     const int *tab;                   // balanced block -> tile table ((ti << 16) | tj, -1 = no tile), or nullptr: formula
-    int *queue;                       // persistent launch (needs tab): eight per-XCD heads into the table's runs; nullptr: one tile per block
     long ksplit, csplit;              // split-K (gridDim.y > 1): block row y takes K elements [y ksplit, (y+1) ksplit), its tile goes to C + y csplit
     int ny;                           // strided batch (ksplit == 0, gridDim.y > 1): problem (y, z) = (blockIdx.y % ny, blockIdx.y / ny)
     long ab1, ab2, bb1, bb2, cb1, cb2;   // takes its operands at A + y ab1 + z ab2, B + .., C + ..
-    const int *yield;                 // trailing update (ROLE 1): per-CU counters raised by a co-resident leaf (common.h, cu_yield)
+    const int *yield;                 // trailing update (ROLE 1): per-CU counters raised by a co-resident workgroup of the panel chain
     int *raise;                       // chain kernels (small tiles, K = 128): raise this CU's counter while a workgroup runs (nullptr: no)
-    int *ticket; int nvb;             // K = 128 kernels under look-ahead: fewer workgroups than chunks, each pulls chunk numbers
-                                      // 0 .. nvb-1 from ticket[0] (ticket[1] counts finished workgroups; the last one zeroes both)
 };
 
 // linear index -> (ti, tj).  Tiles are enumerated in super-tiles of 8 x SN (SN = min(8, tiles_n)),
@@ -176,63 +158,16 @@ __device__ __forceinline__ void store_tile(double4_t (&acc)[4][4], double *cbase
     }
 }
 
-// ROLE only names the instantiation (0 generic, 1 trailing update of the Cholesky) so that profilers list
-// the kernel the metric lives in under its own symbol
-// epilogue of C += alpha * D without reading C: one fire-and-forget global_atomic_add_f64 per element (every element of C
-// gets exactly one add per launch, so the result is the same single rounding as the read-modify-write and does not depend
-// on the order) -- no load round trips between the last MFMA and the end of the workgroup
-__device__ __forceinline__ void atomic_tile(double4_t (&acc)[4][4], double *cbase, long ldc, double alpha) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                unsafeAtomicAdd(&cbase[(i * 16 + 4 * v) * ldc + j * 16], alpha * acc[i][j][v]);
-}
-
-template <int AKM, int BNM, int ROLE, int DBG = 0, int PERSIST = 0>
+// ROLE only names the instantiation (0 generic, 1 trailing update of the Cholesky) so that profilers list the kernel the metric
+// lives in under its own symbol; ROLE 1 also yields its compute unit to the panel chain (see the K loop)
+template <int AKM, int BNM, int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
-    // 76 KB, a little more than the 72 KB of operand images: the look-ahead leaf kernel (73 KB) must fit
-    // into the LDS range one retiring workgroup of this kernel frees
-#ifndef FVGP_UPDATE_ONE_PER_CU
-#define FVGP_UPDATE_ONE_PER_CU 0          // experiment: pad the trailing update's LDS so that only ONE of its workgroups fits a compute unit
-#endif
-    __shared__ double smem[2][2][IMG + 128 + ((DBG & 1024) ? 640 : 0) + ((ROLE == 1 && DBG == 0 && FVGP_UPDATE_ONE_PER_CU) ? 320 : 0)];
-
-    // XCD-aware remap: hardware deals block b to XCD b%8.  Blocks b, b+8, b+16, .. (one XCD) walk whole
-    // super-tiles: the 8*SN tiles of a super-tile run together on one L2, and super-tiles are dealt
-    // round-robin over the XCDs so every XCD gets the same mix of full and diagonal (half-empty) ones.
-    // Persistent form (g.queue; the trailing update in the chain-bound phase): the launch has FEWER workgroups than the chip has
-    // slots and every workgroup pulls tiles until the table is empty, so the slots it leaves free stay free for the whole
-    // launch -- the panel chain's kernels (look-ahead, other stream) start at once instead of waiting for a round of update
-    // tiles to retire.  Each XCD walks its own run of the table (same L2 locality as the one-tile-per-block launch: block b
-    // -> XCD b % 8) and steals from the others when it runs dry.
-    __shared__ int s_next;
+    // 76 KB, a little more than the operand images: a workgroup of the look-ahead panel chain (leaf / chain kernel, 73 KB) must
+    // fit into the LDS range one retiring workgroup of this kernel frees
+    __shared__ double smem[2][2][IMG + 128];
     const int tid = threadIdx.x;
-    int xcc = 0;
-    if constexpr (PERSIST) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-  for (;;) {
     int ti, tj;
-    if constexpr (PERSIST) {
-        if (tid == 0) {
-            const int per = (int)(g.ntiles >> 3);
-            int found = -1;
-            for (int s = 0; s < 8 && found < 0; ++s) {
-                const int y = (xcc + s) & 7;
-                const int i = atomicAdd(g.queue + y, 1);
-                if (i < per) found = 8 * i + y;
-            }
-            s_next = found;
-        }
-        __syncthreads();
-        const int b = s_next;
-        __syncthreads();              // everybody has read it before thread 0 may write the next one
-        if (b < 0) return;
-        const int e = g.tab[b];
-        if (e < 0) continue;
-        ti = e >> 16; tj = e & 0xffff;
-    } else if (g.tab) {               // balanced table: every XCD (blocks b, b + 8, ..) gets the same number of real tiles
+    if (g.tab) {                      // balanced table: every XCD (blocks b, b + 8, ..) gets the same number of real tiles
         const int e = g.tab[blockIdx.x];
         if (e < 0) return;
         ti = e >> 16; tj = e & 0xffff;
@@ -265,37 +200,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     const int nk = kend > kbeg ? (int)((kend - kbeg) / BK) : 0;
 
-    // Staggered start (the trailing update).  All tiles of a launch take the same time, so the 512 resident workgroups retire
-    // together, round after round, and a kernel of the panel chain that arrives in between (look-ahead) waits for the end of
-    // the round whatever its priority: half a tile time on average, per dependent kernel (rocprofv3: a 4-workgroup TRSM of the
-    // chain 150 us under the update, 12 us alone).  The first wave of workgroups (blocks 0 .. 511) therefore starts in
-    // `stagger` phases spread over one tile time; blocks b and b + 256 share a compute unit and start half a tile apart, so
-    // the partner's MFMAs fill the sleeper's pipe time (the launch loses nothing measurable) and slots come free `stagger`
-    // times per tile time for the rest of the launch.
-    if constexpr (ROLE == 1 && !PERSIST && DBG == 0) {
-        if (g.stagger > 1 && blockIdx.x < 512 && gridDim.x > 1024) {
-            const int ph = ((int)blockIdx.x >> 8) * (g.stagger >> 1) + (((int)blockIdx.x >> 5) & ((g.stagger >> 1) - 1));
-            // a K step of this tile takes ~3.4 us (two workgroups per CU): phase ph starts ph / stagger of a tile late
-            for (int i = (nk * ph) / g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-
     const long m0 = (long)ti * 128, n0 = (long)tj * 128;
     long nb0 = n0;                    // first row of this tile's B block
     if (!BNM) { const int idx = tj + g.bco; nb0 = ((long)(idx % g.bcr) * g.bcb + idx / g.bcr) * 128; }
 
-    // both operands k-minor (the trailing update, every panel product): unpadded [128][16] images whose 16-byte chunks are
-    // XOR-swizzled within their row by s(row) = bit1(row) | bit2(row) << 2.  ds_read_b128 serves a wave in four groups of
-    // sixteen lanes, {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32: every group holds each r = lane & 15 once,
-    // with lane group q = lane >> 4 alternating between two values, and with this swizzle the sixteen chunks of a group fall
-    // on sixteen different 16-byte bank groups (the padded [128][18] image left a third of the LDS cycles to 2-way
-    // conflicts: SQ_LDS_BANK_CONFLICT = 4 cycles per read); a row is still 128 contiguous bytes for the ds_write_b128 side.
-    constexpr bool SWZ = !AKM && !BNM && DBG != 64 && ((DBG & 256) || (DBG == 0 && FVGP_GEMM_SWZ_DEFAULT));
+    // both operands k-minor: unpadded [128][16] images whose 16-byte chunks are XOR-swizzled within their row by
+    // s(row) = bit1(row) | bit2(row) << 2.  ds_read_b128 serves a wave in four groups of sixteen lanes, {0-3,12-15,20-27},
+    // {4-11,16-19,28-31} and the same +32: every group holds each r = lane & 15 once, with lane group q = lane >> 4 alternating
+    // between two values, and with this swizzle the sixteen chunks of a group fall on sixteen different 16-byte bank groups;
+    // a row is still 128 contiguous bytes for the fill.
+    constexpr bool KM = !AKM && !BNM;
     auto swz = [](int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); };
-    // global -> register staging maps (4 x 16 B per operand per thread)
+    // global -> register staging maps of the first K step (4 x 16 B per operand per thread)
     const double *ga[4]; const double *gb[4];
     int sa[4], sb[4];
-    long astep, bstep;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         if (AKM) {           // A stored (K, M): rows of 128 contiguous m
@@ -305,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         } else {             // A stored (M, K): rows of 16 contiguous k
             int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
             ga[p] = gA + (m0 + row) * g.lda + kbeg + kc;
-            sa[p] = SWZ ? row * 16 + (((tid & 7) ^ swz(row)) << 1) : row * LDK + kc;
+            sa[p] = KM ? row * 16 + (((tid & 7) ^ swz(row)) << 1) : row * LDK + kc;
         }
         if (BNM) {           // B stored (K, N)
             int kr = p * 4 + (tid >> 6), nc = (tid & 63) * 2;
@@ -314,37 +232,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         } else {             // B stored (N, K)
             int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
             gb[p] = gB + (nb0 + row) * g.ldb + kbeg + kc;
-            sb[p] = SWZ ? row * 16 + (((tid & 7) ^ swz(row)) << 1) : row * LDK + kc;
+            sb[p] = KM ? row * 16 + (((tid & 7) ^ swz(row)) << 1) : row * LDK + kc;
         }
     }
-    astep = AKM ? (long)BK * g.lda : BK;
-    bstep = BNM ? (long)BK * g.ldb : BK;
-
-    // fragment read offsets (doubles) for k-substep 0; substep s adds 4*s (k-minor) or 4*s*LDM
-    int fa[4], fb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        fa[i] = AKM ? (q * LDM + wm * 64 + i * 16 + r) : ((wm * 64 + i * 16 + r) * LDK + q);
-        fb[i] = BNM ? (q * LDM + wn * 64 + i * 16 + r) : ((wn * 64 + i * 16 + r) * LDK + q);
-    }
-    // both operands k-minor: lane group q takes k = 4q .. 4q+3 of a K step instead of q, q+4, q+8, q+12 (the same
-    // permutation of the sum on both sides), so a pair of fragments is one 16-byte LDS read; probe 64 keeps the 8-byte reads
-    constexpr bool KPERM = !AKM && !BNM && (!(DBG & 7) || (DBG & 512)) && DBG != 64;
-    if constexpr (KPERM) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { fa[i] += 3 * q; fb[i] += 3 * q; }
-    }
-    int fa1[4], fb1[4];               // SWZ: second half of a K step = the neighbouring chunk (chunk ^ 1)
-    if constexpr (SWZ) {
-        const int c0 = (2 * q) ^ swz(r);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa[i] = (wm * 64 + i * 16 + r) * 16 + 2 * c0; fa1[i] = (wm * 64 + i * 16 + r) * 16 + 2 * (c0 ^ 1);
-            fb[i] = (wn * 64 + i * 16 + r) * 16 + 2 * c0; fb1[i] = (wn * 64 + i * 16 + r) * 16 + 2 * (c0 ^ 1);
-        }
-    }
-    constexpr int SA = AKM ? 4 * LDM : 4;
-    constexpr int SB = BNM ? 4 * LDM : 4;
+    const long astep = AKM ? (long)BK * g.lda : BK;
+    const long bstep = BNM ? (long)BK * g.ldb : BK;
 
     double4_t acc[4][4];
 #pragma unroll
@@ -367,16 +259,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     __syncthreads();
 
-    // K loop without vector-ALU work (both operands k-minor).  fp64 MFMA and the vector ALU do not execute side by side on a
-    // SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in this kernel): every v_lshl_add_u64 of a pointer bump, every LDS base that is
-    // recomputed per step comes straight out of the MFMA stream (12 such instructions per K step and wave cost ~4 %).
-    // Here the global loads go through buffer descriptors -- a constant 32-bit offset per lane, the K position in an SGPR
-    // bumped by the scalar ALU -- and the loop is unrolled over the two LDS buffers so that every LDS address is one
-    // loop-invariant register plus an immediate.
-    constexpr bool PIPE = KPERM && !SWZ && (DBG == 128 || (DBG == 0 && FVGP_GEMM_PIPE_DEFAULT));
-    constexpr bool LEAN = KPERM && ((DBG & 512) || (DBG == 0 && FVGP_GEMM_LEAN_DEFAULT));
-    constexpr int PB = (DBG & 512) ? (DBG & 31) : 0;      // timing probes of this loop: 1 no global loads / LDS writes, 2 no barrier, 4 no LDS reads
-    if constexpr (LEAN) {
+    if constexpr (KM) {
+        // K loop without vector-ALU work.  fp64 MFMA and the vector ALU do not execute side by side on a SIMD
+        // (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in this kernel): every pointer bump, every LDS base recomputed per step comes straight
+        // out of the MFMA stream.  The global loads go through buffer descriptors -- a constant 32-bit offset per lane, the K
+        // position in an SGPR bumped by the scalar ALU -- and write the swizzled image directly (LDS-DMA: a wave instruction
+        // fills eight whole rows, lane l lands 16 l bytes behind the wave's base, so it fetches chunk (l & 7) ^ s(row) of row
+        // l >> 3 of its rows); the loop is unrolled over the two LDS buffers so that every LDS address is one loop-invariant
+        // register plus an immediate.
+        int fa[4], fb[4], fa1[4], fb1[4];               // second half of a K step = the neighbouring chunk (chunk ^ 1)
+        {
+            const int c0 = (2 * q) ^ swz(r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = (wm * 64 + i * 16 + r) * 16 + 2 * c0; fa1[i] = (wm * 64 + i * 16 + r) * 16 + 2 * (c0 ^ 1);
+                fb[i] = (wn * 64 + i * 16 + r) * 16 + 2 * c0; fb1[i] = (wn * 64 + i * 16 + r) * 16 + 2 * (c0 ^ 1);
+            }
+        }
         const double *abase = uniform_ptr(gA + m0 * g.lda + kbeg);
         const double *bbase = uniform_ptr(gB + nb0 * g.ldb + kbeg);
         const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(abase), 0, 0xffffffff, 0x00020000);
@@ -384,23 +283,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         int voa[4], vob[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int row = p * 32 + (tid >> 3), kc = (tid & 7) * 2;
+            const int row = p * 32 + (tid >> 3), kc = ((tid & 7) ^ swz(row)) * 2;
             voa[p] = (int)(((long)row * g.lda + kc) * 8);
             vob[p] = (int)(((long)row * g.ldb + kc) * 8);
         }
-        // LDS-DMA staging (DMA): the loads write the swizzled image directly -- a wave instruction fills eight whole rows (lane l
-        // lands at 16 l bytes behind the wave's base, so lane l fetches chunk (l & 7) ^ s(row) of row l >> 3 of its rows) -- no
-        // staging registers, no ds_write instructions
-        constexpr bool DMA = SWZ && ((DBG & 2048) || (DBG == 0 && FVGP_GEMM_DMA_DEFAULT));
         typedef __attribute__((address_space(3))) void lds_void;
-        if constexpr (DMA) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int row = p * 32 + (tid >> 3), kc = ((tid & 7) ^ swz(row)) * 2;
-                voa[p] = (int)(((long)row * g.lda + kc) * 8);
-                vob[p] = (int)(((long)row * g.ldb + kc) * 8);
-            }
-        }
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // the LDS destination of a wave's DMA is a scalar (M0)
         auto dma_step = [&](auto bufc, int so) {
             constexpr int BUF = decltype(bufc)::value;
@@ -412,34 +299,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_src, db, 16, vob[p], so, 0, 0);
             }
         };
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 la[4] = {}, lb[4] = {};
-        u32x4 sink = {};
         int soff = 0;                                   // byte offset of the K step being fetched
-        // Cooperative yield (the trailing update only).  A leaf of the panel chain that shares this compute unit (look-ahead)
-        // is a chain of dependent vector / MFMA instructions, and beside this loop each of them waits for a 64-cycle MFMA:
-        // 130-250 us instead of 37.  The leaf raises its CU's counter; every wave here reads that word once per K step with a
-        // scalar load (no vector-ALU work: issued behind the step's LDS reads, long landed when the step's MFMAs are through)
-        // and sleeps while it is up -- the CU is the leaf's for its 37 us, this workgroup loses those instead of sharing its
-        // pipes for 250.  Bounded: a wave sleeps at most ~1 ms per tile whatever the counter says.
-        constexpr bool YIELD = ROLE == 1 && DBG == 0 && FVGP_GEMM_YIELD_DEFAULT;
+        // Cooperative yield (the trailing update only).  A workgroup of the panel chain that shares this compute unit
+        // (look-ahead) is a chain of dependent vector / MFMA instructions, and beside this loop each of them waits for a
+        // 64-cycle MFMA: 130-250 us for a leaf instead of 37.  It raises its CU's counter; every wave here reads that word once
+        // per K step with a scalar load (no vector-ALU work: issued behind the step's LDS reads, long landed when the step's
+        // MFMAs are through) and sleeps while it is up.  Bounded: a wave sleeps at most ~1 ms per tile whatever the counter says.
+        constexpr bool YIELD = ROLE == 1;
         const int *yp = nullptr;
         int ybudget = 256;
-        if constexpr (YIELD) {
-            yp = cu_yield_slot(const_cast<int *>(g.yield));
-        }
+        if constexpr (YIELD) yp = cu_yield_slot(const_cast<int *>(g.yield));
         auto kstep = [&](auto curc, const bool more) {
             constexpr int CUR = decltype(curc)::value;
-            if (more && !(PB & 1) && !(PB & 8)) {
+            if (more) {
                 soff += BK * 8;
-                if constexpr (DMA) dma_step(std::integral_constant<int, CUR ^ 1>{}, soff);
-                else {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        la[p] = __builtin_amdgcn_raw_buffer_load_b128(ra_src, voa[p], soff, 0);
-                        lb[p] = __builtin_amdgcn_raw_buffer_load_b128(rb_src, vob[p], soff, 0);
-                    }
-                }
+                dma_step(std::integral_constant<int, CUR ^ 1>{}, soff);
             }
             const double *pa = &smem[CUR][0][0];
             const double *pb = &smem[CUR][1][0];
@@ -450,14 +324,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (PB & 4) { a2[hf][i] = ra[i] + (double)(hf + CUR); b2[hf][i] = rb[i] + (double)(hf + CUR); }
-                    else if constexpr (SWZ) {
-                        a2[hf][i] = *reinterpret_cast<const double2_t *>(pa + (hf ? fa1[i] : fa[i]));
-                        b2[hf][i] = *reinterpret_cast<const double2_t *>(pb + (hf ? fb1[i] : fb[i]));
-                    } else {
-                        a2[hf][i] = *reinterpret_cast<const double2_t *>(pa + fa[i] + 2 * hf);
-                        b2[hf][i] = *reinterpret_cast<const double2_t *>(pb + fb[i] + 2 * hf);
-                    }
+                    a2[hf][i] = *reinterpret_cast<const double2_t *>(pa + (hf ? fa1[i] : fa[i]));
+                    b2[hf][i] = *reinterpret_cast<const double2_t *>(pb + (hf ? fb1[i] : fb[i]));
                 }
             __builtin_amdgcn_sched_barrier(0);
             int yv = 0;
@@ -480,19 +348,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                     asm volatile("s_load_dword %0, %1, 0x0 glc\n s_waitcnt lgkmcnt(0)" : "={s95}"(yv) : "s"(yp) : "memory");
                 }
             }
-            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next step's image has landed
-            if (!DMA && more && !(PB & 1) && !(PB & 16)) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    *reinterpret_cast<u32x4 *>(&smem[CUR ^ 1][0][sa[p]]) = la[p];
-                    *reinterpret_cast<u32x4 *>(&smem[CUR ^ 1][1][sb[p]]) = lb[p];
-                }
-            }
-            if ((PB & 16) && more) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) sink ^= la[p] ^ lb[p];
-            }
-            if (!(PB & 2)) __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next step's image has landed
+            __syncthreads();
         };
         int kt = 0;
         for (; kt + 1 < nk; kt += 2) {
@@ -500,22 +357,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             kstep(std::integral_constant<int, 1>{}, kt + 2 < nk);
         }
         if (kt < nk) kstep(std::integral_constant<int, 0>{}, false);
-        if ((PB & 16) && sink[0] == 0x12345u) smem[0][0][tid] = 1.0;
-    } else
-    // Software-pipelined K loop (both operands k-minor): a K step's MFMAs are split around its barrier.  The fragments of
-    // the step's second half are read before the first half's MFMAs, the next step's first-half fragments right after the
-    // barrier and before the second half's MFMAs -- every LDS read has 32 MFMAs (2048 pipe cycles) of the wave's own work
-    // between issue and use, and the wave arrives at the barrier with half a step of MFMAs still to issue behind it, so
-    // the LDS round trip no longer sits between the barrier and the first MFMA of the next step.
-    if constexpr (PIPE) {
-        double2_t f0a[4], f0b[4], f1a[4], f1b[4];
-        if (nk > 0) {
+    } else {
+        // (K,M) and / or (K,N) operands: global -> registers -> LDS, padded images, 8-byte fragment reads
+        int fa[4], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f0a[i] = *reinterpret_cast<const double2_t *>(&smem[0][0][fa[i]]);
-                f0b[i] = *reinterpret_cast<const double2_t *>(&smem[0][1][fb[i]]);
-            }
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = AKM ? (q * LDM + wm * 64 + i * 16 + r) : ((wm * 64 + i * 16 + r) * LDK + q);
+            fb[i] = BNM ? (q * LDM + wn * 64 + i * 16 + r) : ((wn * 64 + i * 16 + r) * LDK + q);
         }
+        constexpr int SA = AKM ? 4 * LDM : 4;
+        constexpr int SB = BNM ? 4 * LDM : 4;
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             const bool more = (kt + 1 < nk);
@@ -529,22 +380,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             }
             const double *pa = &smem[cur][0][0];
             const double *pb = &smem[cur][1][0];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f1a[i] = *reinterpret_cast<const double2_t *>(pa + fa[i] + 2);
-                f1b[i] = *reinterpret_cast<const double2_t *>(pb + fb[i] + 2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            // the fragment reads and MFMAs of this wave go out at raised priority; the memory phase of the K step (global
+            // loads above, LDS writes and barrier below) yields to the co-resident workgroup's MFMAs
             __builtin_amdgcn_s_setprio(ROLE ? 1 : 2);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 4; ++s) {
+                double a[4], bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a[i] = pa[fa[i] + s * SA]; bv[i] = pb[fb[i] + s * SB]; }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0a[i][s], f0b[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(ROLE ? 0 : 1);
-            __builtin_amdgcn_sched_barrier(0);
             if (more) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -553,228 +403,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 }
             }
             __syncthreads();
-            if (more) {
-                const double *na = &smem[cur ^ 1][0][0];
-                const double *nb = &smem[cur ^ 1][1][0];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f0a[i] = *reinterpret_cast<const double2_t *>(na + fa[i]);
-                    f0b[i] = *reinterpret_cast<const double2_t *>(nb + fb[i]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(ROLE ? 1 : 2);
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1a[i][s], f1b[j][s], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(ROLE ? 0 : 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = (kt + 1 < nk);
-        if (more && !(DBG & 1)) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                ga[p] += astep; gb[p] += bstep;
-                ra[p] = *reinterpret_cast<const double2_t *>(ga[p]);
-                rb[p] = *reinterpret_cast<const double2_t *>(gb[p]);
-            }
-        }
-        const double *pa = &smem[cur][0][0];
-        const double *pb = &smem[cur][1][0];
-        // the fragment reads and MFMAs of this wave go out at raised priority; the memory phase of the K step (global
-        // loads above, LDS writes and barrier below) yields to the co-resident workgroup's MFMAs (+1.3 % on 8192^3)
-        if (DBG != 8) __builtin_amdgcn_s_setprio(ROLE ? 1 : 2);
-        if constexpr (KPERM) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                double2_t a2[4], b2[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if constexpr (SWZ) {
-                        a2[i] = *reinterpret_cast<const double2_t *>(pa + (hf ? fa1[i] : fa[i]));
-                        b2[i] = *reinterpret_cast<const double2_t *>(pb + (hf ? fb1[i] : fb[i]));
-                    } else {
-                        a2[i] = *reinterpret_cast<const double2_t *>(pa + fa[i] + 2 * hf);
-                        b2[i] = *reinterpret_cast<const double2_t *>(pb + fb[i] + 2 * hf);
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i][s], b2[j][s], acc[i][j], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            double a[4], bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (DBG & 4) { a[i] = ra[i][0] + s; bv[i] = rb[i][1] + s; }       // probe: no LDS reads
-                else { a[i] = pa[fa[i] + s * SA]; bv[i] = pb[fb[i] + s * SB]; }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        }
-        if (DBG != 8) __builtin_amdgcn_s_setprio(ROLE ? 0 : 1);
-        if (more && !(DBG & 1)) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][0][sa[p]]) = ra[p];
-                *reinterpret_cast<double2_t *>(&smem[cur ^ 1][1][sb[p]]) = rb[p];
-            }
-        }
-        if (!(DBG & 2)) __syncthreads();
-    }
-
-    // the persistent form adds its tile with fire-and-forget atomics (beta == 1 there): no registers for the old values, so the
-    // addressing it keeps alive across tiles fits beside the accumulators
-    constexpr bool ATOM = PERSIST || (DBG & 4096) || (DBG == 0 && FVGP_GEMM_ATOMIC_DEFAULT);
-    if ((ATOM || (ROLE == 1 && DBG == 0 && g.atom)) && (PERSIST || g.beta == 1.0)) atomic_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha);
-    else store_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
-    if constexpr (!PERSIST) return;
-  }
-}
-
-// PROBE: the 256 x 128 macro-tile the round-2 review asked about.  One workgroup of EIGHT waves (4 x 2, each 64 x 64 as in the
-// shipped kernel) per compute unit instead of two workgroups of four: the same sixteen MFMA waves' worth of work per K step
-// reads 256 + 128 operand rows instead of 2 x (128 + 128) (-25 % of the global -> LDS traffic), at the price of ONE barrier
-// domain per CU (nobody computes while the eight waves meet).  Same loop as the shipped kernel otherwise (swizzled unpadded
-// images, LDS-DMA staging, all sixteen fragment reads before the MFMAs, no vector-ALU work).  (M,K) x (N,K) layout, full tile
-// grids, M % 256 == 0; option gemm_probe = 9000.  Measured: tools/gemm_ab.py 0 9000, profiles/r03_macro_tile.txt.
-__global__ __launch_bounds__(512, 2) void gemm_f64_macro_kernel(GemmArgs g) {
-    constexpr int ROWS = 256 + 128;
-    __shared__ double smem[3][ROWS * 16];                 // three stages of 48 KB: one workgroup per CU, the DMA two K steps ahead
-    const int tid = threadIdx.x;
-    const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
-    int ti, tj;
-    tile_of(t, g.tiles_m, g.tiles_n, false, ti, tj);       // tiles_m counts 256-row tiles here
-    if (ti >= g.tiles_m || tj >= g.tiles_n) return;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 15, q = lane >> 4;
-    const int nk = (int)(g.K / BK);
-    const long m0 = (long)ti * 256, n0 = (long)tj * 128;
-    auto swz = [](int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); };
-    const double *abase = uniform_ptr(g.A + m0 * g.lda);
-    const double *bbase = uniform_ptr(g.B + n0 * g.ldb);
-    const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(abase), 0, 0xffffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(bbase), 0, 0xffffffff, 0x00020000);
-    // LDS-DMA: a wave instruction fills eight whole rows (lane l lands 16 l bytes behind the wave's base)
-    int voa[4], vob[2];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int row = p * 64 + wave * 8 + (lane >> 3), kc = ((lane & 7) ^ swz(row)) * 2;
-        voa[p] = (int)(((long)row * g.lda + kc) * 8);
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int row = p * 64 + wave * 8 + (lane >> 3), kc = ((lane & 7) ^ swz(row)) * 2;
-        vob[p] = (int)(((long)row * g.ldb + kc) * 8);
-    }
-    typedef __attribute__((address_space(3))) void lds_void;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto dma_step = [&](auto bufc, int so) {
-        constexpr int BUF = decltype(bufc)::value;
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_src, (lds_void *)&smem[BUF][(p * 64 + wave_u * 8) * 16], 16, voa[p], so, 0, 0);
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_src, (lds_void *)&smem[BUF][(256 + p * 64 + wave_u * 8) * 16], 16, vob[p], so, 0, 0);
-    };
-    int fa[4], fa1[4], fb[4], fb1[4];
-    {
-        const int c0 = (2 * q) ^ swz(r);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa[i] = (wm * 64 + i * 16 + r) * 16 + 2 * c0; fa1[i] = (wm * 64 + i * 16 + r) * 16 + 2 * (c0 ^ 1);
-            fb[i] = (256 + wn * 64 + i * 16 + r) * 16 + 2 * c0; fb1[i] = (256 + wn * 64 + i * 16 + r) * 16 + 2 * (c0 ^ 1);
         }
     }
-    double4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    if (nk > 0) dma_step(std::integral_constant<int, 0>{}, 0);
-    if (nk > 1) dma_step(std::integral_constant<int, 1>{}, BK * 8);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stage 0 has landed
-    __syncthreads();
-    int soff = BK * 8;
-    // one barrier domain: a K step's MFMAs are split around its barrier -- the second half's fragments are read before the first
-    // half's MFMAs, the next step's first-half fragments right behind the barrier and before the second half's MFMAs, so no wave
-    // arrives at or leaves the barrier with nothing to issue
-    double2_t f0a[4], f0b[4], f1a[4], f1b[4];
-    if (nk > 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f0a[i] = *reinterpret_cast<const double2_t *>(&smem[0][fa[i]]);
-            f0b[i] = *reinterpret_cast<const double2_t *>(&smem[0][fb[i]]);
-        }
-    }
-    // step s computes on stage s % 3, its DMA fetches step s + 2 into stage (s + 2) % 3 (read last in step s - 1: everybody
-    // has passed that step's barrier), and the wait in front of the barrier only asks for step s + 1's six loads
-    auto kstep = [&](auto curc, const bool more, const bool more2) {
-        constexpr int CUR = decltype(curc)::value;
-        if (more2) { soff += BK * 8; dma_step(std::integral_constant<int, (CUR + 2) % 3>{}, soff); }
-        const double *ps = &smem[CUR][0];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f1a[i] = *reinterpret_cast<const double2_t *>(ps + fa1[i]);
-            f1b[i] = *reinterpret_cast<const double2_t *>(ps + fb1[i]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0a[i][s2], f0b[j][s2], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (more) {
-            const double *pn = &smem[(CUR + 1) % 3][0];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f0a[i] = *reinterpret_cast<const double2_t *>(pn + fa[i]);
-                f0b[i] = *reinterpret_cast<const double2_t *>(pn + fb[i]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1a[i][s2], f1b[j][s2], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    int kt = 0;
-    for (; kt + 2 < nk; kt += 3) {
-        kstep(std::integral_constant<int, 0>{}, true, true);
-        kstep(std::integral_constant<int, 1>{}, true, kt + 3 < nk);
-        kstep(std::integral_constant<int, 2>{}, kt + 3 < nk, kt + 4 < nk);
-    }
-    if (kt < nk) kstep(std::integral_constant<int, 0>{}, kt + 1 < nk, false);
-    if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, false, false);
-    store_tile(acc, g.C + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
+    store_tile(acc, g.C + coff + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
 }
 
 // Small-tile variant for the latency-bound steps of the panel chain (TRSM by the inverted diagonal block, in-panel
@@ -985,39 +616,15 @@ __device__ __forceinline__ void k128_chunk(const GemmArgs &g, const int vb, doub
             cbase[(4 * v) * g.ldc + ph * 32] = alpha * acc[ph][v] + (beta != 0.0 ? beta * old[ph][v] : 0.0);
 }
 
-// Chunk loop of the chain's many-workgroup kernels under look-ahead.  Beside a trailing update that fills the chip, a chain
-// kernel's workgroups only start as update workgroups retire -- about three slots a microsecond -- and one that has run its
-// 10 us hands its slot back to whoever is next, usually the update: 590 workgroups took 200 us to all get their turn
-// (tools/chain_stamps.py).  So a contended launch brings about sqrt(60 chunks) workgroups, and each keeps its slot and
-// pulls chunk numbers from a ticket counter until none are left; the next ticket is in flight during a chunk.
-template <typename Body>
-__device__ __forceinline__ void chunk_loop(int *ticket, const int nvb, int *s_vb, Body body) {
-    const int tid = threadIdx.x;
-    if (!ticket) { body((int)blockIdx.x); return; }
-    int nxt = 0;
-    if (tid == 0) nxt = atomicAdd(ticket, 1);
-    for (;;) {
-        if (tid == 0) *s_vb = nxt;
-        __syncthreads();
-        const int vb = *s_vb;
-        if (vb >= nvb) break;
-        if (tid == 0) nxt = atomicAdd(ticket, 1);
-        body(vb);
-        __syncthreads();                  // the LDS images and s_vb are free again
-    }
-    if (tid == 0 && atomicAdd(ticket + 1, 1) == (int)gridDim.x - 1) { atomicExch(ticket, 0); atomicExch(ticket + 1, 0); }
-}
-
 template <int TN>
 __global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
     constexpr int LDS_ = 130, TM = 32;
     __shared__ double sA[TM * LDS_];
     __shared__ double sB[32 * LDS_];
-    __shared__ int s_vb;
     __builtin_amdgcn_s_setprio(3);        // a step of the chain: ahead of the trailing-update waves it shares its SIMDs with
     int *yflag = nullptr;                 // the co-resident trailing-update workgroup sleeps while this one runs (10 us instead of 53)
     if (g.raise && threadIdx.x == 0) { yflag = cu_yield_slot(g.raise); atomicAdd(yflag, 1); }
-    chunk_loop(g.ticket, g.nvb, &s_vb, [&](const int vb) { k128_chunk<TN>(g, vb, sA, sB); });
+    k128_chunk<TN>(g, (int)blockIdx.x, sA, sB);
     if (yflag) atomicAdd(yflag, -1);
 }
 
@@ -1028,15 +635,12 @@ __global__ __launch_bounds__(256) void gemm_f64_k128_kernel(GemmArgs g) {
 // owns 32 rows, a wave 16 of them; everything is computed transposed so that a finished tile is already the next
 // product's B operand: R^T = A_t^T - sum L[t,s] X_s^T accumulates in the MFMA D layout, X_t^T = inv(L_tt) R^T takes it as
 // it is.  L passes through LDS in four phases of 32 rows (all of it is fetched into registers up front); 67 KB of LDS.
-struct TrsmTilesArgs { double *A; long lda; const double *L; long ldl; const double *dinv;
-                       unsigned long long *stamps; int seq; int *raise; int *ticket; int nvb; };      // diagnostics (option "chain_stamps"): per-workgroup start / end times
+struct TrsmTilesArgs { double *A; long lda; const double *L; long ldl; const double *dinv; int *raise; };
 
 __device__ __forceinline__ void trsm_tiles_chunk(const TrsmTilesArgs &g, const int vb, double *sX, double *sL) {
     constexpr int LDS_ = 130;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    unsigned long long t_start = 0;
-    if (g.stamps && tid == 0) t_start = __builtin_amdgcn_s_memrealtime();
     double *Arows = g.A + (long)vb * 32 * g.lda;
     // every global load of the kernel goes out at once (the phases would otherwise each wait a memory round trip):
     // the workgroup's 32 rows of A, all 128 rows of L (four phases of 32), the eight tile inverses
@@ -1115,13 +719,6 @@ __device__ __forceinline__ void trsm_tiles_chunk(const TrsmTilesArgs &g, const i
 #pragma unroll
     for (int p = 0; p < 16; ++p)
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]), a_src, vo, (2 * p + wave_u) * arow, 0);
-    if (g.stamps && tid == 0) {           // {launch number, chunk, start, end} in 100 MHz ticks
-        const unsigned long long i = atomicAdd(g.stamps, 1ull);
-        if (i < (1ull << 20)) {
-            unsigned long long *e = g.stamps + 8 + 4 * i;
-            e[0] = (unsigned long long)g.seq; e[1] = vb; e[2] = t_start; e[3] = __builtin_amdgcn_s_memrealtime();
-        }
-    }
 }
 
 // at most 256 registers: under look-ahead a workgroup must fit beside the ONE trailing-update wave (224) a SIMD keeps when the other
@@ -1130,124 +727,11 @@ __global__ __launch_bounds__(128, 2) void trsm_tiles_kernel(TrsmTilesArgs g) {
     constexpr int LDS_ = 130;
     __shared__ double sX[32 * LDS_];
     __shared__ double sL[32 * LDS_];
-    __shared__ int s_vb;
     __builtin_amdgcn_s_setprio(3);        // a step of the chain: ahead of the trailing-update waves it shares its SIMDs with
     int *yflag = nullptr;                 // the co-resident trailing-update workgroup sleeps while this one runs (10 us instead of 53)
     if (g.raise && threadIdx.x == 0) { yflag = cu_yield_slot(g.raise); atomicAdd(yflag, 1); }
-    chunk_loop(g.ticket, g.nvb, &s_vb, [&](const int vb) { trsm_tiles_chunk(g, vb, sX, sL); });
+    trsm_tiles_chunk(g, (int)blockIdx.x, sX, sL);
     if (yflag) atomicAdd(yflag, -1);
-}
-
-// LDS-free variant for the (M,K) x (N,K) layout (the trailing update): every wave loads its own MFMA operands straight
-// from global memory into registers.  v_mfma_f64_16x16x4 wants lane (r, q) to hold A[row r][k_q]; WHICH four k a step
-// contracts is free as long as A and B agree, so lane (r, q) takes the two consecutive doubles k0 + 2q, k0 + 2q + 1 of
-// its row (one 16-byte load) and an 8-deep K stage is two MFMAs per accumulator.  No LDS image, no barrier, no
-// fragment reads: 16 loads per 64 MFMAs per wave, each operand row fetched by the two waves that share it (through L1/L2).
-// Two register stages (k0 and k0 + 8) alternate, so a stage's loads have 32 MFMAs of cover.
-template <int ROLE>
-__global__ __launch_bounds__(256, 2) void gemm_f64_direct_kernel(GemmArgs g) {
-    int ti, tj;
-    if (g.tab) {                      // balanced table: every XCD (blocks b, b + 8, ..) gets the same number of real tiles
-        const int e = g.tab[blockIdx.x];
-        if (e < 0) return;
-        ti = e >> 16; tj = e & 0xffff;
-    } else {
-        const long t = xcd_remap(blockIdx.x, gridDim.x, g.tiles_n);
-        if (g.lower == 2) tile_of_rs(t, g.tiles_m, g.tiles_n, g.ls, g.lo, ti, tj);
-        else tile_of(t, g.tiles_m, g.tiles_n, g.lower == 1, ti, tj);
-        if (ti >= g.tiles_m || tj >= g.tiles_n) return;
-        if (g.lower == 1 && tj > ti) return;
-        if (g.lower == 2 && tj > ti * g.ls + g.lo) return;
-    }
-    if (g.rev) ti = g.tiles_m - 1 - ti;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 15, q = lane >> 4;
-
-    long kbeg = g.kb0 + g.kbi * ti + g.kbj * tj;
-    long kend = (g.ke0 < 0 ? g.K : g.ke0 + g.kei * ti + g.kej * tj);
-    if (kbeg < 0) kbeg = 0;
-    if (kend > g.K) kend = g.K;
-    const int nk = kend > kbeg ? (int)((kend - kbeg) / BK) : 0;
-
-    const long m0 = (long)ti * 128, n0 = (long)tj * 128;
-    const int idx = tj + g.bco;
-    const long nb0 = ((long)(idx % g.bcr) * g.bcb + idx / g.bcr) * 128;
-
-    // wave-uniform bases in SGPRs + one 32-bit byte offset per lane and 16-row block (a wave's 64 rows span < 4 GB)
-    const double *abase = g.A + (m0 + wm * 64) * g.lda + kbeg;
-    const double *bbase = g.B + (nb0 + wn * 64) * g.ldb + kbeg;
-    abase = uniform_ptr(abase);
-    bbase = uniform_ptr(bbase);
-    unsigned oa[4], ob[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        oa[i] = (unsigned)(((long)(i * 16 + r) * g.lda + 2 * q) * 8);
-        ob[i] = (unsigned)(((long)(i * 16 + r) * g.ldb + 2 * q) * 8);
-    }
-
-    double4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-    // The loads are issued by hand (inline asm) so that the wait in front of a stage is exactly "this stage's eight
-    // loads": hipcc merges the wait-count state of the prologue and of the loop's back edge conservatively and would
-    // wait for the stage just issued as well.  The waits carry the fragments as in/out operands, which orders the
-    // consuming MFMAs behind them.
-    // three register stages of 8 k each rotate: the loads of a stage have 64 MFMAs of cover (the same distance the
-    // LDS kernel gives its global loads), enough for operands that come from HBM rather than the L2 / Infinity Cache
-    double2_t a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
-#define FVGP_LOAD_STAGE(AF, BF, OFF)                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                          \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(AF[i]) : "v"(oa[i]), "s"(abase) : "memory");       \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(BF[i]) : "v"(ob[i]), "s"(bbase) : "memory");       \
-    }
-#define FVGP_WAIT_STAGE(AF, BF, N)                                                                                           \
-    asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(AF[0]), "+v"(AF[1]), "+v"(AF[2]), "+v"(AF[3]),                             \
-                                             "+v"(BF[0]), "+v"(BF[1]), "+v"(BF[2]), "+v"(BF[3]) :: "memory")
-#define FVGP_MFMA_STAGE(AF, BF)                                                                          \
-    _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(AF[i][tt], BF[j][tt], acc[i][j], 0, 0, 0)
-    if (nk > 0) {
-        const int ns = 2 * nk;                      // stages of 8 k
-        int st = 0;                                 // stage held by a0 / b0; a1 / b1 hold st + 1, a2 / b2 hold st + 2
-        FVGP_LOAD_STAGE(a0, b0, 0)
-        FVGP_LOAD_STAGE(a1, b1, 64)
-        if (ns > 2) { FVGP_LOAD_STAGE(a2, b2, 128) }
-        // steady state: no branch inside the body; the wait in front of a stage leaves the two younger stages in flight
-        for (; st + 5 < ns; st += 3) {
-            FVGP_WAIT_STAGE(a0, b0, 16);
-            FVGP_MFMA_STAGE(a0, b0);
-            FVGP_LOAD_STAGE(a0, b0, 192)
-            FVGP_WAIT_STAGE(a1, b1, 16);
-            FVGP_MFMA_STAGE(a1, b1);
-            FVGP_LOAD_STAGE(a1, b1, 256)
-            FVGP_WAIT_STAGE(a2, b2, 16);
-            FVGP_MFMA_STAGE(a2, b2);
-            FVGP_LOAD_STAGE(a2, b2, 320)
-            abase += 24; bbase += 24;
-        }
-        // the last two to five stages
-        FVGP_WAIT_STAGE(a0, b0, 0);
-        FVGP_WAIT_STAGE(a1, b1, 0);
-        if (ns > 2) FVGP_WAIT_STAGE(a2, b2, 0);
-        FVGP_MFMA_STAGE(a0, b0);
-        if (st + 3 < ns) { FVGP_LOAD_STAGE(a0, b0, 192) }
-        FVGP_MFMA_STAGE(a1, b1);
-        if (st + 4 < ns) { FVGP_LOAD_STAGE(a1, b1, 256) }
-        if (st + 2 < ns) { FVGP_MFMA_STAGE(a2, b2); }
-        if (st + 3 < ns) { FVGP_WAIT_STAGE(a0, b0, 0); FVGP_MFMA_STAGE(a0, b0); }
-        if (st + 4 < ns) { FVGP_WAIT_STAGE(a1, b1, 0); FVGP_MFMA_STAGE(a1, b1); }
-    }
-#undef FVGP_LOAD_STAGE
-#undef FVGP_WAIT_STAGE
-#undef FVGP_MFMA_STAGE
-    store_tile(acc, g.C + (m0 + wm * 64 + q) * g.ldc + n0 + wn * 64 + r, g.ldc, g.alpha, g.beta);
 }
 
 __global__ void mfma_selftest_kernel(const double *A, const double *B, double *D) {
@@ -1342,7 +826,6 @@ static void drop_tile_tables(fvgp_handle *h) {
 
 void gemm_release_tables(fvgp_handle *h) {
     drop_tile_tables(h);
-    if (h->tile_queue) { (void)hipFree(h->tile_queue); h->tile_queue = nullptr; }
     if (h->copy_stream) { (void)hipStreamDestroy(h->copy_stream); h->copy_stream = nullptr; }
 }
 
@@ -1418,21 +901,7 @@ bool gemm_takes_small_tiles(const fvgp_handle *h, const GemmDesc &d) {
     if (!d.b_nmajor && (const double *)d.C == d.B) return false;
     if (!d.b_nmajor && (const double *)d.C == d.A && d.N != 128) return false;
     if (d.b_nmajor && (d.lower == 2 || d.bc_ranks != 1 || d.bc_off != 0)) return false;
-    return !d.probe && !d.a_kmajor && !d.rev_m && few &&
-           d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && h->gemm_direct < 2;
-}
-
-// grid of a chain kernel of `nvb` chunks: all of them at once, or -- under a trailing update that fills the chip
-// (fvgp_handle::chain_contended) -- about sqrt(60 nvb) workgroups that pull chunk numbers from a ticket (chunk_loop above:
-// slots come at ~3 per microsecond, a chunk takes ~10 us; G/6 + 10 nvb/G is least at G = sqrt(60 nvb))
-static void chain_grid(fvgp_handle *h, int nvb, int **ticket, int *nvb_out, unsigned *grid) {
-    *ticket = nullptr; *nvb_out = nvb; *grid = (unsigned)nvb;
-    if (!h->chain_contended || !h->chain_loop || !h->chain_tickets || nvb < 128) return;
-    int G = (int)__builtin_sqrt((double)h->chain_loop * (double)nvb);
-    if (G < 64) G = 64;
-    if (G >= nvb) return;
-    *ticket = h->chain_tickets + 2 * (h->chain_ticket_next++ % 256);
-    *grid = (unsigned)G;
+    return !d.a_kmajor && !d.rev_m && few && d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0;
 }
 
 int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
@@ -1448,18 +917,17 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     g.A = d.A; g.B = d.B; g.C = d.C; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
     g.alpha = d.alpha; g.beta = d.beta; g.K = d.K;
     g.tiles_m = (int)(d.M / 128); g.tiles_n = (int)(d.N / 128); g.lower = d.lower; g.ls = d.lower_scale; g.lo = d.lower_off;
-    g.bcr = d.bc_ranks; g.bcb = d.bc_blocks; g.bco = d.bc_off; g.rev = d.rev_m; g.stagger = d.role == 1 ? h->update_stagger : 0; g.atom = (d.role == 1 && d.K <= h->update_atomic_k) ? 1 : 0;
+    g.bcr = d.bc_ranks; g.bcb = d.bc_blocks; g.bco = d.bc_off; g.rev = d.rev_m;
 
     if (d.rev_m && d.lower) { fvgp_set_error("gemm: rev_m is for full (non-triangular) tile grids"); return -3; }
     if (d.bc_ranks < 1) return -7;
     if ((d.bc_ranks > 1 || d.bc_off) && d.b_nmajor) { fvgp_set_error("gemm: block-cyclic B needs the (N, K) layout"); return -7; }
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
-    g.tab = nullptr; g.queue = nullptr; g.ksplit = 0; g.csplit = 0; g.yield = h->cu_yield; g.raise = (h->chain_yield && d.role != 1) ? h->cu_yield : nullptr; g.ticket = nullptr; g.nvb = 0;
+    g.tab = nullptr; g.ksplit = 0; g.csplit = 0; g.yield = h->cu_yield; g.raise = (h->chain_yield && d.role != 1) ? h->cu_yield : nullptr;
     g.ny = 0; g.ab1 = g.ab2 = g.bb1 = g.bb2 = g.cb1 = g.cb2 = 0;
     const bool plain_k = d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && d.kei == 0 && d.kej == 0;
-    if (h->tile_tables && plain_k && !d.rev_m && !d.probe && g.tiles_m < 32768 && g.tiles_n < 32768 &&
-        g.ntiles >= 64 && !gemm_takes_small_tiles(h, d)) {
+    if (h->tile_tables && plain_k && !d.rev_m && g.tiles_m < 32768 && g.tiles_n < 32768 && g.ntiles >= 64 && !gemm_takes_small_tiles(h, d)) {
         // equal work per tile: balance the XCDs by tile count (launches with per-tile K ranges keep the formula map)
         const int rc = tile_table(h, g.tiles_m, g.tiles_n, g.lower, g.ls, g.lo, &g.tab, &g.ntiles);
         if (rc) return rc;
@@ -1468,7 +936,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     dim3 grid((unsigned)g.ntiles), block(256);
     const bool split = d.split > 1;
     if (split) {
-        if (!plain_k || d.probe || d.rev_m || !d.split_ws) { fvgp_set_error("gemm: split-K needs a plain K range and a workspace"); return -3; }
+        if (!plain_k || d.rev_m || !d.split_ws) { fvgp_set_error("gemm: split-K needs a plain K range and a workspace"); return -3; }
         const long steps = (d.K / BK + d.split - 1) / d.split;
         g.ksplit = steps * BK; g.csplit = (long)d.M * d.N;
         g.C = d.split_ws; g.ldc = d.N; g.beta = 0.0;
@@ -1476,30 +944,9 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     }
     const bool batched = (long)d.batch_y * d.batch_z > 1;
     if (batched) {
-        if (split || d.probe || d.batch_y < 1 || d.batch_z < 1) { fvgp_set_error("gemm: a strided batch excludes split-K and probes"); return -3; }
+        if (split || d.batch_y < 1 || d.batch_z < 1) { fvgp_set_error("gemm: a strided batch excludes split-K"); return -3; }
         g.ny = d.batch_y; g.ab1 = d.a_by; g.ab2 = d.a_bz; g.bb1 = d.b_by; g.bb2 = d.b_bz; g.cb1 = d.c_by; g.cb2 = d.c_bz;
         grid.y = (unsigned)(d.batch_y * d.batch_z);
-    }
-    if (d.probe == 9000) {            // the 256 x 128 macro-tile probe
-        if (d.a_kmajor || d.b_nmajor || d.lower || !plain_k || split || batched || d.M % 256 || d.rev_m || d.bc_ranks != 1 || d.bc_off ||
-            d.lda >= (1L << 20) || d.ldb >= (1L << 20)) {          // 256 rows within a 32-bit byte offset
-            fvgp_set_error("gemm probe 9000: (M,K) x (N,K), full grid, M % 256 == 0"); return -3;
-        }
-        g.tiles_m = (int)(d.M / 256); g.tab = nullptr;
-        const long nt = gemm_grid_tiles(g.tiles_m, g.tiles_n, false);
-        hipLaunchKernelGGL(gemm_f64_macro_kernel, dim3((unsigned)nt), dim3(512), 0, h->stream, g);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-    if (d.probe) {
-        // timing probes of the K loop with parts of it removed (results are meaningless unless noted): 1 no global
-        // loads / LDS writes, 2 no barrier, 4 no LDS fragment reads, 8 the full loop without s_setprio, 64 with 8-byte
-        // fragment reads in the plain k order (both with correct results) -- tools/gemm_probe.py
-#define PR(V) case V: hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 0, V>), grid, block, 0, h->stream, g); break
-        switch (d.probe) { PR(1); PR(2); PR(3); PR(4); PR(5); PR(6); PR(7); PR(8); PR(64); PR(128); PR(256); PR(512); PR(513); PR(514); PR(515); PR(516); PR(517); PR(518); PR(519); PR(520); PR(522); PR(528); PR(530); PR(768); PR(2816); PR(6912); PR(1536); default: return -3; }
-#undef PR
-        HIPCHK(hipGetLastError());
-        return 0;
     }
     if (!split && !batched && gemm_takes_small_tiles(h, d)) {             // too few 128-tiles to fill the chip (the panel chain's steps): 64-tiles
         const long t128 = (long)g.tiles_m * g.tiles_n;
@@ -1507,8 +954,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         if (!d.b_nmajor) {
             const bool one_stage = d.K == 128 && h->k128_kernels;
             const bool in_place = (const double *)d.C == d.A || (const double *)d.C == d.B;
-            dim3 kg(in_place ? sg.x : (unsigned)(t128 * 8));
-            if (one_stage) chain_grid(h, (int)kg.x, &g.ticket, &g.nvb, &kg.x);
+            const dim3 kg(in_place ? sg.x : (unsigned)(t128 * 8));
             if (in_place) {                                                        // in place: a workgroup owns whole rows
                 if (one_stage) hipLaunchKernelGGL((gemm_f64_k128_kernel<128>), kg, block, 0, h->stream, g);
                 else hipLaunchKernelGGL((gemm_f64_small_kernel<32, 128, 0>), sg, block, 0, h->stream, g);
@@ -1524,26 +970,6 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         }
         HIPCHK(hipGetLastError());
         return 0;
-    }
-    const bool direct_ = d.direct || h->gemm_direct >= 2 || (h->gemm_direct == 1 && d.role == 1);
-    if (direct_ && !split && !batched && !d.probe && !d.a_kmajor && !d.b_nmajor && d.lda < (1L << 22) && d.ldb < (1L << 22)) {   // 64 rows of a wave within a 32-bit byte offset
-        if (d.role == 1) hipLaunchKernelGGL((gemm_f64_direct_kernel<1>), grid, block, 0, h->stream, g);
-        else hipLaunchKernelGGL((gemm_f64_direct_kernel<0>), grid, block, 0, h->stream, g);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-    // the trailing update as a persistent launch that leaves `update_reserve` compute units' worth of slots free for the chain
-    if (d.role == 1 && !d.a_kmajor && !d.b_nmajor && g.tab && !split && !batched && d.reserve_cus > 0 && d.reserve_cus < h->n_cus) {
-        const long slots = 2L * (h->n_cus - d.reserve_cus);
-        if (g.ntiles > slots && d.beta == 1.0) {
-            if (!h->tile_queue) HIPCHK(hipMalloc((void **)&h->tile_queue, 8 * sizeof(int) * 512));
-            g.queue = h->tile_queue + 8 * (h->tile_queue_next++ % 512);
-            HIPCHK(hipMemsetAsync(g.queue, 0, 8 * sizeof(int), h->stream));
-            grid.x = (unsigned)slots;
-            hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 1, 0, 1>), grid, block, 0, h->stream, g);
-            HIPCHK(hipGetLastError());
-            return 0;
-        }
     }
 #define GO(AK, BN) do { if (d.role == 1) hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 1>), grid, block, 0, h->stream, g); \
                         else hipLaunchKernelGGL((gemm_f64_kernel<AK, BN, 0>), grid, block, 0, h->stream, g); } while (0)
@@ -1561,10 +987,8 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
 int launch_trsm_tiles(fvgp_handle *h, double *A, int64_t lda, int64_t rows, const double *L, int64_t ldl, const double *dinv) {
     if (rows <= 0) return 0;
     if (rows % 32 || (lda & 1) || (ldl & 1) || ((uintptr_t)A & 15) || ((uintptr_t)L & 15)) { fvgp_set_error("trsm_tiles: rows % 32, even leading dimensions, 16-byte alignment"); return -2; }
-    TrsmTilesArgs g{A, (long)lda, L, (long)ldl, dinv, h->chain_stamps, h->chain_seq++, h->chain_yield ? h->cu_yield : nullptr, nullptr, 0};
-    unsigned grid = 0;
-    chain_grid(h, (int)(rows / 32), &g.ticket, &g.nvb, &grid);
-    hipLaunchKernelGGL(trsm_tiles_kernel, dim3(grid), dim3(128), 0, h->stream, g);
+    TrsmTilesArgs g{A, (long)lda, L, (long)ldl, dinv, h->chain_yield ? h->cu_yield : nullptr};
+    hipLaunchKernelGGL(trsm_tiles_kernel, dim3((unsigned)(rows / 32)), dim3(128), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
 }

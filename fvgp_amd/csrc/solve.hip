@@ -471,18 +471,6 @@ __global__ __launch_bounds__(256) void winv_seed_kernel(const double *linv, doub
     }
 }
 
-// dst (rows x cols, row stride ldd) <- src (row stride lds), 16 bytes per thread and trip: the compact copy of the rows below a
-// panel's square (api.hip, panel_factor_square)
-__global__ __launch_bounds__(256) void copy_panel_kernel(const double *src, long lds, double *dst, long ldd, long rows, int cols2) {
-    const long tot = rows * cols2;
-#pragma unroll 4
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
-        const long i = e / cols2;
-        const int j = (int)(e - i * cols2);
-        *reinterpret_cast<double2_t *>(dst + i * ldd + 2 * j) = *reinterpret_cast<const double2_t *>(src + i * lds + 2 * j);
-    }
-}
-
 // posterior mean k^T alpha (gp_posterior.py:158) as a streaming pass over k: partial[chunk][p][c] = sum over the
 // chunk's rows n of K[n][p] * alpha[n][c]; a wave reads 512 contiguous bytes of a row per instruction.  Summed in a
 // fixed order by kt_alpha_reduce_kernel (no atomics: results do not depend on scheduling).
@@ -836,15 +824,6 @@ int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W
     while ((1L << wshift) < w) ++wshift;
     if ((1L << wshift) != w || w > 8192) { fvgp_set_error("block inverses: the width must be 128 times a power of two"); return -5; }
     hipLaunchKernelGGL(winv_seed_kernel, dim3((unsigned)nblk, 8), dim3(256), 0, h->stream, linv, W, wshift);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-int launch_copy_panel(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t rows, int64_t cols) {
-    if (rows <= 0 || cols <= 0) return 0;
-    if ((cols & 1) || (lds & 1) || (ldd & 1) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) { fvgp_set_error("copy_panel: even widths, 16-byte alignment"); return -2; }
-    long blocks = (rows * (cols / 2) + 1023) / 1024; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(copy_panel_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, src, (long)lds, dst, (long)ldd, (long)rows, (int)(cols / 2));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -70,17 +70,23 @@ int fvgp_hip_sync(fvgp_handle *h);
  * the panel chain a few CUs of its own so its small kernels never queue behind the trailing update. */
 int fvgp_hip_stream_create(void **out_stream, int device, int high_priority, const uint32_t *cu_mask, int mask_words);
 int fvgp_hip_stream_destroy(void *stream);
-/* keys: "outer_block" (panel width = K of the trailing update, multiple of 128; default 1024),
- *       "outer_block_big" / "big_threshold" (optional wider panels while more rows than the threshold remain),
- *       "inner_block" (sub-panel width inside panels wider than it: a third block size; 0 = off),
- *       "lookahead" (0/1: factor the next panel on a high-priority side stream under the trailing update),
- *       "outer_block_small" / "small_threshold" (narrower panels, default 512, for the last `small_threshold` rows),
- *       "leaf_yield" / "chain_yield" (0/1, default 1: the trailing update's waves sleep while a leaf / a K = 128 kernel of the
- *       panel chain shares their compute unit), "bwd_sweep" (0/1, default 1: the backward vector sweep in one launch),
- *       "posterior_halves" (0/1, default 1: posterior covariance at 512-1024 points as two halves on two streams),
- *       "profile" (0/1: time the trailing-update launches with HIP events -> fvgp_hip_get_profile);
- *       further tuning / diagnostic keys, all with defaults: INTEGRATION.md section 4.  None of them changes a result bit
- *       except the panel widths (a different, equally valid summation order). */
+/* Every key has a default and a test (tests/test_gpu_primitives.py); none changes a result except where noted "order": another,
+ * equally valid order of the same sums (LAPACK accuracy either way).
+ *   panel widths ("order"): "outer_block" (1024: panel width = K of the trailing update, multiple of 128),
+ *       "outer_block_big" / "big_threshold" (2048 while more than 24576 rows remain), "outer_block_small" / "small_threshold"
+ *       (512 for the last 12288 rows), "inner_block" / "panel_recursive" (how the three-launch chain splits a panel);
+ *   panel chain: "panel_chain" (1: one resident kernel per panel, csrc/chain.hip, for panels with at least "panel_chain_min" = 4096
+ *       rows below their first column; 0: three launches per 128 columns; 2: also for the row-sharded driver's stacked panel) ("order"),
+ *       "leaf_tiles" / "leaf_tiles_rows" / "k128_kernels" / "small_tile_max" / "small_tile_max_update" (kernels of the three-launch
+ *       chain) ("order"), "leaf_yield" / "chain_yield" (1: the trailing update's waves sleep while a workgroup of the chain shares
+ *       their compute unit; chain_yield 2: also for the resident kernel's rows below the square);
+ *   schedule: "lookahead" (0/1) from "lookahead_min" = 4608 padded rows on: the next panel's chain on a high-priority side stream
+ *       under the trailing update; "tile_tables" (1: XCD-balanced block -> tile tables instead of the formula map);
+ *   solves / posterior / gradient: "bwd_sweep" (1: the backward vector sweep in one launch), "block_inverses" (1: the posterior
+ *       substitutes with inverted 1024-blocks) ("order"), "posterior_halves" (1: 512-1024 points as two halves on two streams)
+ *       ("order"), "potri_kminor" (1: POTRI on (M,K) x (N,K) products only) ("order");
+ *   measurement: "profile" (0/1: time the trailing-update launches with HIP events -> fvgp_hip_get_profile), "chain_stamps" /
+ *       "leaf_stamps" (device pointers, 0 = off: in-kernel timestamps of the panel kernel's hand-offs / the leaf's phases). */
 int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value);
 /* out[0] = number of trailing-update launches of the last potrf, out[1] = their summed
  * duration in ms, out[2] = their summed algorithmic flops, out[3] = whole-potrf ms; of the last fused

@@ -111,29 +111,59 @@ def test_backward_sweep_in_one_launch_matches_the_step_kernels(H, n):
         assert np.max(np.abs(out[1][0] - ref)) / np.max(np.abs(ref)) < 1e-11
 
 
-def test_macro_tile_probe_is_bit_identical(H):
-    """The 256 x 128 macro-tile probe kernel (one eight-wave workgroup per CU, option gemm_probe = 9000; measured and not
-    adopted) contracts k in the shipped kernel's order: same bits (33, 65 and 129 K steps: every tail of
-    its three-stage ring)."""
+def test_launch_shape_options_keep_the_result(H):
+    """The options that only pick a launch shape: `tile_tables` (XCD-balanced block -> tile table vs the formula map) and
+    the diagnostic stamp buffers change WHERE and WHEN a tile runs, never its arithmetic: same bits.  `lookahead_min` (look-ahead
+    on / off at this size: two streams and a split trailing update vs one stream) and  `small_tile_max(_update)` = 0 sends the chain's small products to the
+    128-tile kernel, which contracts k in another order: LAPACK accuracy either way.  The diagnostic stamp buffers
+    (`chain_stamps`, `leaf_stamps`) fill when set and change nothing."""
     import torch
     g = torch.Generator(device="cuda"); g.manual_seed(3)
-    for (M, N, K) in ((512, 384, 528), (768, 128, 1040), (256, 256, 2064)):      # K > 512: the shipped path takes its 128-tile kernel too
+    for (M, N, K) in ((1024, 1024, 528), (768, 128, 1040)):
         A = torch.randn(M, K, dtype=torch.float64, device="cuda", generator=g)
         B = torch.randn(N, K, dtype=torch.float64, device="cuda", generator=g)
         C0 = torch.randn(M, N, dtype=torch.float64, device="cuda", generator=g)
         out = {}
         try:
-            for v in (0, 9000):
-                H.set_option("gemm_probe", v)
+            for v in (1, 0):
+                H.set_option("tile_tables", v)
                 C = C0.clone()
                 H.gemm(0, 0, 0, M, N, K, -0.75, A, B, 1.25, C)
                 H.sync()
                 out[v] = C
         finally:
-            H.set_option("gemm_probe", 0)
-        assert torch.equal(out[0], out[9000])
-        ref = -0.75 * A @ B.T + 1.25 * C0
-        assert float((out[9000] - ref).abs().max()) < 1e-11 * K
+            H.set_option("tile_tables", 1)
+        assert torch.equal(out[0], out[1])
+        assert float((out[1] + 0.75 * A @ B.T - 1.25 * C0).abs().max()) < 1e-11 * K
+    from fvgp_amd._lib import pad128
+    n = 5200
+    M_ = _spd(n, 23)
+    Lref = np.tril(sla.cho_factor(M_, lower=True)[0])
+    npad = pad128(n)
+    buf = np.zeros((npad, npad)); buf[:n, :n] = np.tril(M_)
+    got = {}
+    stamps = torch.zeros(8 + 4 * 4096, dtype=torch.int64, device="cuda")
+    lstamps = torch.zeros(64, dtype=torch.int64, device="cuda")
+    try:
+        for name, opts in (("default", {}), ("no_lookahead", {"lookahead_min": 1 << 30}), ("lookahead", {"lookahead_min": 0}),
+                           ("no_small_tiles", {"small_tile_max": 0, "small_tile_max_update": 0}),
+                           ("stamps", {"chain_stamps": stamps.data_ptr(), "leaf_stamps": lstamps.data_ptr()})):
+            for k, v in opts.items():
+                H.set_option(k, v)
+            A = H.to_device(buf)
+            assert H.potrf(A, n) == 0
+            got[name] = np.tril(A.cpu().numpy()[:n, :n])
+            for k, v in dict(lookahead_min=4608, small_tile_max=160, small_tile_max_update=512, chain_stamps=0, leaf_stamps=0).items():
+                H.set_option(k, v)
+    finally:
+        for k, v in dict(lookahead_min=4608, small_tile_max=160, small_tile_max_update=512, chain_stamps=0, leaf_stamps=0).items():
+            H.set_option(k, v)
+    assert np.array_equal(got["default"], got["lookahead"]) and np.array_equal(got["default"], got["stamps"])
+    assert int(stamps[0]) > 0 and int(lstamps[:8].abs().sum()) > 0
+    # (without look-ahead a panel's update is ONE launch instead of two: the next panel's columns may then run on the other tile
+    # size, i.e. in the other k order)
+    for name in ("default", "no_small_tiles", "no_lookahead"):
+        assert np.max(np.abs(got[name] - Lref)) / np.max(np.abs(Lref)) < 1e-13
 
 
 @pytest.mark.parametrize("one_stage", [1, 0])
@@ -639,6 +669,15 @@ def test_posterior_block_inverse_substitution(H, n, P):
         H.sync()
         got[mode] = (mean.cpu().numpy()[:, 0] + np.mean(y), S.cpu().numpy()[:P, :P], var.cpu().numpy())
     H.set_option("block_inverses", 1)
+    if 512 <= Pp <= 1024:            # the two halves of the points on two streams (the default at these sizes) against one stream
+        try:
+            H.set_option("posterior_halves", 0)
+            kx = H.empty(npad, Pp); mean = H.empty(P, 1); var = H.empty(P); S = H.empty(Pp, Pp)
+            H.posterior(0, xd, theta, KV, alpha, 1, H.to_device(xp), kx, mean, var, S)
+            H.sync()
+        finally:
+            H.set_option("posterior_halves", 1)
+        assert np.max(np.abs(S.cpu().numpy()[:P, :P] - got[1][1])) < 1e-11 * theta[0]
     for mode in (1, 0):
         m, S, v = got[mode]
         np.testing.assert_allclose(m, want_m, rtol=1e-8, atol=1e-9)

@@ -1,6 +1,6 @@
 """Same-box A/B of one library option on the log-likelihood evaluation: alternates the values round by round in ONE process.
   python tools/option_ab.py leaf_yield 0,1 8000,20000,50000 [reps]
-  python tools/option_ab.py panel_square=0/panel_square=1,update_reserve=16 - 20000     (whole configurations, '/'-separated)
+  python tools/option_ab.py panel_chain=0/panel_chain=1,panel_chain_min=0 - 20000     (whole configurations, '/'-separated)
 Prints the median and the minimum of the evaluation time per (size, value)."""
 import os
 import sys

@@ -6,8 +6,6 @@ import torch
 from fvgp_amd import _lib
 
 H = _lib.Handle(0)
-if len(sys.argv) > 1:
-    H.set_option("gemm_direct", int(sys.argv[1]))
 
 
 def timeit(fn, reps=3):
