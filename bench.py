@@ -142,6 +142,18 @@ def config_records():
                  "posterior_cov_bound_ms": 1e3 * (n * n * 1000.0 + 2.0 * n * 1000.0 ** 2) / peak}
     del gp
     torch.cuda.empty_cache()
+    # the training loop's sizes (gp_mcmc.py:96-224 calls log_likelihood(theta) 10 000 times; C1 is N=500, d=1): wall time of the
+    # public call, best of five
+    small = {}
+    for n, d in ((500, 1), (2000, 3), (8000, 3)):
+        x, y = synth(n, d)
+        ths = np.array([1.0] + [0.2 if d == 1 else 0.3] * d)
+        gp = fvgp_amd.GP(x, y, init_hyperparameters=ths, noise_variances=np.full(n, 0.01), kernel_function="rbf_ard")
+        ms = best(lambda: gp.log_likelihood(ths * 1.01), reps=5)
+        small[f"N={n} d={d}"] = {"loglik_ms": ms, "bound_ms": 1e3 * n ** 3 / 3 / peak, "frac": (1e3 * n ** 3 / 3 / peak) / ms}
+        del gp
+    out["small_N"] = {"workload": "RBF log_likelihood(theta) at the training loop's sizes (C1: N=500 d=1)", **small}
+    torch.cuda.empty_cache()
     # C3
     n = 50000
     x, y = synth(n, 3)
@@ -186,13 +198,22 @@ def config_records():
         sh = ShardedGP(x, y, nv, kernel="rbf_ard", panel=1024, rank=0, world=1, force_collectives=True, collectives="rccl")
         svals = []
         sharded = best(lambda: svals.append(sh.log_likelihood(th * 1.01)[0]), reps=1)
+        # the collectives of ONE more evaluation, timed with events on the chain stream, i.e. beside the rank's trailing update
+        # (fvgp_hip_comm_profile); the same calls alone on the idle chip: profiles/r04_rccl_beside_update.txt
+        sh.ops.set_option("profile", 1)
+        sh.collective_summary()
+        sh.log_likelihood(th * 1.01)
+        torch.cuda.synchronize()
+        cs = sh.collective_summary()
+        sh.ops.set_option("profile", 0)
         flops = float(n) ** 3 / 3
         out["C4_size_one_gpu"] = {
             "workload": "N=100000 d=3 RBF log_likelihood(theta) on ONE MI355X: fused driver vs the row-sharded driver at one rank "
                         "(panel buffers, diagonal-block gather and panel all-gather through a one-rank RCCL communicator)",
             "fused_ms": fused, "fused_tflops": flops / fused / 1e9, "sharded_world1_rccl_ms": sharded,
             "sharded_world1_rccl_tflops": flops / sharded / 1e9, "bound_ms": 1e3 * flops / peak,
-            "rel_diff": abs(vals[-1] - svals[-1]) / abs(vals[-1])}
+            "rel_diff": abs(vals[-1] - svals[-1]) / abs(vals[-1]),
+            "collectives": {k: {"calls": v[0], "bytes_from_peers": v[1], "ms_on_chain_stream_beside_update": v[2]} for k, v in cs.items()}}
         del sh
         torch.cuda.empty_cache()
     except Exception as e:                      # noqa: BLE001 -- a side record must not take the headline down
