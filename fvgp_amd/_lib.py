@@ -29,7 +29,8 @@ SYMBOLS = [
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower", "fvgp_hip_trace_dot", "fvgp_hip_colsumsq", "fvgp_hip_add_matrix", "fvgp_hip_dot", "fvgp_hip_coldot",
     "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
     "fvgp_hip_grad_trace_cols", "fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy", "fvgp_hip_all_reduce",
-    "fvgp_hip_all_gather", "fvgp_hip_comm_profile", "fvgp_hip_dist_workspace", "fvgp_hip_loglik_dist",
+    "fvgp_hip_all_gather", "fvgp_hip_comm_profile", "fvgp_hip_dist_workspace", "fvgp_hip_loglik_dist", "fvgp_hip_dist_scratch", "fvgp_hip_solve_dist",
+    "fvgp_hip_posterior_dist", "fvgp_hip_grad_dist",
 ]
 
 
@@ -67,11 +68,44 @@ def bind_dist(L):
     L.fvgp_hip_all_gather.argtypes = [c_p, c_p, c_p, c_l]
     L.fvgp_hip_dist_workspace.argtypes = [ctypes.POINTER(DistDesc), ctypes.POINTER(c_l)]
     L.fvgp_hip_loglik_dist.argtypes = [c_p, ctypes.POINTER(DistDesc), P_d, c_i, P_d, P_i]
-    for s in ("fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_profile", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy",
+    L.fvgp_hip_dist_scratch.argtypes = [ctypes.POINTER(DistDesc), c_i, c_l, c_l]
+    L.fvgp_hip_dist_scratch.restype = c_l
+    L.fvgp_hip_solve_dist.argtypes = [c_p, ctypes.POINTER(DistDesc), c_p, c_p]
+    L.fvgp_hip_posterior_dist.argtypes = [c_p, ctypes.POINTER(DistDesc), P_d, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p]
+    L.fvgp_hip_grad_dist.argtypes = [c_p, ctypes.POINTER(DistDesc), P_d, c_i, c_p, c_i, c_l, P_d, c_p, c_p]
+    for s in ("fvgp_hip_solve_dist", "fvgp_hip_posterior_dist", "fvgp_hip_grad_dist", "fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_profile", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy",
               "fvgp_hip_all_reduce", "fvgp_hip_all_gather", "fvgp_hip_dist_workspace", "fvgp_hip_loglik_dist"):
         if hasattr(L, s):
             getattr(L, s).restype = c_i
     return L
+
+
+class DistCalls:
+    """The row-sharded entry points that follow a kept factorisation (include/fvgp_hip.h: fvgp_hip_solve_dist, _posterior_dist,
+    _grad_dist), as methods over `self._dist_lib()` (the loaded library) and `self._h` (its handle) with `self._dist_check` as the
+    status check: the product's Handle binds libfvgp_hip.so, the CPU tests' stand-in binds the CPU twin of the ABI the same way.
+    Tensors are anything with data_ptr()."""
+
+    def dist_scratch(self, desc, what, npred=0, slab=TILE):
+        n = self._dist_lib().fvgp_hip_dist_scratch(ctypes.byref(desc), int(what), int(npred), int(slab))
+        if n < 0:
+            raise ValueError("fvgp_hip_dist_scratch: bad arguments")
+        return int(n)
+
+    def solve_dist(self, desc, alpha_out, ws):
+        self._dist_check(self._dist_lib().fvgp_hip_solve_dist(self._h, ctypes.byref(desc), _ptr(alpha_out), _ptr(ws)), "fvgp_hip_solve_dist")
+
+    def posterior_dist(self, desc, theta, xpred, npred, k_pre, kk_pre, alpha, mean_out, S_out, ws):
+        t, tp, nt = _theta(theta)
+        self._dist_check(self._dist_lib().fvgp_hip_posterior_dist(self._h, ctypes.byref(desc), tp, nt, _ptr(xpred), int(npred), _ptr(k_pre), _ptr(kk_pre),
+                                                                  _ptr(alpha), _ptr(mean_out), _ptr(S_out), _ptr(ws)), "fvgp_hip_posterior_dist")
+
+    def grad_dist(self, desc, theta, alpha, component, slab, diag_out, ws):
+        t, tp, nt = _theta(theta)
+        g = (ctypes.c_double * nt)()
+        self._dist_check(self._dist_lib().fvgp_hip_grad_dist(self._h, ctypes.byref(desc), tp, nt, _ptr(alpha), int(component), int(slab), g,
+                                                             _ptr(diag_out), _ptr(ws)), "fvgp_hip_grad_dist")
+        return np.array(list(g))
 
 
 class HipExtensionError(RuntimeError):
@@ -167,7 +201,7 @@ def lib():
     L.fvgp_hip_grad_trace_cols.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_l, c_l, c_l, c_p, c_l, c_p, P_d]
     bind_dist(L)
     for s in SYMBOLS:
-        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_workspace_bytes"):
+        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_workspace_bytes", "fvgp_hip_dist_scratch"):
             getattr(L, s).restype = c_i
     _lib = L
     return L
@@ -215,7 +249,7 @@ def destroy_stream(stream):
     _check(lib().fvgp_hip_stream_destroy(ctypes.c_void_p(stream)), "fvgp_hip_stream_destroy")
 
 
-class Handle:
+class Handle(DistCalls):
     """One device + one stream.  Thin, argument-for-argument wrapper of the C ABI; tensors are
     torch CUDA fp64 tensors used purely as device-memory containers."""
 
@@ -282,7 +316,7 @@ class Handle:
         out = (ctypes.c_double * 8)()
         _check(lib().fvgp_hip_get_profile(self._h, out), "fvgp_hip_get_profile")
         return {"launches": out[0], "ms": out[1], "flops": out[2], "potrf_ms": out[3],
-                "kmat_ms": out[4], "kmat_bytes": out[5], "tail_ms": out[6]}
+                "kmat_ms": out[4], "kmat_bytes": out[5], "tail_ms": out[6], "host_enqueue_ms": out[7]}
 
     # -- ABI calls -----------------------------------------------------------------------------
     def kmat(self, kernel_id, x1, x2, theta, K, vdiag=None, uplo=FULL, pad=PAD_NONE):
@@ -390,6 +424,13 @@ class Handle:
 
     def all_gather(self, send, recv):
         _check(lib().fvgp_hip_all_gather(self._h, _ptr(send), _ptr(recv), send.numel()), "fvgp_hip_all_gather")
+
+    def _dist_lib(self):
+        return lib()
+
+    @staticmethod
+    def _dist_check(rc, what):
+        _check(rc, what)
 
     def comm_profile(self):
         out = (ctypes.c_double * 6)()

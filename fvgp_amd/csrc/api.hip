@@ -179,7 +179,7 @@ int fvgp_hip_get_profile(fvgp_handle *h, double *out) {
         h->rs_used = 0; h->rs_flops.clear();
     }
     out[0] = h->prof_launches; out[1] = h->prof_ms; out[2] = h->prof_flops; out[3] = h->prof_total_ms;
-    out[4] = h->prof_kmat_ms; out[5] = h->prof_kmat_bytes; out[6] = h->prof_tail_ms; out[7] = 0.0;
+    out[4] = h->prof_kmat_ms; out[5] = h->prof_kmat_bytes; out[6] = h->prof_tail_ms; out[7] = h->prof_host_enqueue_ms;
     return 0;
 }
 

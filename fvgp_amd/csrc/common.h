@@ -107,6 +107,7 @@ struct fvgp_handle {
     std::vector<hipEvent_t> ev;
     std::vector<double> ev_flops;
     double prof_launches = 0, prof_ms = 0, prof_flops = 0, prof_total_ms = 0;
+    double prof_host_enqueue_ms = 0;   // row-sharded evaluation: host time to enqueue one evaluation (no synchronisation inside)
     double prof_kmat_ms = 0, prof_kmat_bytes = 0, prof_tail_ms = 0;   // fused evaluation: assembly, everything after the factorisation
     hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};
     // row-sharded trailing updates timed since the last get_profile (option "profile")

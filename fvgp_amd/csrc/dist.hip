@@ -6,6 +6,7 @@
 // the trailing updates on its main stream, RCCL called directly on the chain stream.  librccl is opened at run time
 // (dlopen) by fvgp_hip_comm_init only: a single-GPU process never loads it.
 #include "common.h"
+#include <chrono>
 #include "dist_driver.h"
 #include <dlfcn.h>
 #include <math.h>
@@ -87,6 +88,11 @@ int timed_collective(fvgp_handle *h, int kind, double bytes, hipStream_t stream,
     return 0;
 }
 
+__global__ void dist_identity_kernel(double *p, long ld, long n) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * n) { const long i = e / n, j = e - i * n; p[i * ld + j] = i == j ? 1.0 : 0.0; }
+}
+
 // the operations dist_driver.h sequences, on the handle's two streams
 struct HipBackend {
     fvgp_handle *h;
@@ -104,6 +110,26 @@ struct HipBackend {
     }
     int zero(double *p, int64_t count) {
         HIPCHK(hipMemsetAsync(p, 0, (size_t)count * sizeof(double), h->stream));
+        return 0;
+    }
+    int zero2d(double *p, int64_t ld, int64_t rows, int64_t cols) {
+        HIPCHK(hipMemset2DAsync(p, (size_t)ld * sizeof(double), 0, (size_t)cols * sizeof(double), (size_t)rows, h->stream));
+        return 0;
+    }
+    int identity2d(double *p, int64_t ld, int64_t n) {          // the n x n block at p (leading dimension ld) <- I
+        hipLaunchKernelGGL(dist_identity_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, h->stream, p, (long)ld, (long)n);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    int identity(double *p, int64_t n) { return identity2d(p, n, n); }
+    int to_device(double *dst, const double *src_host, int64_t count) {
+        HIPCHK(hipMemcpyAsync(dst, src_host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return 0;
+    }
+    int to_host(double *dst_host, const double *src, int64_t count) {
+        HIPCHK(hipMemcpyAsync(dst_host, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
         return 0;
     }
     int copy2d(double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int64_t cols) {
@@ -267,7 +293,9 @@ int fvgp_hip_loglik_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *
     HipBackend b{h, h->stream, h->side};
     HIPCHK(hipMemsetAsync(d->info_dev, 0, (size_t)g.npan * sizeof(int), b.mainS));
     HIPCHK(hipMemsetAsync(d->logdet_dev, 0, (size_t)g.npan * sizeof(double), b.mainS));
+    const auto host_t0 = std::chrono::steady_clock::now();
     rc = fvgp_dist::evaluate(b, *d, theta, ntheta);
+    h->prof_host_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     h->stream = b.mainS;
     if (rc) return rc;
     // scalars: |z|^2 over the appended rows, the per-panel log-dets, the per-panel info -- one host round trip
@@ -286,6 +314,63 @@ int fvgp_hip_loglik_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *
     out_host[1] = logdet;
     out_host[2] = quad;
     return 0;
+}
+
+static int dist_after_factor_check(fvgp_handle *h, const fvgp_dist_desc *d) {
+    if (!h) return -1;
+    if (!d) return -2;
+    if (d->n <= 0 || d->d < 1 || d->d > FVGP_MAX_DIM || d->panel < FVGP_TILE || d->panel % FVGP_TILE || !d->A || !d->x_all) return -2;
+    if (d->nranks != h->coll_nranks || d->rank != h->coll_rank) {
+        fvgp_set_error("dist: rank / nranks of the descriptor differ from the handle's communicator (fvgp_hip_comm_init)"); return -2;
+    }
+    if ((d->nranks > 1 || d->force_general) && !d->Dfac) return -2;
+    if (d->nranks > 1 && (!h->coll.all_gather || !h->coll.all_reduce_sum)) {
+        fvgp_set_error("no collectives bound to this handle: call fvgp_hip_comm_init first"); return 2003;
+    }
+    if (!d->keep_factor) { fvgp_set_error("dist: the last evaluation did not keep its factor (keep_factor = 0)"); return -2; }
+    return 0;
+}
+
+int64_t fvgp_hip_dist_scratch(const fvgp_dist_desc *d, int what, int64_t npred, int64_t slab) {
+    if (!d || what < 0 || what > 2 || npred < 0 || (what == 2 && (slab < FVGP_TILE || slab % FVGP_TILE))) return -1;
+    return fvgp_dist::scratch_doubles(*d, what, npred, slab);
+}
+
+int fvgp_hip_solve_dist(fvgp_handle *h, const fvgp_dist_desc *d, double *alpha_out, double *ws) {
+    int rc = dist_after_factor_check(h, d); if (rc) return rc;
+    if (!alpha_out) return -3;
+    if (!ws) return -4;
+    HIPCHK(hipSetDevice(h->device));
+    HipBackend b{h, h->stream, h->side};
+    return fvgp_dist::solve_backward(b, h, *d, alpha_out, ws);
+}
+
+int fvgp_hip_posterior_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *theta, int ntheta, const double *xpred, int64_t npred,
+                            const double *k_pre, const double *kk_pre, const double *alpha, double *mean_out, double *S_out, double *ws) {
+    int rc = dist_after_factor_check(h, d); if (rc) return rc;
+    if (!theta) return -3;
+    if (npred <= 0) return -6;
+    if (!xpred && !(k_pre && (kk_pre || !S_out || d->rank != 0))) return -5;
+    if (!alpha) return -9;
+    if (!mean_out) return -10;
+    if (!ws) return -12;
+    HIPCHK(hipSetDevice(h->device));
+    HipBackend b{h, h->stream, h->side};
+    return fvgp_dist::posterior(b, h, *d, theta, ntheta, xpred, npred, k_pre, kk_pre, alpha, mean_out, S_out, ws);
+}
+
+int fvgp_hip_grad_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *theta, int ntheta, const double *alpha, int component,
+                       int64_t slab, double *grad_host, double *diag_out, double *ws) {
+    int rc = dist_after_factor_check(h, d); if (rc) return rc;
+    if (!theta || ntheta < 1 || ntheta > FVGP_MAX_DIM + 1) return -3;
+    if (!alpha) return -5;
+    if (component < 0 || component >= FVGP_TILE) return -6;
+    if (slab < FVGP_TILE || slab % FVGP_TILE) return -7;
+    if (!grad_host) return -8;
+    if (!ws) return -10;
+    HIPCHK(hipSetDevice(h->device));
+    HipBackend b{h, h->stream, h->side};
+    return fvgp_dist::gradient(b, h, *d, theta, ntheta, alpha, component, slab, grad_host, diag_out, ws);
 }
 
 }  // extern "C"

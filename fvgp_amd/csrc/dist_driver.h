@@ -187,4 +187,198 @@ static int evaluate(B &b, const fvgp_dist_desc &d, const double *theta, int nthe
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// After the factorisation: what the reference's distributed mode answers through the same object (gp_kv.py:574-593,
+// gp_posterior.py:139-288, tests/test_fvgp.py:3112-3149) -- KVinvY, the posterior, the gradient -- on the factor that
+// evaluate(keep_factor = 1) left: the rank's block rows of L in A, every factored diagonal block replicated (Dfac).
+// The operations are the library's own ABI entries (gemm, triangular solves, the trace pass) on the handle's stream; the
+// backend only moves memory.  `ws`: caller-owned scratch, sizes from scratch_doubles().
+
+struct PanelRows { int64_t la, lb, first, J0, Jend; };
+// local blocks [la, lb) are this rank's rows of panel J; they sit at positions first, first + P, ... of the panel's 128-row blocks
+static inline PanelRows panel_rows(const Geom &g, int J) {
+    PanelRows r;
+    r.J0 = g.bnd(J); r.Jend = g.bnd(J + 1);
+    const int64_t b0 = r.J0 / T128, b1 = r.Jend / T128;
+    r.la = ceil_pos(b0 - g.p, g.P);
+    r.lb = ceil_pos(b1 - g.p, g.P); if (r.lb < r.la) r.lb = r.la;
+    r.first = r.la * g.P + g.p - b0;
+    return r;
+}
+static inline const double *diag_block(const fvgp_dist_desc &d, const Geom &g, int J, int64_t *ld) {
+    if (g.P > 1 || d.force_general) { *ld = g.NB; return d.Dfac + (int64_t)J * g.NB * g.NB; }
+    *ld = g.ld; return d.A + g.bnd(J) * g.ld + g.bnd(J);
+}
+
+enum { SCRATCH_SOLVE = 0, SCRATCH_POSTERIOR = 1, SCRATCH_GRADIENT = 2 };
+static inline int64_t pad128_(int64_t n) { return (n + T128 - 1) / T128 * T128; }
+static inline int64_t scratch_doubles(const fvgp_dist_desc &d, int what, int64_t npred, int64_t slab) {
+    const Geom g = geometry(d);
+    const int64_t rows = g.nb_max * T128, pp = pad128_(npred);
+    const int64_t solve = 2 * g.np * T128 + 3 * g.NB * T128 + T128 * T128;
+    if (what == SCRATCH_SOLVE) return solve;
+    if (what == SCRATCH_POSTERIOR) return rows * pp + rows * T128 + g.NB * pp;                       // k, alpha's local rows, the panel's rows of the solve
+    const int64_t nt = g.np / T128;
+    return rows * g.np + g.np * slab + g.NB * g.np + nt * (slab / T128) * (d.d + 2) + 64;            // inv(L)'s rows, one slab of the Gram matrix, the solve's panel, trace partials
+}
+
+// KVinvY = L^-T z (the second half of cho_solve), replicated: alpha (np x 128, row-major; columns >= ncol carry zeros).
+// Column sweep over the panels from the last: the rows of panel J are solved against the replicated diagonal block
+// (redundantly, no traffic), then every rank adds L[its rows of J, columns left of J]^T alpha_J to its own partial sum; one
+// all-reduce of an NB x 128 slice per panel completes the right-hand side of the next.
+template <class B>
+static int solve_backward(B &b, fvgp_handle *h, const fvgp_dist_desc &d, double *alpha, double *ws) {
+    const Geom g = geometry(d);
+    double *Y = ws, *S = Y + g.np * T128, *G = S + g.np * T128, *Sg = G + g.NB * T128, *mine = Sg + g.NB * T128, *I = mine + g.NB * T128;
+    int rc = b.identity(I, T128); if (rc) return rc;
+    // z^T sits in the extra block row of A: Y (np x 128) = its transpose
+    rc = fvgp_hip_gemm(h, 1, 1, 0, g.np, T128, T128, 1.0, d.A + g.zrow * g.ld, g.ld, I, T128, 0.0, Y, T128); if (rc) return rc;
+    rc = b.zero(S, g.np * T128); if (rc) return rc;
+    for (int J = g.npan - 1; J >= 0; --J) {
+        const PanelRows r = panel_rows(g, J);
+        const int64_t w = r.Jend - r.J0;
+        rc = b.copy2d(Sg, T128, S + r.J0 * T128, T128, w, T128); if (rc) return rc;
+        rc = fvgp_hip_all_reduce(h, Sg, w * T128); if (rc) return rc;
+        rc = b.copy2d(G, T128, Y + r.J0 * T128, T128, w, T128); if (rc) return rc;
+        rc = fvgp_hip_add_matrix(h, G, T128, Sg, T128, w, T128, -1.0); if (rc) return rc;      // z_J - the sum of the ranks' parts
+        int64_t ldd; const double *D = diag_block(d, g, J, &ldd);
+        rc = fvgp_hip_invalidate_factor(h); if (rc) return rc;
+        rc = fvgp_hip_trsm_lower_t(h, D, w, ldd, G, T128, T128); if (rc) return rc;
+        rc = b.copy2d(alpha + r.J0 * T128, T128, G, T128, w, T128); if (rc) return rc;
+        if (r.lb > r.la && r.J0 > 0) {
+            for (int64_t l = r.la; l < r.lb; ++l) {
+                rc = b.copy2d(mine + (l - r.la) * T128 * T128, T128, G + (r.first + (l - r.la) * g.P) * T128 * T128, T128, T128, T128);
+                if (rc) return rc;
+            }
+            rc = fvgp_hip_gemm(h, 1, 1, 0, r.J0, T128, (r.lb - r.la) * T128, 1.0, d.A + r.la * T128 * g.ld, g.ld, mine, T128, 1.0, S, T128);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+// Bm <- this rank's rows of L^-1 B_global for a right-hand side distributed by rows like the matrix itself (Bm: nb_max*128
+// local rows x m columns, m a multiple of 128).  Per panel: the panel's rows are summed to every rank, solved against the
+// replicated diagonal block, and applied to the rank's later rows as one GEMM.  triangular: B_global is lower triangular (the
+// identity: inv(L)), so panel J only carries its first Jend columns.  Gs: NB x m doubles.
+template <class B>
+static int forward_trsm(B &b, fvgp_handle *h, const fvgp_dist_desc &d, const Geom &g, double *Bm, int64_t ldb, int64_t m, bool triangular, double *Gs) {
+    int rc;
+    for (int J = 0; J < g.npan; ++J) {
+        const PanelRows r = panel_rows(g, J);
+        const int64_t w = r.Jend - r.J0;
+        const int64_t mJ = triangular ? (m < r.Jend ? m : r.Jend) : m;
+        double *G = Gs;                                                     // w x mJ, contiguous: the collective needs it
+        if (g.P > 1) {
+            rc = b.zero(G, w * mJ); if (rc) return rc;
+            for (int64_t l = r.la; l < r.lb; ++l) {
+                rc = b.copy2d(G + (r.first + (l - r.la) * g.P) * T128 * mJ, mJ, Bm + l * T128 * ldb, ldb, T128, mJ); if (rc) return rc;
+            }
+            rc = fvgp_hip_all_reduce(h, G, w * mJ); if (rc) return rc;
+        } else {
+            rc = b.copy2d(G, mJ, Bm + r.J0 * ldb, ldb, w, mJ); if (rc) return rc;
+        }
+        int64_t ldd; const double *D = diag_block(d, g, J, &ldd);
+        rc = fvgp_hip_invalidate_factor(h); if (rc) return rc;
+        rc = fvgp_hip_trsm_lower(h, D, w, ldd, G, mJ, mJ); if (rc) return rc;
+        for (int64_t l = r.la; l < r.lb; ++l) {
+            rc = b.copy2d(Bm + l * T128 * ldb, ldb, G + (r.first + (l - r.la) * g.P) * T128 * mJ, mJ, T128, mJ); if (rc) return rc;
+        }
+        const int64_t below = (g.nb_max - r.lb) * T128;
+        if (below > 0) {
+            rc = fvgp_hip_gemm(h, 0, 1, 0, below, mJ, w, -1.0, d.A + r.lb * T128 * g.ld + r.J0, g.ld, G, mJ, 1.0, Bm + r.lb * T128 * ldb, ldb);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+// this rank's rows of a matrix whose rows are the global rows: block l <- src block l * P + p (zero beyond the last block)
+template <class B>
+static int local_rows(B &b, const Geom &g, double *dst, int64_t ldd, const double *src, int64_t lds, int64_t cols) {
+    for (int64_t l = 0; l < g.nb_max; ++l) {
+        const int64_t gb = l * g.P + g.p;
+        const int rc = gb < g.nblk ? b.copy2d(dst + l * T128 * ldd, ldd, src + gb * T128 * lds, lds, T128, cols) : b.zero2d(dst + l * T128 * ldd, ldd, T128, cols);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// k^T KVinvY and kk - k^T KV^-1 k (gp_posterior.py:139-182,229-288) at the factored hyperparameters: every rank assembles its
+// own rows of k(x_data, x_pred) (or takes them from the caller: k_pre, host kernel callables); the mean and V^T V (V = L^-1 k)
+// are summed over the ranks.  alpha: KVinvY (np x 128, replicated).  mean_out: pp x 128, S_out: pp x pp or null (both device,
+// replicated; pp = padded_dim(npred)); kk_pre: the caller's k(x_pred, x_pred) (pp x pp, only read on rank 0) or null.
+template <class B>
+static int posterior(B &b, fvgp_handle *h, const fvgp_dist_desc &d, const double *theta, int ntheta, const double *xpred, int64_t npred,
+                     const double *k_pre, const double *kk_pre, const double *alpha, double *mean_out, double *S_out, double *ws) {
+    const Geom g = geometry(d);
+    const int64_t rows = g.nb_max * T128, pp = pad128_(npred);
+    double *k = ws, *a_loc = k + rows * pp, *Gs = a_loc + rows * T128;
+    int rc;
+    if (k_pre) { rc = b.copy2d(k, pp, k_pre, pp, rows, pp); if (rc) return rc; }
+    else {
+        rc = b.zero(k, rows * pp); if (rc) return rc;
+        for (int64_t l = 0; l < g.nb_max; ++l) {
+            const int64_t r0 = (l * g.P + g.p) * T128;
+            int64_t cnt = g.n - r0; if (cnt > T128) cnt = T128;
+            if (cnt <= 0) continue;
+            rc = fvgp_hip_kmat(h, d.kernel_id, d.x_all + r0 * d.d, cnt, xpred, npred, d.d, theta, ntheta, nullptr, k + l * T128 * pp, pp, FVGP_FULL, 0);
+            if (rc) return rc;
+        }
+    }
+    rc = local_rows(b, g, a_loc, T128, alpha, T128, T128); if (rc) return rc;
+    rc = fvgp_hip_gemm(h, 1, 1, 0, pp, T128, rows, 1.0, k, pp, a_loc, T128, 0.0, mean_out, T128); if (rc) return rc;
+    rc = fvgp_hip_all_reduce(h, mean_out, pp * T128); if (rc) return rc;
+    if (!S_out) return 0;
+    rc = forward_trsm(b, h, d, g, k, pp, pp, false, Gs); if (rc) return rc;
+    rc = b.zero(S_out, pp * pp); if (rc) return rc;
+    if (g.p == 0) {
+        if (kk_pre) { rc = b.copy2d(S_out, pp, kk_pre, pp, pp, pp); if (rc) return rc; }
+        else { rc = fvgp_hip_kmat(h, d.kernel_id, xpred, npred, xpred, npred, d.d, theta, ntheta, nullptr, S_out, pp, FVGP_FULL, 0); if (rc) return rc; }
+    }
+    rc = fvgp_hip_gemm(h, 1, 1, 0, pp, pp, rows, -1.0, k, pp, k, pp, 1.0, S_out, pp); if (rc) return rc;
+    return fvgp_hip_all_reduce(h, S_out, pp * pp);
+}
+
+// 1/2 (tr(KV^-1 dK_i) - b^T dK_i b), b = KVinvY[:, component] (gp_marginal_likelihood.py:262-300) for the kernel-owned
+// hyperparameters.  inv(L) is built by rows with the distributed forward solve (N^2 / P doubles per rank); the Gram matrix of
+// the rank's rows (the sum over ranks is KV^-1, never formed) is walked in column slabs of `slab` columns, traced by the fused
+// pass and dropped; the (ntheta,) partial results are summed over the ranks.  grad_host: ntheta doubles; diag_out: np doubles
+// (device, replicated: diag(KV^-1), the gradients of noise-function hyperparameters need it) or null.
+template <class B>
+static int gradient(B &b, fvgp_handle *h, const fvgp_dist_desc &d, const double *theta, int ntheta, const double *alpha, int component,
+                    int64_t slab, double *grad_host, double *diag_out, double *ws) {
+    const Geom g = geometry(d);
+    const int64_t rows = g.nb_max * T128, np = g.np;
+    double *W = ws, *Gm = W + rows * np, *Gs = Gm + np * slab, *partial = Gs + g.NB * np, *gdev = partial + (np / T128) * (slab / T128) * (d.d + 2);
+    int rc = b.zero(W, rows * np); if (rc) return rc;
+    for (int64_t l = 0; l < g.nb_max; ++l) {                                // this rank's rows of the identity
+        const int64_t gb = l * g.P + g.p;
+        if (gb < g.nblk) { rc = b.identity2d(W + l * T128 * np + gb * T128, np, T128); if (rc) return rc; }
+    }
+    rc = forward_trsm(b, h, d, g, W, np, np, true, Gs); if (rc) return rc;
+    for (int i = 0; i < ntheta; ++i) grad_host[i] = 0.0;
+    double part[FVGP_MAX_DIM + 2];
+    for (int64_t c0 = 0; c0 < np; c0 += slab) {
+        const int64_t wc = slab < np - c0 ? slab : np - c0;
+        // rows >= c0 of the slab: (W^T W)[c0:, c0:c0+wc] = W[:, c0:]^T W[:, c0:c0+wc]
+        rc = fvgp_hip_gemm(h, 1, 1, 0, np - c0, wc, rows, 1.0, W + c0, np, W + c0, np, 0.0, Gm + c0 * slab, slab); if (rc) return rc;
+        if (c0 < g.n) {
+            const int64_t nc = wc < g.n - c0 ? wc : g.n - c0;
+            rc = fvgp_hip_grad_trace_cols(h, d.kernel_id, d.x_all, g.n, d.d, theta, ntheta, Gm, slab, c0, nc,
+                                          g.p == 0 ? alpha + component : nullptr, T128, partial, part);
+            if (rc) return rc;
+            for (int i = 0; i < ntheta; ++i) grad_host[i] += part[i];
+        }
+    }
+    rc = b.to_device(gdev, grad_host, ntheta); if (rc) return rc;
+    rc = fvgp_hip_all_reduce(h, gdev, ntheta); if (rc) return rc;
+    rc = b.to_host(grad_host, gdev, ntheta); if (rc) return rc;
+    if (diag_out) {
+        rc = fvgp_hip_colsumsq(h, W, rows, np, np, diag_out); if (rc) return rc;
+        rc = fvgp_hip_all_reduce(h, diag_out, np); if (rc) return rc;
+    }
+    return 0;
+}
+
 }  // namespace fvgp_dist

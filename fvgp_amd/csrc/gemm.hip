@@ -305,7 +305,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         // 64-cycle MFMA: 130-250 us for a leaf instead of 37.  It raises its CU's counter; every wave here reads that word once
         // per K step with a scalar load (no vector-ALU work: issued behind the step's LDS reads, long landed when the step's
         // MFMAs are through) and sleeps while it is up.  Bounded: a wave sleeps at most ~1 ms per tile whatever the counter says.
+#ifdef FVGP_NO_YIELD
+        constexpr bool YIELD = false;             // (A/B build: tools/build_variant.sh noyield -DFVGP_NO_YIELD)
+#else
         constexpr bool YIELD = ROLE == 1;
+#endif
         const int *yp = nullptr;
         int ybudget = 256;
         if constexpr (YIELD) yp = cu_yield_slot(const_cast<int *>(g.yield));

@@ -77,33 +77,26 @@ class HipOps:
     def kmat(self, kernel_id, x1, x2, theta, out, vdiag=None, pad=_lib.PAD_ZERO):
         self.H.kmat(kernel_id, x1, x2, theta, out, vdiag=vdiag, pad=pad)
 
-    def gemm(self, a_kmajor, b_nmajor, lower, M, N, K, alpha, A, B, beta, C):
-        self.H.gemm(a_kmajor, b_nmajor, lower, M, N, K, alpha, A, B, beta, C)
-
-    def trsm_lower(self, L, n, B, nrhs):
-        """B <- L^-1 B with a factored diagonal block this object keeps across evaluations: the handle's cached block
-        inverses are keyed on the address, so they are dropped first"""
-        self.H.invalidate_factor()
-        self.H.trsm_lower(L, n, B, nrhs)
-
-    def trsm_lower_t(self, L, n, B, nrhs):
-        self.H.invalidate_factor()
-        self.H.trsm_lower_t(L, n, B, nrhs)
-
-    def grad_trace_cols(self, kernel_id, x, theta, W, col0, ncols, b, partial):
-        return self.H.grad_trace_cols(kernel_id, x, theta, W, col0, ncols, b, partial)
-
     def add_matrix(self, A, B, alpha=1.0):
         self.H.add_matrix(A, B, alpha)
-
-    def colsumsq(self, V, out):
-        self.H.colsumsq(V, out)
 
     def dist_workspace(self, desc):
         return self.H.dist_workspace(desc)
 
     def loglik_dist(self, desc, theta):
         return self.H.loglik_dist(desc, theta)
+
+    def dist_scratch(self, desc, what, npred=0, slab=TILE):
+        return self.H.dist_scratch(desc, what, npred, slab)
+
+    def solve_dist(self, desc, alpha_out, ws):
+        self.H.solve_dist(desc, alpha_out, ws)
+
+    def posterior_dist(self, desc, theta, xpred, npred, k_pre, kk_pre, alpha, mean_out, S_out, ws):
+        self.H.posterior_dist(desc, theta, xpred, npred, k_pre, kk_pre, alpha, mean_out, S_out, ws)
+
+    def grad_dist(self, desc, theta, alpha, component, slab, diag_out, ws):
+        return self.H.grad_dist(desc, theta, alpha, component, slab, diag_out, ws)
 
     def all_reduce(self, t):
         self.H.all_reduce(t)
@@ -324,22 +317,6 @@ class ShardedGP:
                 o.add_matrix(A[:self.nv, :self.n], o.to_device(self.noise_matrix[self.gidx[:self.nv]]))
         self._desc.preassembled = 1
 
-    def _diag_block(self, J):
-        """the factored diagonal block of panel J (lower triangle), on this rank"""
-        J0, Jend = self.bnd[J], self.bnd[J + 1]
-        if not self.general:
-            return self.A[J0:Jend, J0:Jend]
-        return self._Dfac[J, :Jend - J0, :Jend - J0]
-
-    def _panel_rows(self, J):
-        """(la, lb, first position, J0, Jend): local blocks [la, lb) are this rank's rows of panel J; they sit at the
-        positions first, first + P, ... of the panel's 128-row blocks"""
-        J0, Jend = self.bnd[J], self.bnd[J + 1]
-        b0, b1 = J0 // TILE, Jend // TILE
-        la = max(0, -(-(b0 - self.p) // self.P))
-        lb = max(la, max(0, -(-(b1 - self.p) // self.P)))
-        return la, lb, la * self.P + self.p - b0, J0, Jend
-
     def evaluate(self, theta, want_alpha=False, keep_factor=True):
         """One pass of the path on the sharded matrix (fvgp_hip_loglik_dist: assemble, factor, the forward solve riding
         along), optionally the backward solve.  Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated.
@@ -366,66 +343,23 @@ class ShardedGP:
         Returns (log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol), replicated on every rank."""
         return self.evaluate(theta, keep_factor=False)
 
-    # -- solves with the distributed factor ---------------------------------------------------------
+    # -- after the factorisation: one library call per method (fvgp_hip_solve_dist / _posterior_dist / _grad_dist; the panel sweeps,
+    #    products and collectives are C, fvgp_amd/csrc/dist_driver.h) -------------------------------------------------------------
     def solve_backward(self):
-        """KVinvY = L^-T z (gp_kv.py:574-593, the second half of cho_solve), replicated on every rank.
-        Column sweep over the panels from the last to the first: the rows of panel J are solved against the replicated
-        diagonal block (redundantly, no traffic), then every rank adds L[its rows of J, columns left of J]^T alpha_J to
-        its own partial sum; one all-reduce of an NB x 128 slice per panel completes the right-hand side of the next."""
-        o, A, P = self.ops, self.A, self.P
+        """KVinvY = L^-T z (gp_kv.py:574-593, the second half of cho_solve), replicated on every rank: (np_, 128), the first
+        ncol columns are the solution."""
+        o = self.ops
         with o.stream():
-            Y = A[self.zrow:self.zrow + TILE, :self.np_].t().contiguous()     # z (np_, 128), replicated
-            S = o.zeros(self.np_, TILE)                                       # this rank's partial sums
             alpha = o.zeros(self.np_, TILE)
-            for J in range(self.npan - 1, -1, -1):
-                la, lb, first, J0, Jend = self._panel_rows(J)
-                w = Jend - J0
-                Sg = S[J0:Jend].clone()
-                self._all_reduce(Sg)
-                G = Y[J0:Jend].clone()
-                o.add_matrix(G, Sg, -1.0)                                         # right-hand side of the panel: z_J - sum of the ranks' parts
-                o.trsm_lower_t(self._diag_block(J), w, G, TILE)
-                alpha[J0:Jend].copy_(G)
-                if lb > la and J0 > 0:
-                    mine = G.view(w // TILE, TILE, TILE)[first::P][:lb - la].reshape(-1, TILE).contiguous()
-                    o.gemm(1, 1, 0, J0, TILE, (lb - la) * TILE, 1.0, A[la * TILE:lb * TILE, :J0], mine, 1.0, S[:J0])
+            ws = o.zeros(o.dist_scratch(self._desc, 0))
+            o.solve_dist(self._desc, alpha, ws)
         self.alpha = alpha
         return alpha
 
-    def forward_trsm(self, B, triangular=False):
-        """B <- this rank's rows of L^-1 B_global, for a right-hand side distributed by rows like the matrix itself
-        (B: nb_max*128 local rows x m columns, m a multiple of 128).  Per panel: the panel's rows are summed to every
-        rank, solved against the replicated diagonal block, and applied to the rank's later rows as one GEMM.
-        triangular: B_global is lower triangular (the identity: inv(L)), so panel J only carries its first Jend columns."""
-        o, A, P = self.ops, self.A, self.P
-        m = B.shape[1]
-        assert m % TILE == 0 and B.shape[0] >= self.nb_max * TILE
-        with o.stream():
-            G_all = o.zeros(self.NB * m)
-            for J in range(self.npan):
-                la, lb, first, J0, Jend = self._panel_rows(J)
-                w = Jend - J0
-                mJ = min(m, Jend) if triangular else m
-                G = G_all[:w * mJ].view(w, mJ)                           # contiguous: the collective needs it
-                if P > 1:
-                    G.zero_()
-                    if lb > la:
-                        G.unflatten(0, (w // TILE, TILE))[first::P][:lb - la].copy_(B[la * TILE:lb * TILE, :mJ].unflatten(0, (lb - la, TILE)))
-                    self._all_reduce(G)
-                else:
-                    G.copy_(B[J0:Jend, :mJ])
-                o.trsm_lower(self._diag_block(J), w, G, mJ)
-                if lb > la:
-                    B[la * TILE:lb * TILE, :mJ].unflatten(0, (lb - la, TILE)).copy_(G.unflatten(0, (w // TILE, TILE))[first::P][:lb - la])
-                below = (self.nb_max - lb) * TILE
-                if below > 0:
-                    o.gemm(0, 1, 0, below, mJ, w, -1.0, A[lb * TILE:self.nb_max * TILE, J0:Jend], G, 1.0,
-                           B[lb * TILE:self.nb_max * TILE, :mJ])
-        return B
-
     def posterior(self, x_pred, want_cov=True):
         """k^T KVinvY and kk - k^T KV^-1 k (gp_posterior.py:139-182,229-288) at the factored hyperparameters: every rank
-        assembles its own rows of k(x_data, x_pred); the mean and V^T V (V = L^-1 k) are summed over the ranks.
+        assembles its own rows of k(x_data, x_pred) (the library does; with a host kernel callable this method does and hands
+        them over); the mean and V^T V (V = L^-1 k) are summed over the ranks.
         Returns host arrays (P_pred, ncol) and (P_pred, P_pred) or None, replicated."""
         assert self.theta is not None, "evaluate() first"
         o = self.ops
@@ -434,28 +368,19 @@ class ShardedGP:
         x_pred = np.ascontiguousarray(x_pred, dtype=np.float64)
         npred = len(x_pred)
         pp = _lib.pad128(npred)
-        rows = self.nb_max * TILE
         with o.stream():
             xp = o.to_device(x_pred)
-            k = o.zeros(rows, pp)
-            self._kernel_rows(x_pred, xp, self.theta, k)
-            a_loc = o.zeros(rows, TILE)
-            inside = self.gidx < self.np_
-            a_loc[:int(inside.sum())] = self.alpha[self.torch.as_tensor(self.gidx[inside], device=self.alpha.device)]
+            k_pre = kk_pre = None
+            if self.kernel_callable is not None:
+                k_pre = o.zeros(self.nb_max * TILE, pp)
+                self._kernel_rows(x_pred, xp, self.theta, k_pre)
+                if want_cov and self.p == 0:
+                    kk_pre = o.zeros(pp, pp)
+                    kk_pre[:npred, :npred].copy_(o.to_device(np.ascontiguousarray(self.kernel_callable(x_pred, x_pred, self.theta), dtype=np.float64)))
             mean = o.zeros(pp, TILE)
-            o.gemm(1, 1, 0, pp, TILE, rows, 1.0, k, a_loc, 0.0, mean)
-            self._all_reduce(mean)
-            S = None
-            if want_cov:
-                self.forward_trsm(k)
-                S = o.zeros(pp, pp)
-                if self.p == 0:
-                    if self.kernel_callable is None:
-                        o.kmat(self.kernel_id, xp, xp, self.theta, S)
-                    else:
-                        S[:npred, :npred].copy_(o.to_device(np.ascontiguousarray(self.kernel_callable(x_pred, x_pred, self.theta), dtype=np.float64)))
-                o.gemm(1, 1, 0, pp, pp, rows, -1.0, k, k, 1.0, S)
-                self._all_reduce(S)
+            S = o.zeros(pp, pp) if want_cov else None
+            ws = o.zeros(o.dist_scratch(self._desc, 1, npred))
+            o.posterior_dist(self._desc, self.theta, xp, npred, k_pre, kk_pre, self.alpha, mean, S, ws)
             o.sync()
         return mean[:npred, :self.ncol].cpu().numpy(), (None if S is None else S[:npred, :npred].cpu().numpy())
 
@@ -491,17 +416,6 @@ class ShardedGP:
         with self.ops.stream():
             return np.tril(self.gather_rows(self.A)[:, :self.n])
 
-    def _inverse_factor_rows(self):
-        """this rank's rows of inv(L) (rows x np_), by the distributed forward solve of the identity"""
-        o, torch = self.ops, self.torch
-        rows = self.nb_max * TILE
-        W = o.zeros(rows, self.np_)
-        inside = self.gidx < self.np_
-        li = torch.as_tensor(np.nonzero(inside)[0], device=W.device)
-        W[li, torch.as_tensor(self.gidx[inside], device=W.device)] = 1.0          # this rank's rows of the identity
-        self.forward_trsm(W, triangular=True)
-        return W
-
     def gradient(self, component=0, slab=2048, want_diag=False):
         """1/2 (tr(KV^-1 dK_i) - b^T dK_i b), b = KVinvY[:, component] (gp_marginal_likelihood.py:262-300) for the
         kernel-owned hyperparameters.  inv(L) is built by rows with the distributed forward solve (N^2 / P doubles per
@@ -513,30 +427,15 @@ class ShardedGP:
         assert self.theta is not None, "evaluate() first"
         if self.kernel_callable is not None:
             raise NotImplementedError("the row-sharded gradient re-evaluates dK/dtheta inside its trace kernel: it takes the named kernels")
-        o, torch = self.ops, self.torch
+        o = self.ops
         if self.alpha is None:
             self.solve_backward()
-        rows = self.nb_max * TILE
         slab = max(TILE, (int(slab) // TILE) * TILE)
         with o.stream():
-            W = self._inverse_factor_rows()
-            nt = self.np_ // TILE
-            partial = o.zeros(nt * (slab // TILE) * (self.d + 2))
-            b = self.alpha[:, component] if self.p == 0 else None
-            g = np.zeros(len(self.theta))
-            Gs = o.zeros(self.np_, slab)
-            for c0 in range(0, self.np_, slab):
-                wc = min(slab, self.np_ - c0)
-                # rows >= c0 of the slab: (W^T W)[c0:, c0:c0+wc] = W[:, c0:]^T W[:, c0:c0+wc]
-                o.gemm(1, 1, 0, self.np_ - c0, wc, rows, 1.0, W[:, c0:], W[:, c0:c0 + wc], 0.0, Gs[c0:, :wc])
-                if c0 < self.n:
-                    g += o.grad_trace_cols(self.kernel_id, self.x_all, self.theta, Gs, c0, min(wc, self.n - c0), b, partial)
-            gt = torch.as_tensor(g, device=Gs.device)
-            self._all_reduce(gt)
-            out = gt.cpu().numpy()
-            if not want_diag:
-                return out
-            dg = o.zeros(self.np_)
-            o.colsumsq(W, dg)
-            self._all_reduce(dg)
-            return out, dg[:self.n].cpu().numpy()
+            dg = o.zeros(self.np_) if want_diag else None
+            ws = o.zeros(o.dist_scratch(self._desc, 2, 0, slab))
+            g = o.grad_dist(self._desc, self.theta, self.alpha, component, slab, dg, ws)
+            o.sync()
+        if not want_diag:
+            return g
+        return g, dg[:self.n].cpu().numpy()

@@ -92,7 +92,8 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value);
  * duration in ms, out[2] = their summed algorithmic flops, out[3] = whole-potrf ms; of the last fused
  * evaluation (fvgp_hip_loglik): out[4] = covariance-assembly ms, out[5] = its algorithmic bytes (lower
  * 128-tiles written once), out[6] = ms of everything after the factorisation (backward solve, reductions);
- * out[7] reserved.  out needs 8 doubles. */
+ * out[7] = host milliseconds the last row-sharded evaluation (fvgp_hip_loglik_dist) took to ENQUEUE (no synchronisation inside).
+ * out needs 8 doubles. */
 int fvgp_hip_get_profile(fvgp_handle *h, double *out8_host);
 /* The handle keeps the inverted 128 x 128 diagonal blocks of the LAST factor it produced or solved with, keyed
  * on (pointer, n, ld).  A caller that fills a factor buffer by any other means than fvgp_hip_potrf / _loglik
@@ -196,6 +197,25 @@ int fvgp_hip_dist_workspace(const fvgp_dist_desc *d, int64_t *out6);
  * the forward solve riding along.  out_host = {log-likelihood, log|KV|, (y-m)^T KV^-1 (y-m) / ncol}, replicated;
  * *info_host = dpotrf's info (global index of the first non-positive pivot) or 0.  One host synchronisation. */
 int fvgp_hip_loglik_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *theta_host, int ntheta, double *out_host, int *info_host);
+/* After fvgp_hip_loglik_dist with keep_factor = 1 -- the rank's block rows of L in A, the factored diagonal blocks replicated in
+ * Dfac -- the rest of what the reference's distributed mode answers through the same object (gp_kv.py:574-593,
+ * gp_posterior.py:139-288, tests/test_fvgp.py:3112-3149), each ONE call per rank (collectives issued from the library):
+ *   solve_dist     : KVinvY = L^-T z, replicated: alpha_out (np x 128 row-major device; columns >= ncol are zero);
+ *   posterior_dist : k^T KVinvY -> mean_out (pp x 128) and kk - k^T KV^-1 k -> S_out (pp x pp, may be null), replicated,
+ *                    pp = padded_dim(npred).  Kernel callables: k_pre = the rank's rows of k(x_data, x_pred)
+ *                    (nb_max*128 x pp, block l = global block l*nranks + rank, zero padded) and kk_pre = k(x_pred, x_pred)
+ *                    (pp x pp, read on rank 0 only) assembled by the caller; else null and xpred (npred x d) is given;
+ *   grad_dist      : 1/2 (tr(KV^-1 dK_i) - b^T dK_i b), b = alpha[:, component] (gp_marginal_likelihood.py:262-300) for the
+ *                    kernel-owned hyperparameters -> grad_host (ntheta), replicated; diag_out (np device doubles or null)
+ *                    receives diag(KV^-1).  The rank's rows of inv(L) (N^2 / nranks doubles) live in the scratch; the Gram
+ *                    matrix is walked in column slabs of `slab` columns (a multiple of 128).
+ * ws: caller-owned device scratch of fvgp_hip_dist_scratch(d, what, npred, slab) doubles, what = 0 solve, 1 posterior, 2 gradient. */
+int64_t fvgp_hip_dist_scratch(const fvgp_dist_desc *d, int what, int64_t npred, int64_t slab);
+int fvgp_hip_solve_dist(fvgp_handle *h, const fvgp_dist_desc *d, double *alpha_out, double *ws);
+int fvgp_hip_posterior_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *theta_host, int ntheta, const double *xpred, int64_t npred,
+                            const double *k_pre, const double *kk_pre, const double *alpha, double *mean_out, double *S_out, double *ws);
+int fvgp_hip_grad_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *theta_host, int ntheta, const double *alpha, int component,
+                       int64_t slab, double *grad_host, double *diag_out, double *ws);
 /* one tall panel T (rows x w, row-major, ldt): the w x w diagonal block on top (lower triangle; the first
  * n_valid rows are data, the rest identity padding), this rank's rows of the panel below it.  Factors the top
  * block and solves the rows below against it, 128 columns at a time (leaf, TRSM by the inverted diagonal tile,

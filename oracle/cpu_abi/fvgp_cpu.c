@@ -358,14 +358,76 @@ int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t
     if (!B) return -11;
     if (!C) return -14;
     if (M % 128 || N % 128 || K % 16 || K < 0) { set_err("gemm: M,N must be multiples of 128 and K of 16"); return -5; }
-    for (int64_t i = 0; i < M; ++i)
-        for (int64_t j = 0; j < N; ++j) {
-            if (lower && j / 128 > i / 128) continue;
-            double s = 0.0;
-            for (int64_t k = 0; k < K; ++k)
-                s += (a_kmajor ? A[k * lda + i] : A[i * lda + k]) * (b_nmajor ? B[k * ldb + j] : B[j * ldb + k]);
-            C[i * ldc + j] = alpha * s + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
+    /* row of C at a time, k outermost inside it: contiguous rows of B^T / columns handled by the inner loop (the row-sharded
+     * gradient's Gram slabs run through here in the gloo tests) */
+    double *acc = (double *)malloc((size_t)N * sizeof(double));
+    if (!acc) return -1;
+    for (int64_t i = 0; i < M; ++i) {
+        const int64_t jmax = lower ? ((i / 128 + 1) * 128 < N ? (i / 128 + 1) * 128 : N) : N;
+        for (int64_t j = 0; j < jmax; ++j) acc[j] = 0.0;
+        if (b_nmajor) {
+            for (int64_t k = 0; k < K; ++k) {
+                const double a = a_kmajor ? A[k * lda + i] : A[i * lda + k];
+                const double *br = B + k * ldb;
+                for (int64_t j = 0; j < jmax; ++j) acc[j] += a * br[j];
+            }
+        } else {
+            for (int64_t j = 0; j < jmax; ++j) {
+                const double *br = B + j * ldb;
+                double t = 0.0;
+                if (a_kmajor) for (int64_t k = 0; k < K; ++k) t += A[k * lda + i] * br[k];
+                else { const double *ar = A + i * lda; for (int64_t k = 0; k < K; ++k) t += ar[k] * br[k]; }
+                acc[j] = t;
+            }
         }
+        for (int64_t j = 0; j < jmax; ++j) C[i * ldc + j] = alpha * acc[j] + (beta != 0.0 ? beta * C[i * ldc + j] : 0.0);
+    }
+    free(acc);
+    return 0;
+}
+int fvgp_hip_add_matrix(fvgp_handle *h, double *A, int64_t lda, const double *B, int64_t ldb, int64_t rows, int64_t cols, double alpha) {
+    if (!h) return -1;
+    if (!A) return -2;
+    if (!B) return -4;
+    for (int64_t i = 0; i < rows; ++i) for (int64_t j = 0; j < cols; ++j) A[i * lda + j] += alpha * B[i * ldb + j];
+    return 0;
+}
+int fvgp_hip_colsumsq(fvgp_handle *h, const double *V, int64_t rows, int64_t ldv, int64_t ncols, double *out) {
+    if (!h) return -1;
+    if (!V) return -2;
+    if (!out) return -6;
+    for (int64_t j = 0; j < ncols; ++j) out[j] = 0.0;
+    for (int64_t i = 0; i < rows; ++i) for (int64_t j = 0; j < ncols; ++j) out[j] += V[i * ldv + j] * V[i * ldv + j];
+    return 0;
+}
+/* the trace pass over the slab W (n rows, ncols columns = columns [col0, col0 + ncols) of the symmetric matrix): rows j >= column k */
+int fvgp_hip_grad_trace_cols(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d, const double *theta, int ntheta,
+                             const double *W, int64_t ldw, int64_t col0, int64_t ncols, const double *b, int64_t ldb, double *partial, double *grad) {
+    (void)partial;
+    if (!h) return -1;
+    if (!x) return -3;
+    if (!theta) return -6;
+    if (!W) return -8;
+    if (!grad) return -15;
+    kdesc k;
+    int rc = kdesc_from_theta(kernel_id, d, theta, ntheta, &k);
+    if (rc) return rc;
+    const int nk = k.iso ? 2 : d + 1;
+    for (int i = 0; i < ntheta; ++i) grad[i] = 0.0;
+    for (int64_t i = col0; i < n; ++i)
+        for (int64_t j = col0; j <= i && j < col0 + ncols; ++j) {
+            const double wt = (i == j ? 1.0 : 2.0) * (W[i * ldw + (j - col0)] - (b ? b[i * ldb] * b[j * ldb] : 0.0));
+            double e2[FVGP_MAX_DIM], r2 = 0.0;
+            for (int q = 0; q < d; ++q) { const double e = (x[i * d + q] - x[j * d + q]) * k.invl[q]; e2[q] = e * e; r2 += e2[q]; }
+            const double r = sqrt(r2);
+            double phi = radial(k.kind, r2), cf;
+            if (k.kind == 0) cf = k.sig * phi;
+            else if (k.kind == 1) cf = 3.0 * k.sig * exp(-sqrt(3.0) * r);
+            else cf = (5.0 / 3.0) * k.sig * (1.0 + sqrt(5.0) * r) * exp(-sqrt(5.0) * r);
+            grad[0] += wt * phi;
+            for (int q = 0; q < d; ++q) grad[k.iso ? 1 : 1 + q] += wt * cf * e2[q] * k.invl[q];
+        }
+    for (int i = 0; i < nk; ++i) grad[i] *= 0.5;
     return 0;
 }
 int fvgp_hip_add_lower(fvgp_handle *h, double *A, int64_t n, int64_t lda, const double *B, int64_t ldb, double alpha) {

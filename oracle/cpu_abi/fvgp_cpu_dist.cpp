@@ -20,6 +20,11 @@ struct CpuBackend {
     int fork() { return 0; }
     int join() { return 0; }
     int zero(double *p, int64_t count) { memset(p, 0, (size_t)count * sizeof(double)); return 0; }
+    int zero2d(double *p, int64_t ld, int64_t rows, int64_t cols) { for (int64_t i = 0; i < rows; ++i) memset(p + i * ld, 0, (size_t)cols * sizeof(double)); return 0; }
+    int identity2d(double *p, int64_t ld, int64_t n) { for (int64_t i = 0; i < n; ++i) for (int64_t j = 0; j < n; ++j) p[i * ld + j] = i == j ? 1.0 : 0.0; return 0; }
+    int identity(double *p, int64_t n) { return identity2d(p, n, n); }
+    int to_device(double *dst, const double *src, int64_t count) { memmove(dst, src, (size_t)count * sizeof(double)); return 0; }
+    int to_host(double *dst, const double *src, int64_t count) { memmove(dst, src, (size_t)count * sizeof(double)); return 0; }
     int copy2d(double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int64_t cols) {
         for (int64_t i = 0; i < rows; ++i) memmove(dst + i * ldd, src + i * lds, (size_t)cols * sizeof(double));
         return 0;
@@ -192,6 +197,44 @@ int fvgp_hip_loglik_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *
     out_host[1] = logdet;
     out_host[2] = quad;
     return 0;
+}
+
+/* after the factorisation: the same drivers as the HIP library's (dist_driver.h), over the host loops of this twin */
+int64_t fvgp_hip_dist_scratch(const fvgp_dist_desc *d, int what, int64_t npred, int64_t slab) {
+    if (!d || what < 0 || what > 2 || npred < 0 || (what == 2 && (slab < FVGP_TILE || slab % FVGP_TILE))) return -1;
+    return fvgp_dist::scratch_doubles(*d, what, npred, slab);
+}
+int fvgp_hip_solve_dist(fvgp_handle *h, const fvgp_dist_desc *d, double *alpha_out, double *ws) {
+    if (!h) return -1;
+    if (!d || !d->keep_factor) return -2;
+    if (!alpha_out) return -3;
+    if (!ws) return -4;
+    CpuBackend b{h};
+    return fvgp_dist::solve_backward(b, h, *d, alpha_out, ws);
+}
+int fvgp_hip_posterior_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *theta, int ntheta, const double *xpred, int64_t npred,
+                            const double *k_pre, const double *kk_pre, const double *alpha, double *mean_out, double *S_out, double *ws) {
+    if (!h) return -1;
+    if (!d || !d->keep_factor) return -2;
+    if (!theta) return -3;
+    if (npred <= 0) return -6;
+    if (!alpha) return -9;
+    if (!mean_out) return -10;
+    if (!ws) return -12;
+    CpuBackend b{h};
+    return fvgp_dist::posterior(b, h, *d, theta, ntheta, xpred, npred, k_pre, kk_pre, alpha, mean_out, S_out, ws);
+}
+int fvgp_hip_grad_dist(fvgp_handle *h, const fvgp_dist_desc *d, const double *theta, int ntheta, const double *alpha, int component,
+                       int64_t slab, double *grad_host, double *diag_out, double *ws) {
+    if (!h) return -1;
+    if (!d || !d->keep_factor) return -2;
+    if (!theta) return -3;
+    if (!alpha) return -5;
+    if (slab < FVGP_TILE || slab % FVGP_TILE) return -7;
+    if (!grad_host) return -8;
+    if (!ws) return -10;
+    CpuBackend b{h};
+    return fvgp_dist::gradient(b, h, *d, theta, ntheta, alpha, component, slab, grad_host, diag_out, ws);
 }
 
 }  /* extern "C" */

@@ -42,7 +42,7 @@ def _chk(rc, what):
         raise RuntimeError(f"{what} (CPU twin) failed with status {rc}: {cpu_abi().fvgp_hip_last_error_string().decode()}")
 
 
-class StubOps:
+class StubOps(_lib.DistCalls):
     torch = torch
     native_collectives = False
 
@@ -88,6 +88,13 @@ class StubOps:
     def comm_profile(self):
         return {}
 
+    def _dist_lib(self):
+        return cpu_abi()
+
+    @staticmethod
+    def _dist_check(rc, what):
+        _chk(rc, what)
+
     def zeros(self, *shape, dtype=None):
         return torch.zeros(*shape, dtype=dtype or torch.float64)
 
@@ -101,44 +108,8 @@ class StubOps:
         out[:r, :c] = 0.0
         out[:k.shape[0], :k.shape[1]] = torch.as_tensor(k)
 
-    def gemm(self, a_kmajor, b_nmajor, lower, M, N, K, alpha, A, B, beta, C):
-        """C = alpha opA opB + beta C on 128-tiles (lower: only tiles with row tile >= column tile), as fvgp_hip_gemm"""
-        assert M % 128 == 0 and N % 128 == 0 and K % 16 == 0
-        a = A[:K, :M].T if a_kmajor else A[:M, :K]
-        b = B[:K, :N] if b_nmajor else B[:N, :K].T
-        full = alpha * (a @ b)
-        for ti in range(M // 128):
-            for tj in range(N // 128):
-                if lower and tj > ti:
-                    continue
-                blk = (slice(ti * 128, (ti + 1) * 128), slice(tj * 128, (tj + 1) * 128))
-                C[blk] = full[blk] + (beta * C[blk] if beta != 0.0 else 0.0)
-
-    def trsm_lower(self, L, n, B, nrhs):
-        B[:n, :nrhs] = torch.linalg.solve_triangular(torch.tril(L[:n, :n]), B[:n, :nrhs], upper=False)
-
-    def trsm_lower_t(self, L, n, B, nrhs):
-        B[:n, :nrhs] = torch.linalg.solve_triangular(torch.tril(L[:n, :n]).T, B[:n, :nrhs], upper=True)
-
-    def grad_trace_cols(self, kernel_id, x, theta, W, col0, ncols, b, partial):
-        """1/2 sum over rows j >= columns k in [col0, col0 + ncols) of m_jk (W_jk - b_j b_k) dK_jk/dtheta_i, m = 1 on the
-        diagonal and 2 below it (the lower triangle stands for the symmetric matrix), as fvgp_hip_grad_trace_cols"""
-        n = len(x)
-        xs = x.numpy()
-        dK = orc.KERNEL_GRADS[NAMES[kernel_id]](xs, xs[col0:col0 + ncols], np.asarray(theta))      # (H, n, ncols)
-        Ws = W[:n, :ncols].numpy().copy()
-        if b is not None:
-            bb = b[:n].numpy()
-            Ws -= np.outer(bb, bb[col0:col0 + ncols])
-        jj, kk = np.arange(n)[:, None], (col0 + np.arange(ncols))[None, :]
-        m = np.where(jj > kk, 2.0, np.where(jj == kk, 1.0, 0.0))
-        return np.array([0.5 * np.sum(m * Ws * dK[i]) for i in range(len(theta))])
-
     def add_matrix(self, A, B, alpha=1.0):
         A[:B.shape[0], :B.shape[1]] += alpha * B
-
-    def colsumsq(self, V, out):
-        out.copy_((V * V).sum(dim=0))
 
     def sync(self):
         pass

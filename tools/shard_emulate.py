@@ -87,7 +87,7 @@ def main():
     flops = args.n ** 3 / 3.0
     print(f"world {args.world} rank {args.rank} n {args.n} panel {args.panel}: {1e3 * dt:.1f} ms per evaluation "
           f"(compute-side floor), {flops / dt / 1e12 / args.world:.1f} TFLOP/s per GPU equivalent; "
-          f"host enqueue {1e3 * min(host):.1f} ms")
+          f"host call {1e3 * min(host):.1f} ms, of which enqueue {ops.H.get_profile().get('host_enqueue_ms', float('nan')):.1f} ms")
 
 
 if __name__ == "__main__":
