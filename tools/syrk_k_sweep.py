@@ -36,9 +36,11 @@ for M in (24576, 16384):
                     A = torch.randn(M, K, dtype=torch.float64, device="cuda", generator=g)
                     C = torch.randn(M, M, dtype=torch.float64, device="cuda", generator=g)
                 ms = timeit(lambda: H.gemm(0, 0, 1, M, M, K, -1.0, A, A, beta, C))
+                ms1 = timeit(lambda: H.syrk_rowshard(M, M, K, A, A, C, 1, 0, 1, 0, 0)) if beta == 1.0 else float("nan")      # the same tiles as ROLE 1: yield poll in the K loop
                 T = M // 128; tiles = T * (T + 1) // 2
                 fl = tiles * 128 * 128 * 2.0 * K
                 print(json.dumps({"M": M, "K": K, "beta": beta, "ld": 50048 if wide else M, "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 2),
-                                  "us_per_round512": round(1e3 * ms / (tiles / 512.0), 1)}), flush=True)
+                                  "us_per_round512": round(1e3 * ms / (tiles / 512.0), 1),
+                                  "role1_us_per_round512": round(1e3 * ms1 / (tiles / 512.0), 1)}), flush=True)
                 if not wide:
                     del A, C
