@@ -150,6 +150,8 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "lookahead_min")) { h->lookahead_min = value; return 0; }
     if (!strcmp(key, "panel_chain")) { if (value < 0 || value > 2) return -3; h->panel_chain = (int)value; return 0; }
     if (!strcmp(key, "panel_chain_min")) { h->panel_chain_min = value; return 0; }
+    if (!strcmp(key, "cols_split")) { h->cols_split = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "cols_split_rows")) { h->cols_split_rows = value; return 0; }
     if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
     if (!strcmp(key, "outer_block_small")) { if (value < 0 || value % TILE) return -3; h->outer_block_small = value; return 0; }
@@ -484,15 +486,38 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
         for (size_t J = 0; J + 1 < npan; ++J) {
             const int64_t J0 = bnd[J], Jend = bnd[J + 1], Nend = bnd[J + 2];           // next panel = [Jend, Nend)
             // (1) main: bring the next panel's block columns up to date with panel J
-            rc = timed_update(J0, Jend, Jend, Nend); if (rc) return rc;
+            // `cols_split`: while few rows remain (the chain is what the factorisation waits for) only the next panel's SQUARE is
+            // updated before its chain starts; the rows below it follow on the main stream beside the chain, whose block rows
+            // below the square wait for a flag in memory that a one-thread kernel raises behind that update (chain.hip) -- the
+            // update of (rows below) x (panel) leaves the critical path: one launch + one stream hand-over per panel
+            const bool split = h->cols_split && h->panel_chain && np - Jend >= h->panel_chain_min && np - Jend <= h->cols_split_rows && np > Nend;
+            unsigned long long cols_tag = 0;
+            if (split) {
+                GemmDesc s{};          // rows and columns [Jend, Nend): lower tiles
+                s.a_kmajor = 0; s.b_nmajor = 0; s.lower = 1; s.M = Nend - Jend; s.N = Nend - Jend; s.K = Jend - J0;
+                s.alpha = -1.0; s.beta = 1.0; s.role = 1;
+                s.A = A + Jend * lda + J0; s.lda = lda; s.B = s.A; s.ldb = lda; s.C = A + Jend * lda + Jend; s.ldc = lda;
+                rc = launch_gemm(h, s); if (rc) return rc;
+            } else {
+                rc = timed_update(J0, Jend, Jend, Nend); if (rc) return rc;
+            }
             HIPCHK(hipEventRecord(h->ev_cols, mainS));
             // (2) side: factor the next panel as soon as (1) is done ...
             HIPCHK(hipStreamWaitEvent(sideS, h->ev_cols, 0));
             h->stream = sideS;
-            rc = panel_factor_any(h, A, n, np, lda, Jend, Nend);
+            if (split) { rc = launch_panel_chain(h, A, n, np, lda, Jend, Nend, &cols_tag); }
+            else rc = panel_factor_any(h, A, n, np, lda, Jend, Nend);
             h->stream = mainS;
             if (rc) return rc;
             HIPCHK(hipEventRecord(h->ev_panel, sideS));
+            if (split) {
+                GemmDesc s{};          // rows [Nend, np) x columns [Jend, Nend): every tile
+                s.a_kmajor = 0; s.b_nmajor = 0; s.lower = 0; s.M = np - Nend; s.N = Nend - Jend; s.K = Jend - J0;
+                s.alpha = -1.0; s.beta = 1.0; s.role = 1;
+                s.A = A + Nend * lda + J0; s.lda = lda; s.B = A + Jend * lda + J0; s.ldb = lda; s.C = A + Nend * lda + Jend; s.ldc = lda;
+                rc = launch_gemm(h, s); if (rc) return rc;
+                rc = launch_chain_cols_ready(h, cols_tag); if (rc) return rc;
+            }
             // (3) ... while main applies panel J to everything right of the next panel
             if (np > Nend) { rc = timed_update(J0, Jend, Nend, np); if (rc) return rc; }
             // the next iteration's updates use panel J+1: wait for its factorisation

@@ -44,6 +44,7 @@ struct ChainArgs {
     int *info; int info_base;
     unsigned long long *flags;        // 16 words (one 128-byte line) apart: ticket, leaf_done, abort, diag_ready[32], row_done[32]
     unsigned long long tick0, tag0;
+    unsigned long long cols_tag;      // != 0: the block rows below the square wait for flags[F_COLS] to reach it (their part of the trailing update runs beside this launch)
     int *yield;
     int yield_below;                  // the block rows below the square raise their compute unit's yield counter too
     int leaf_preloaded;
@@ -53,7 +54,7 @@ struct ChainArgs {
 };
 
 constexpr int FL = 16;                // 64-bit words between two flags
-constexpr int F_TICKET = 0, F_LEAF = 1, F_ABORT = 2, F_ROW = 3;
+constexpr int F_TICKET = 0, F_LEAF = 1, F_ABORT = 2, F_ROW = 3, F_COLS = 40;
 constexpr int IMGD = 128 * 16;        // doubles of one operand image (128 rows x 16 k)
 
 __device__ __forceinline__ unsigned long long flag_load(const unsigned long long *p) {
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
     if (g.yield_below && g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
     const int stride = (int)gridDim.x - n;
     double4_t xt[8];
+    if (g.cols_tag && !chain_wait(g, F_COLS, g.cols_tag, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
     for (int row = t; row < g.rows; row += stride) {
         // ---- a block row below the square, left-looking ----
         double *Ar = g.A + (long)row * 128 * g.lda;
@@ -507,10 +509,21 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
     if (yslot) atomicAdd(yslot, -1);
 }
 
+__global__ void chain_cols_ready_kernel(unsigned long long *flag, unsigned long long tag) { flag_store(flag, tag); }
+
 }  // namespace
 
+// behind the update of a panel's rows below its square: the resident kernel's block rows below the square may read them now
+// (a kernel boundary lies between that update and this store: its results are in memory, every L2 has been invalidated since)
+int launch_chain_cols_ready(fvgp_handle *h, unsigned long long tag) {
+    hipLaunchKernelGGL(chain_cols_ready_kernel, dim3(1), dim3(1), 0, h->stream, h->chain_flags + F_COLS * FL, tag);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // One panel [J0, J0 + 128 n) of the padded np x np matrix A, every row from J0 down: factor, solve, update -- one launch.
-int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
+// cols_tag_out != nullptr: the block rows below the square wait for launch_chain_cols_ready(*cols_tag_out) on another stream.
+int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, int64_t lda, int64_t J0, int64_t Jend, unsigned long long *cols_tag_out) {
     const int64_t w = Jend - J0;
     if (w <= 0 || w % TILE || J0 % TILE || np % TILE || Jend > np || w / TILE > 32) { fvgp_set_error("panel chain: bad panel"); return -5; }
     if (lda >= (1L << 21) || (lda & 1) || ((uintptr_t)A & 15)) { fvgp_set_error("panel chain: leading dimension / alignment"); return -4; }
@@ -527,6 +540,8 @@ int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, i
     g.flags = h->chain_flags;
     h->chain_tag += 64;
     g.tag0 = h->chain_tag; g.tick0 = h->chain_tick;
+    g.cols_tag = cols_tag_out ? h->chain_tag : 0;
+    if (cols_tag_out) *cols_tag_out = h->chain_tag;
     g.yield = h->leaf_yield ? h->cu_yield : nullptr;
     g.stamps = h->chain_stamps; g.seq = h->chain_seq++; g.leaf_stamps = h->leaf_stamps; g.leaf_factor = 1; g.leaf_tiles = 1; g.leaf_preloaded = 1; g.yield_below = h->chain_yield >= 2;
     int grid = g.rows < 480 ? g.rows : 480;       // one block row per ticket (the first n: the square), the rows below dealt round-robin beyond 480

@@ -77,6 +77,8 @@ int fvgp_hip_stream_destroy(void *stream);
  *       (512 for the last 12288 rows), "inner_block" / "panel_recursive" (how the three-launch chain splits a panel);
  *   panel chain: "panel_chain" (1: one resident kernel per panel, csrc/chain.hip, for panels with at least "panel_chain_min" = 4096
  *       rows below their first column; 0: three launches per 128 columns; 2: also for the row-sharded driver's stacked panel) ("order"),
+ *       "cols_split" (1: while at most "cols_split_rows" = 8192 rows remain only the next panel's square is brought up to date before
+ *       its resident kernel starts; the rows below follow on the main stream and the kernel's block rows wait for a flag in memory),
  *       "leaf_tiles" / "leaf_tiles_rows" / "k128_kernels" / "small_tile_max" / "small_tile_max_update" (kernels of the three-launch
  *       chain) ("order"), "leaf_yield" / "chain_yield" (1: the trailing update's waves sleep while a workgroup of the chain shares
  *       their compute unit; chain_yield 2: also for the resident kernel's rows below the square);

@@ -336,12 +336,15 @@ def test_potrf_solve_logdet(H, n, outer):
                                    dict(outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0, panel_recursive=0),
                                    dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, panel_chain=0),
                                    dict(outer_block=512, outer_block_big=2048, big_threshold=1000, inner_block=512, lookahead=1, panel_chain=1, panel_chain_min=0),
-                                   dict(outer_block=256, outer_block_big=1024, big_threshold=24576, inner_block=512, lookahead=0, panel_chain=1, panel_chain_min=0, outer_block_small=128, small_threshold=1024)])
+                                   dict(outer_block=256, outer_block_big=1024, big_threshold=24576, inner_block=512, lookahead=0, panel_chain=1, panel_chain_min=0, outer_block_small=128, small_threshold=1024),
+                                   dict(outer_block=256, outer_block_big=768, big_threshold=0, inner_block=512, lookahead=1, lookahead_min=0, panel_chain=1, panel_chain_min=0, cols_split=1, cols_split_rows=100000),
+                                   dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, lookahead_min=0, panel_chain=1, panel_chain_min=0, cols_split=0)])
 def test_potrf_panel_schedules_agree(H, sched):
     """Every panel schedule (regular / wide panels, sub-panels of a third block size, with and without look-ahead; the
     chain's TRSM by the inverted 128-block, by substitution with the 16 x 16 tile inverses, or switching between the two
     on the way down; panels by recursive halving (the default) or by 128-column steps inside sub-panels; the chain as three launches
-    per 128 columns or as ONE resident kernel per panel, chain.hip, for panels of 128 ... 2048 columns) is the same factorisation:
+    per 128 columns or as ONE resident kernel per panel, chain.hip, for panels of 128 ... 2048 columns, its rows below the square
+    updated before it starts or beside it behind a flag in memory) is the same factorisation:
     compare with LAPACK on one matrix."""
     from fvgp_amd._lib import pad128
     n = 3000
@@ -368,7 +371,7 @@ def test_potrf_panel_schedules_agree(H, sched):
     finally:
         for k, v in dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=1,
                          leaf_tiles_rows=8192, panel_recursive=1, panel_chain=1, panel_chain_min=4096, outer_block_small=512,
-                         small_threshold=12288).items():
+                         small_threshold=12288, lookahead_min=4608, cols_split=1, cols_split_rows=8192).items():
             H.set_option(k, v)
 
 
