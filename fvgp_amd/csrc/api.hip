@@ -474,6 +474,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     // a switch between the two streams costs ~12 us (event wait): below ~6k rows the panels are too short to pay for it
     // (measured: N=4000 2.78 ms with, 2.68 without; N=8000 7.48 / 7.58; N=12000 16.4 / 16.9)
     const bool la = h->lookahead && npan > 2 && np >= h->lookahead_min;
+    const bool can_split = la && h->cols_split && h->panel_chain && np - bnd[1] >= h->panel_chain_min && chain_streams_concurrent(h) == 1;
     if (!la) {
         for (size_t J = 0; J < npan; ++J) {
             rc = panel_factor_any(h, A, n, np, lda, bnd[J], bnd[J + 1]); if (rc) return rc;
@@ -490,7 +491,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             // updated before its chain starts; the rows below it follow on the main stream beside the chain, whose block rows
             // below the square wait for a flag in memory that a one-thread kernel raises behind that update (chain.hip) -- the
             // update of (rows below) x (panel) leaves the critical path: one launch + one stream hand-over per panel
-            const bool split = h->cols_split && h->panel_chain && np - Jend >= h->panel_chain_min && np - Jend <= h->cols_split_rows && np > Nend;
+            const bool split = can_split && np - Jend >= h->panel_chain_min && np - Jend <= h->cols_split_rows && np > Nend;
             unsigned long long cols_tag = 0;
             if (split) {
                 GemmDesc s{};          // rows and columns [Jend, Nend): lower tiles

@@ -511,7 +511,48 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
 
 __global__ void chain_cols_ready_kernel(unsigned long long *flag, unsigned long long tag) { flag_store(flag, tag); }
 
+// one lane waits up to ~20 ms for *flag to become `tag`: do kernels of two streams really run side by side here?
+__global__ void chain_probe_wait_kernel(const unsigned long long *flag, unsigned long long tag, int *seen) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int ok = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < 2000000ull) {          // 100 MHz
+        if (flag_load(flag) == tag) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    *seen = ok;
+}
+
 }  // namespace
+
+// A kernel that waits in memory for a kernel of ANOTHER stream needs the two to run concurrently.  Profilers that collect hardware
+// counters, and serialising debug modes of the runtime, run one kernel at a time: the wait would only end by its timeout.  Probed
+// once per handle (a waiting kernel on the chain stream, the kernel that raises the flag on the main stream, ~0.1 ms): without
+// concurrency the split column update (potrf_driver, `cols_split`) stays off.
+int chain_streams_concurrent(fvgp_handle *h) {
+    if (h->streams_concurrent >= 0) return h->streams_concurrent;
+    h->streams_concurrent = 0;
+    if (fvgp_ensure_side(h)) return 0;
+    if (!h->chain_flags) {
+        if (hipMalloc((void **)&h->chain_flags, 80 * 16 * sizeof(unsigned long long)) != hipSuccess) return 0;
+        if (hipMemset(h->chain_flags, 0, 80 * 16 * sizeof(unsigned long long)) != hipSuccess) return 0;
+        h->chain_tag = 0; h->chain_tick = 0;
+    }
+    h->chain_tag += 64;
+    int *seen = h->dinfo + 2;
+    unsigned long long *flag = h->chain_flags + F_COLS * FL;
+    hipEvent_t e0 = nullptr;
+    if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess) return 0;
+    // both streams first wait for the handle's stream (whichever it is now), then: side waits in memory, main raises the flag
+    (void)hipEventRecord(e0, h->stream);
+    (void)hipStreamWaitEvent(h->side, e0, 0);
+    hipLaunchKernelGGL(chain_probe_wait_kernel, dim3(1), dim3(1), 0, h->side, flag, h->chain_tag, seen);
+    hipLaunchKernelGGL(chain_cols_ready_kernel, dim3(1), dim3(1), 0, h->stream, flag, h->chain_tag);
+    int host_seen = 0;
+    if (hipStreamSynchronize(h->side) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess &&
+        hipMemcpy(&host_seen, seen, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) h->streams_concurrent = host_seen ? 1 : 0;
+    (void)hipEventDestroy(e0);
+    return h->streams_concurrent;
+}
 
 // behind the update of a panel's rows below its square: the resident kernel's block rows below the square may read them now
 // (a kernel boundary lies between that update and this store: its results are in memory, every L2 has been invalidated since)

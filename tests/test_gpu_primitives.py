@@ -1,6 +1,9 @@
 """HIP kernels through the C ABI (fvgp_amd/_lib.py -> libfvgp_hip.so) against numpy/scipy and the
 oracle, on sizes the CPU finishes in seconds.  Mirrors tests/test_fvgp.py:44-182 of the reference
 (GPU vs CPU linalg), with its rtol 1e-5 tightened to the fp64 bars of SURVEY 8c."""
+import json
+import os
+
 import numpy as np
 import pytest
 import scipy.linalg as sla
@@ -11,6 +14,7 @@ from oracle import fvgp_oracle as orc
 pytestmark = pytest.mark.gpu
 
 EPS = np.finfo(np.float64).eps
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -547,6 +551,36 @@ def test_scheduling_mechanisms_do_not_change_a_bit(H):
     assert info == 0
     assert abs(ll - out[0][0]) <= 1e-12 * abs(ll) and abs(logdet - out[0][1]) <= 1e-12 * abs(logdet)
     assert np.max(np.abs(alpha[:n, 0].cpu().numpy() - out[0][3])) <= 1e-9 * np.max(np.abs(out[0][3]))
+
+
+def test_serialised_kernels_do_not_hang_the_split_update(tmp_path):
+    """With kernels serialised (AMD_SERIALIZE_KERNEL=3; hardware-counter profilers do the same) a kernel that waits in memory for a
+    kernel of another stream would only end by its timeout: the handle probes once whether its two streams run concurrently and
+    keeps the split column update off when they do not -- the evaluation completes and agrees with the concurrent one."""
+    import subprocess
+    import sys
+    code = f"""
+import sys, json
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+from fvgp_amd import _lib
+n = 9000
+rng = np.random.default_rng(20240501); x = rng.random((n, 3)); y = np.sin(3.0 * x.sum(axis=1)) + 0.1 * rng.standard_normal(n)
+H = _lib.Handle(0)
+npad = _lib.pad128(n)
+ymd = H.zeros(npad, 1); ymd[:n, 0] = H.to_device(y - np.mean(y))
+KV = H.empty(npad, npad); alpha = H.empty(npad, 1)
+out = H.loglik(0, H.to_device(x), np.array([1.0, 0.3, 0.3, 0.3]), H.to_device(np.full(n, 0.01)), ymd, KV, alpha)
+print(json.dumps(list(out)))
+"""
+    outs = []
+    for env_extra in ({}, {"AMD_SERIALIZE_KERNEL": "3"}):
+        env = dict(os.environ, **env_extra)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(json.loads(res.stdout.strip().splitlines()[-1]))
+    assert outs[0][3] == 0 and outs[1][3] == 0
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-12 * abs(outs[0][0])
 
 
 # ---- row-sharded building blocks (fvgp_amd/dist.py) ------------------------------------------------

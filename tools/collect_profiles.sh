@@ -3,7 +3,7 @@
 # Kernel trace + stats of the headline command, the two PMC passes for the trailing update's traffic (separate runs:
 # FETCH_SIZE and WRITE_SIZE do not fit one pass; no tracing next to --pmc), and kernel stats of the C2 / C3 / C5 paths.
 set -o pipefail
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 OUT=gpurun_out/${TAG}_profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
