@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X dense fp64 matrix peak: 256 CU x 2.4 GHz x 128 flop/clk/CU
 PEAK_HBM_GBS = 8000.0
 XGMI_GBPS_PER_GPU = 7 * 153.0    # 7 links x ~153 GB/s (point-to-point)
-TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01f_pmc_traffic.json")
+TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01f_pmc_traffic.json")
 
 
 def synth(n, d, seed=20240501):
@@ -361,7 +361,7 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d, 
             "collectives": coll, "collectives_via": {"rccl": "RCCL called from libfvgp_hip.so on the chain stream (fvgp_hip_comm_init)",
                                                      "torch": "torch.distributed callbacks (gloo test path)"}[collectives_via],
             "xgmi_peak_GBps_per_gpu": XGMI_GBPS_PER_GPU,
-            "roofline": {"kernel": "gemm_f64_kernel<0, 0, 1, 0, 0> (row-sharded trailing update, rank 0's launches)", "bound": "mfma",
+            "roofline": {"kernel": "gemm_f64_kernel<0, 0, 1> (row-sharded trailing update, rank 0's launches)", "bound": "mfma",
                          "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                          "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1.0),
@@ -512,7 +512,7 @@ def main():
                            "ms_per_eval": prof["kmat_ms"] / args.steps, "algorithmic_bytes_per_eval": prof["kmat_bytes"] / args.steps},
             "after_factorisation_ms_per_eval": prof["tail_ms"] / args.steps,
             "roofline": {
-                "kernel": "gemm_f64_kernel<0, 0, 1, 0, 0> (trailing update of the blocked Cholesky, lower tiles)",
+                "kernel": "gemm_f64_kernel<0, 0, 1> (trailing update of the blocked Cholesky, lower tiles)",
                 "bound": "mfma", "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                 "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1.0),

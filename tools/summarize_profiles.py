@@ -9,10 +9,10 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", f"{tag}_profiles")
 dst = os.path.join(ROOT, "profiles")
-KERNEL = "gemm_f64_kernel<0, 0, 1, 0, 0>"
+KERNEL = "gemm_f64_kernel<0, 0, 1>"
 
 
 def counter_sum(path, name):
