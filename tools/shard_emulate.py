@@ -25,7 +25,6 @@ def main():
     ap.add_argument("--panel", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (repeatable)")
-    ap.add_argument("--stamps", action="store_true", help="per-workgroup start / end times of the chain's trsm_tiles launches (one evaluation)")
     args = ap.parse_args()
     import ctypes
     import torch
@@ -67,19 +66,6 @@ def main():
         torch.cuda.synchronize()
 
     once()
-    if args.stamps:
-        stamps = torch.zeros(8 + 4 * (1 << 20), dtype=torch.int64, device="cuda")
-        ops.H.set_option("chain_stamps", stamps.data_ptr())
-        once()
-        ops.H.set_option("chain_stamps", 0)
-        sarr = stamps.cpu().numpy()
-        cnt = int(sarr[0]); e = sarr[8:8 + 4 * cnt].reshape(cnt, 4)
-        print(" launch   WGs  first->last start us   WG run us (median / max)   launch span us")
-        for q in np.unique(e[:, 0])[:400:8]:
-            w = e[e[:, 0] == q]
-            t0s, t1s = w[:, 2], w[:, 3]
-            run = (t1s - t0s) / 100.0
-            print(f"{int(q):7d} {len(w):5d} {(t0s.max() - t0s.min()) / 100.0:12.1f} {np.median(run):18.1f} / {run.max():6.1f} {(t1s.max() - t0s.min()) / 100.0:14.1f}")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         once()
