@@ -29,7 +29,7 @@ int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred) {
         // transposed right-hand sides + its split-K partials, split-K partials of S -= V^T V
         winv = np * 1024;
         const int64_t tiles = (pp / TILE) * 8, want = tiles >= 512 ? 1 : 512 / tiles;
-        const int64_t stiles = (pp / TILE) * (pp / TILE), swant = stiles >= 512 ? 1 : (512 + stiles - 1) / stiles;
+        const int64_t stiles = (pp / TILE) * (pp / TILE + 1) / 2, swant = stiles >= 512 ? 1 : 512 / stiles;      // S -= V^T V: lower tiles
         const int64_t cand[3] = {np * 256 + 1024, (1 + want) * pp * 1024 + 64, swant * pp * pp + 64};
         for (int64_t c : cand) if (c > vec) vec = c;
     }
@@ -1192,11 +1192,13 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
                 KmatDesc kk = k;
                 kk.x1 = xpred; kk.n1 = P; kk.x2 = xpred; kk.n2 = P; kk.K = S_out; kk.ldk = lds; kk.uplo = FVGP_FULL; kk.pad = 2;
                 rc = launch_kmat(h, kk); if (rc) return rc;
-                GemmDesc g{};   // S -= V^T V = KT KT^T; few output tiles and K = np: split K so that the launch fills the chip
-                g.a_kmajor = 0; g.b_nmajor = 0; g.lower = 0; g.M = Pp; g.N = Pp; g.K = np; g.alpha = -1.0; g.beta = 1.0;
+                // S -= V^T V = KT KT^T on the 128-tiles on and below the block diagonal only (S is symmetric: 36 of 64 tiles at
+                // 1024 points), the rest mirrored; few output tiles and K = np: split K so that the launch fills the chip once
+                GemmDesc g{};
+                g.a_kmajor = 0; g.b_nmajor = 0; g.lower = 1; g.M = Pp; g.N = Pp; g.K = np; g.alpha = -1.0; g.beta = 1.0;
                 g.A = KT; g.lda = np; g.B = KT; g.ldb = np; g.C = S_out; g.ldc = lds;
-                const int64_t tiles = (Pp / TILE) * (Pp / TILE);
-                int64_t split = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
+                const int64_t tr = Pp / TILE, tiles = tr * (tr + 1) / 2;
+                int64_t split = tiles >= 512 ? 1 : 512 / tiles;
                 const int64_t max_split = np / 512 > 0 ? np / 512 : 1;       // at least 512 of K per workgroup
                 if (split > max_split) split = max_split;
                 if (split > 1) {
@@ -1204,6 +1206,7 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
                     g.split = (int)split; g.split_ws = h->vec;
                 }
                 rc = launch_gemm(h, g); if (rc) return rc;
+                rc = launch_transpose_lower_tiles(h, S_out, lds, S_out, lds, Pp); if (rc) return rc;
             }
             if (var_out) {
                 // v_p = k(x_p,x_p) - |L^-1 k_p|^2 ; stationary kernels: k(x,x) = signal variance

@@ -528,10 +528,13 @@ __global__ void copy_lower_tiles_kernel(const double *src, long lds, double *dst
 // dst tile (tj, ti) <- transpose of src tile (ti, tj) for the 128 x 128 tiles on and below the block diagonal, in 32 x 32
 // pieces through LDS (the upper part of src's diagonal tiles is explicit zeros, so dst's diagonal tiles come out with a zero
 // lower part): W = inv(L) (lower, k-major for W^T W) becomes W^T (upper, k-minor: the (M,K) x (N,K) layout of the fast GEMM)
-__global__ void transpose_lower_tiles_kernel(const double *src, long lds, double *dst, long ldd) {
+// `mirror`: in place (dst == src), only the pieces strictly below the diagonal -- a symmetric matrix whose 128-tiles on and below
+// the block diagonal were computed gets its upper part (the diagonal tiles were computed whole)
+__global__ void transpose_lower_tiles_kernel(const double *src, long lds, double *dst, long ldd, int mirror) {
     __shared__ double t[32][33];
     const int bj = blockIdx.x, bi = blockIdx.y;           // 32-granular block coordinates in src
     if ((bj >> 2) > (bi >> 2)) return;
+    if (mirror && bj >= bi) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int rr = ty; rr < 32; rr += 8) t[rr][tx] = src[((long)bi * 32 + rr) * lds + (long)bj * 32 + tx];
     __syncthreads();
@@ -856,7 +859,7 @@ int launch_kt_alpha(fvgp_handle *h, const double *K, int64_t ldk, const double *
 int launch_transpose_lower_tiles(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t np) {
     unsigned nb = (unsigned)(np / 32);
     if (nb == 0) return 0;
-    hipLaunchKernelGGL(transpose_lower_tiles_kernel, dim3(nb, nb), dim3(256), 0, h->stream, src, (long)lds, dst, (long)ldd);
+    hipLaunchKernelGGL(transpose_lower_tiles_kernel, dim3(nb, nb), dim3(256), 0, h->stream, src, (long)lds, dst, (long)ldd, src == dst ? 1 : 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
