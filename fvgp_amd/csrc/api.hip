@@ -24,13 +24,14 @@ int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred) {
     const int64_t np = pad128(n), nblk = np / TILE, pp = pad128(npred);
     int64_t vec = np * 16 + pp * 16 > np * 8 ? np * 16 + pp * 16 : np * 8;      // posterior mean widening vs vector sweeps
     int64_t winv = 0;
-    if (npred > 4) {
-        // many-point posterior: inverted 1024-blocks (np x 1024), their doubling scratch (np x 256), one block of the
-        // transposed right-hand sides + its split-K partials, split-K partials of S -= V^T V
-        winv = np * 1024;
-        const int64_t tiles = (pp / TILE) * 8, want = tiles >= 512 ? 1 : 512 / tiles;
-        const int64_t stiles = (pp / TILE) * (pp / TILE + 1) / 2, swant = stiles >= 512 ? 1 : 512 / stiles;      // S -= V^T V: lower tiles
-        const int64_t cand[3] = {np * 256 + 1024, (1 + want) * pp * 1024 + 64, swant * pp * pp + 64};
+    if (npred > 0) {
+        // posterior: inverted diagonal blocks (np x WB; 2048 wide up to 1024 points, 1024 beyond), their doubling
+        // scratch (np x WB/4), one block of the transposed right-hand sides + its split-K partials, split-K partials of S -= V^T V
+        const int64_t WB = pp <= 1024 ? 2048 : 1024;
+        winv = np * WB;
+        const int64_t tiles = (pp / TILE) * (WB / TILE), want = tiles >= 512 ? 1 : 512 / tiles;
+        const int64_t stiles = (pp / TILE) * (pp / TILE + 1) / 2, swant = stiles >= 512 ? 1 : 64 / ((stiles + 7) / 8);      // S -= V^T V: lower tiles
+        const int64_t cand[3] = {np * (WB / 4) + 1024, (1 + want) * pp * WB + 64, swant * pp * pp + 64};
         for (int64_t c : cand) if (c > vec) vec = c;
     }
     // + the per-CU yield counters, the backward sweep's granules (16 bytes per row) and ticket, the resident panel kernel's flag words
@@ -154,6 +155,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "cols_split_rows")) { h->cols_split_rows = value; return 0; }
     if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
+    if (!strcmp(key, "posterior_block")) { if (value != 1024 && value != 2048) return -3; h->posterior_block = value; return 0; }
     if (!strcmp(key, "outer_block_small")) { if (value < 0 || value % TILE) return -3; h->outer_block_small = value; return 0; }
     if (!strcmp(key, "small_threshold")) { h->small_threshold = value; return 0; }
     fvgp_set_error(std::string("unknown option ") + key);
@@ -238,15 +240,17 @@ int ensure_linv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl) {
     return 0;
 }
 
-// inverses of the 1024 x 1024 diagonal blocks of L, from the 128-block inverses by doubling:
-//     inv [[A, 0], [C, B]] = [[inv A, 0], [-inv(B) C inv(A), inv B]]      at block sizes 128 -> 256 -> 512 -> 1024,
-// every level two strided-batch GEMM launches over all full 1024-blocks (T = C inv(A) into the handle scratch, then
-// -inv(B) T into place) plus single launches for the pairs of a narrower last block.  O(N 1024^2) flops, a few hundred
-// microseconds; kept until the factor changes.
-static int ensure_winv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl) {
+// inverses of the WB x WB diagonal blocks of L (WB = 1024: POTRI, posterior at more than 1024 points; 2048: posterior up to 1024
+// points), from the 128-block inverses by doubling:
+//     inv [[A, 0], [C, B]] = [[inv A, 0], [-inv(B) C inv(A), inv B]]      at block sizes 128 -> 256 -> 512 -> 1024 (-> 2048),
+// every level two strided-batch GEMM launches over all full WB-blocks (T = C inv(A) into the handle scratch, then
+// -inv(B) T into place) plus single launches for the pairs of a narrower last block.  O(N WB^2) flops, a few hundred
+// microseconds; kept until the factor changes or the other width is asked for.
+static int ensure_winv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, int64_t WB = 1024) {
     int rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
-    if (h->winv_ok) return 0;
-    const int64_t np = pad128(n), nblk = np / TILE, WB = 1024;
+    if (h->winv_ok && h->winv_w == WB) return 0;
+    h->winv_ok = false;
+    const int64_t np = pad128(n), nblk = np / TILE;
     const size_t need = (size_t)np * WB;
     if (need > h->winv_cap) {
         if (h->winv) HIPCHK(hipFree(h->winv));
@@ -255,8 +259,8 @@ static int ensure_winv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl) 
         h->winv_cap = need;
     }
     double *W = h->winv;
-    rc = launch_winv_seed(h, h->linv, nblk, W); if (rc) return rc;
-    rc = ensure_scratch(h, np * 32 + 128); if (rc) return rc;          // T: at most np/2 x 512 doubles
+    rc = launch_winv_seed(h, h->linv, nblk, W, WB); if (rc) return rc;
+    rc = ensure_scratch(h, np * (WB / 32) + 128); if (rc) return rc;   // T: at most np/2 x WB/2 doubles
     double *T = h->vec;
     const int64_t nfull = np / WB, t0 = nfull * WB, wt = np - t0;
     for (int64_t hs = TILE; hs < WB; hs *= 2) {
@@ -292,7 +296,7 @@ static int ensure_winv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl) 
             rc = launch_gemm(h, b); if (rc) return rc;
         }
     }
-    h->winv_ok = true;
+    h->winv_ok = true; h->winv_w = WB;
     return 0;
 }
 
@@ -621,8 +625,10 @@ static int trsm_fwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl
 // leaves (L^-1 B)^T.  Every product is then the (M,K) x (N,K) layout of the factorisation's own panel TRSM and trailing
 // update -- X_k^T = B_k^T inv(L_kk)^T in place, BT[:, block] -= X^T L[block, k]^T -- i.e. the kernels with the 16-byte
 // fragment reads, and what follows (V^T V, row sums) reads contiguous rows.
-// The block itself is then ONE product with the inverse of its 1024 x 1024 diagonal block (ensure_winv) instead of eight
-// 128-steps of two latency-bound launches each.
+// The block itself is then ONE product with the inverse of its NB x NB diagonal block (ensure_winv) instead of NB / 128
+// steps of two latency-bound launches each.  NB = 2048 up to 1024 rows, where the sweep is a chain of dependent launches and
+// half as many are worth the larger block products (N = 20k: P = 8 .. 64 2.53 -> 1.68 ms, 600 5.8 -> 5.4, 1000 8.4 -> 8.1);
+// 1024 beyond (flop-bound: P = 2000 / 4000 +0.7 % with 2048).
 // LEFT-looking over the outer blocks: block J first receives everything to its left in one product,
 //     BT[:, J] -= BT[:, 0:J0] L[J, 0:J0]^T          (rows/128 x NB/128 output tiles, K = J0),
 // with K split over enough workgroups to fill the chip (deterministic two-pass reduction).  A right-looking sweep has
@@ -630,16 +636,16 @@ static int trsm_fwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl
 // the time to partly filled rounds (measured at N = 20k, P = 1000: 7.3 ms for 3.9e11 flops); here every launch is one round.
 // `slots`: the workgroups one launch should bring (512 = the whole chip; 256 when two halves of the rows run side by side on two
 // streams, trsm_fwd_gemm_t below); scratch: trsm_fwd_scratch(rows, slots) doubles.
-static int64_t trsm_fwd_scratch(int64_t rows, int64_t slots) {
-    const int64_t NB = 1024, tiles = (rows / TILE) * (NB / TILE);
+static int64_t trsm_fwd_scratch(int64_t rows, int64_t slots, int64_t NB) {
+    const int64_t tiles = (rows / TILE) * (NB / TILE);
     const int64_t want = tiles >= slots ? 1 : slots / tiles;
     return rows * NB + want * rows * NB;
 }
 
-// one outer block [J0, J0 + 1024) of the sweep for `rows` rows of BT
+// one outer block [J0, J0 + NB) of the sweep for `rows` rows of BT
 static int trsm_fwd_gemm_t_block(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt,
-                                 int64_t slots, double *scratch, int64_t J0) {
-    const int64_t np = pad128(n), NB = 1024;
+                                 int64_t slots, double *scratch, int64_t J0, int64_t NB) {
+    const int64_t np = pad128(n);
     const bool winv = h->block_inverses != 0;
     int rc = 0;
     // scratch: tmp (rows x NB: block J with everything to its left applied) and the split-K partials behind it
@@ -667,7 +673,7 @@ static int trsm_fwd_gemm_t_block(fvgp_handle *h, const double *L, int64_t n, int
             if (!in_tmp) { rc = launch_copy_cols(h, BT + J0, ldbt, tmp, w, rows, w, rows, w); if (rc) return rc; }
             GemmDesc d{};   // X_J^T = B_J^T inv(L_JJ)^T
             d.a_kmajor = 0; d.b_nmajor = 0; d.lower = 0; d.M = rows; d.N = w; d.K = w; d.alpha = 1.0; d.beta = 0.0;
-            d.A = tmp; d.lda = w; d.B = h->winv + J0 * 1024; d.ldb = 1024; d.C = BT + J0; d.ldc = ldbt;
+            d.A = tmp; d.lda = w; d.B = h->winv + J0 * NB; d.ldb = NB; d.C = BT + J0; d.ldc = ldbt;
             int64_t split = want;
             if (split > w / TILE) split = w / TILE;
             if (split > 1) { d.split = (int)split; d.split_ws = ws; }
@@ -691,29 +697,30 @@ static int trsm_fwd_gemm_t_block(fvgp_handle *h, const double *L, int64_t n, int
 
 // With 512 or more rows (posterior covariance at P >= 512 points) the rows are cut in two halves that run the same sweep side
 // by side on the two streams of the handle, each with launches of 256 workgroups: a step of the sweep is three dependent
-// launches with two reductions between them (~66 us of fixed cost per 1024-block, 20 blocks at N = 20k), and the other half's
+// launches with two reductions between them (~66 us of fixed cost per block, 10 blocks at N = 20k), and the other half's
 // product fills the chip while they run.
 static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt) {
     const bool winv = h->block_inverses != 0;
-    int rc = winv ? ensure_winv(h, L, n, ldl) : ensure_linv(h, L, n, ldl); if (rc) return rc;
+    const int64_t NB = rows <= 1024 ? h->posterior_block : 1024;     // up to 1024 points the sweep is a chain of dependent launches: half as many
+    int rc = winv ? ensure_winv(h, L, n, ldl, NB) : ensure_linv(h, L, n, ldl); if (rc) return rc;
     const bool halves = h->posterior_halves && winv && rows >= 512 && rows <= 1024 && rows % 256 == 0;    // (2048 rows: +3 %)
     const int64_t np = pad128(n);
     if (!halves) {
-        rc = ensure_scratch(h, (trsm_fwd_scratch(rows, 512) + 7) / 8); if (rc) return rc;
-        for (int64_t J0 = 0; J0 < np && !rc; J0 += 1024) rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT, rows, ldbt, 512, h->vec, J0);
+        rc = ensure_scratch(h, (trsm_fwd_scratch(rows, 512, NB) + 7) / 8); if (rc) return rc;
+        for (int64_t J0 = 0; J0 < np && !rc; J0 += NB) rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT, rows, ldbt, 512, h->vec, J0, NB);
         return rc;
     }
-    const int64_t r2 = rows / 2, sc = trsm_fwd_scratch(r2, 256);
+    const int64_t r2 = rows / 2, sc = trsm_fwd_scratch(r2, 256, NB);
     rc = ensure_scratch(h, (2 * sc + 7) / 8); if (rc) return rc;
     rc = fvgp_ensure_side(h); if (rc) return rc;
     hipStream_t mainS = h->stream, sideS = h->side;
     HIPCHK(hipEventRecord(h->ev_cols, mainS));
     HIPCHK(hipStreamWaitEvent(sideS, h->ev_cols, 0));
-    for (int64_t J0 = 0; J0 < np && !rc; J0 += 1024) {          // the two halves are enqueued block by block (a launch costs the host ~17 us)
-        rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT, r2, ldbt, 256, h->vec, J0);
+    for (int64_t J0 = 0; J0 < np && !rc; J0 += NB) {          // the two halves are enqueued block by block (a launch costs the host ~17 us)
+        rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT, r2, ldbt, 256, h->vec, J0, NB);
         if (rc) break;
         h->stream = sideS;
-        rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT + r2 * ldbt, r2, ldbt, 256, h->vec + sc, J0);
+        rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT + r2 * ldbt, r2, ldbt, 256, h->vec + sc, J0, NB);
         h->stream = mainS;
     }
     if (rc) return rc;
@@ -1162,89 +1169,56 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
     HIPCHK(hipSetDevice(h->device));
     KmatDesc k{};
     rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &k); if (rc) return rc;
-    const bool few = P <= 4;          // a handful of prediction points (acquisition-function optimisers ask for one at a
-                                      // time): vector sweeps instead of 128-wide GEMM tiles; measured break-even between 4 and 8
-    if (!few) {
-        // ---- the GEMM path works on the TRANSPOSED cross covariance k(x_pred, x_data), Pp x np with leading dimension np
-        //      in the caller's scratch: the substitution then runs on the factorisation's own (M,K) x (N,K) kernels
-        //      (trsm_fwd_gemm_t) and S -= V^T V is A A^T of contiguous rows
-        double *KT = kx;
-        k.x1 = xpred; k.n1 = P; k.x2 = x; k.n2 = n; k.vdiag = nullptr; k.K = KT; k.ldk = np; k.uplo = FVGP_FULL; k.pad = 2;
-        rc = launch_kmat(h, k); if (rc) return rc;
-        if (mean_out && ncol <= FVGP_MAX_RHS_VEC) {
-            rc = launch_rows_dot(h, KT, np, alpha, ncol, ncol, n, P, mean_out, ncol); if (rc) return rc;
-        } else if (mean_out) {
-            // many columns of y: GEMM with alpha widened to 128 columns in the handle scratch;
-            // the (Pp x 128) result goes to the tail of the same scratch
-            rc = ensure_scratch(h, np * 16 + Pp * 16); if (rc) return rc;
-            double *aw = h->vec;
-            rc = launch_copy_cols(h, alpha, ncol, aw, 128, np, ncol, np, 128); if (rc) return rc;
-            double *mw = h->vec + np * 128;
-            GemmDesc g{};
-            g.a_kmajor = 0; g.b_nmajor = 1; g.lower = 0; g.M = Pp; g.N = 128; g.K = np; g.alpha = 1.0; g.beta = 0.0;
-            g.A = KT; g.lda = np; g.B = aw; g.ldb = 128; g.C = mw; g.ldc = 128;
-            rc = launch_gemm(h, g); if (rc) return rc;
-            rc = launch_copy_cols(h, mw, 128, mean_out, ncol, P, ncol, P, ncol); if (rc) return rc;
-        }
-        if (var_out || S_out) {
-            rc = trsm_fwd_gemm_t(h, L, n, ldl, KT, Pp, np); if (rc) return rc;             // KT <- (L^-1 k)^T
-            if (S_out) {
-                KmatDesc kk = k;
-                kk.x1 = xpred; kk.n1 = P; kk.x2 = xpred; kk.n2 = P; kk.K = S_out; kk.ldk = lds; kk.uplo = FVGP_FULL; kk.pad = 2;
-                rc = launch_kmat(h, kk); if (rc) return rc;
-                // S -= V^T V = KT KT^T on the 128-tiles on and below the block diagonal only (S is symmetric: 36 of 64 tiles at
-                // 1024 points), the rest mirrored; few output tiles and K = np: split K so that the launch fills the chip once
-                GemmDesc g{};
-                g.a_kmajor = 0; g.b_nmajor = 0; g.lower = 1; g.M = Pp; g.N = Pp; g.K = np; g.alpha = -1.0; g.beta = 1.0;
-                g.A = KT; g.lda = np; g.B = KT; g.ldb = np; g.C = S_out; g.ldc = lds;
-                const int64_t tr = Pp / TILE, tiles = tr * (tr + 1) / 2;
-                int64_t split = tiles >= 512 ? 1 : 512 / tiles;
-                const int64_t max_split = np / 512 > 0 ? np / 512 : 1;       // at least 512 of K per workgroup
-                if (split > max_split) split = max_split;
-                if (split > 1) {
-                    rc = ensure_scratch(h, (split * Pp * Pp + 7) / 8); if (rc) return rc;
-                    g.split = (int)split; g.split_ws = h->vec;
-                }
-                rc = launch_gemm(h, g); if (rc) return rc;
-                rc = launch_transpose_lower_tiles(h, S_out, lds, S_out, lds, Pp); if (rc) return rc;
-            }
-            if (var_out) {
-                // v_p = k(x_p,x_p) - |L^-1 k_p|^2 ; stationary kernels: k(x,x) = signal variance
-                rc = launch_rows_sumsq_base(h, KT, np, np, P, k.sig, var_out); if (rc) return rc;
-            }
-        }
-        return 0;
-    }
-    // ---- a few points: cross covariance k(x_data, x_pred) (gp_prior.py:200-215) in the (np x ldk) layout, zero padding
-    k.x1 = x; k.n1 = n; k.x2 = xpred; k.n2 = P; k.vdiag = nullptr; k.K = kx; k.ldk = ldk; k.uplo = FVGP_FULL; k.pad = 2;
+    // ---- every product runs on the TRANSPOSED cross covariance k(x_pred, x_data), Pp x np with leading dimension np
+    //      in the caller's scratch: the substitution then runs on the factorisation's own (M,K) x (N,K) kernels
+    //      (trsm_fwd_gemm_t) and S -= V^T V is A A^T of contiguous rows.  Also for a handful of points (acquisition-function
+    //      optimisers ask for one at a time): the sweep over 2048-blocks is ten dependent steps at N = 20k, 1.7 ms whatever
+    //      P <= 64, where vector sweeps took 3.0 / 4.6 / 9.0 ms at P = 1 / 2 / 4 (they do not need the inverted blocks: the
+    //      first call after a new factor is 1 ms dearer here)
+    double *KT = kx;
+    k.x1 = xpred; k.n1 = P; k.x2 = x; k.n2 = n; k.vdiag = nullptr; k.K = KT; k.ldk = np; k.uplo = FVGP_FULL; k.pad = 2;
     rc = launch_kmat(h, k); if (rc) return rc;
     if (mean_out && ncol <= FVGP_MAX_RHS_VEC) {
-        // mean = k^T alpha: one streaming pass over k (k is read once: 8 N P bytes), fixed-order reduction
-        rc = ensure_scratch(h, (kt_alpha_scratch_doubles(n, P, ncol) + 7) / 8); if (rc) return rc;
-        rc = launch_kt_alpha(h, kx, ldk, alpha, ncol, ncol, n, P, h->vec, mean_out, ncol, 1.0, 0); if (rc) return rc;
+        rc = launch_rows_dot(h, KT, np, alpha, ncol, ncol, n, P, mean_out, ncol); if (rc) return rc;
     } else if (mean_out) {
+        // many columns of y: GEMM with alpha widened to 128 columns in the handle scratch;
+        // the (Pp x 128) result goes to the tail of the same scratch
         rc = ensure_scratch(h, np * 16 + Pp * 16); if (rc) return rc;
         double *aw = h->vec;
         rc = launch_copy_cols(h, alpha, ncol, aw, 128, np, ncol, np, 128); if (rc) return rc;
         double *mw = h->vec + np * 128;
         GemmDesc g{};
-        g.a_kmajor = 1; g.b_nmajor = 1; g.lower = 0; g.M = Pp; g.N = 128; g.K = np; g.alpha = 1.0; g.beta = 0.0;
-        g.A = kx; g.lda = ldk; g.B = aw; g.ldb = 128; g.C = mw; g.ldc = 128;
+        g.a_kmajor = 0; g.b_nmajor = 1; g.lower = 0; g.M = Pp; g.N = 128; g.K = np; g.alpha = 1.0; g.beta = 0.0;
+        g.A = KT; g.lda = np; g.B = aw; g.ldb = 128; g.C = mw; g.ldc = 128;
         rc = launch_gemm(h, g); if (rc) return rc;
         rc = launch_copy_cols(h, mw, 128, mean_out, ncol, P, ncol, P, ncol); if (rc) return rc;
     }
     if (var_out || S_out) {
-        rc = potrs_vec(h, L, n, ldl, kx, P, ldk, false); if (rc) return rc;       // kx <- L^-1 k
+        rc = trsm_fwd_gemm_t(h, L, n, ldl, KT, Pp, np); if (rc) return rc;             // KT <- (L^-1 k)^T
         if (S_out) {
             KmatDesc kk = k;
             kk.x1 = xpred; kk.n1 = P; kk.x2 = xpred; kk.n2 = P; kk.K = S_out; kk.ldk = lds; kk.uplo = FVGP_FULL; kk.pad = 2;
             rc = launch_kmat(h, kk); if (rc) return rc;
-            // S -= V^T V as a streaming pass over V (P x P outputs)
-            rc = ensure_scratch(h, np + (kt_alpha_scratch_doubles(n, P, (int)P) + 7) / 8); if (rc) return rc;
-            rc = launch_kt_alpha(h, kx, ldk, kx, ldk, (int)P, n, P, h->vec + np * 8, S_out, lds, -1.0, 1); if (rc) return rc;
+            // S -= V^T V = KT KT^T on the 128-tiles on and below the block diagonal only (S is symmetric: 36 of 64 tiles at
+            // 1024 points), the rest mirrored; few output tiles and K = np: split K so that the launch fills the chip once
+            GemmDesc g{};
+            g.a_kmajor = 0; g.b_nmajor = 0; g.lower = 1; g.M = Pp; g.N = Pp; g.K = np; g.alpha = -1.0; g.beta = 1.0;
+            g.A = KT; g.lda = np; g.B = KT; g.ldb = np; g.C = S_out; g.ldc = lds;
+            const int64_t tr = Pp / TILE, tiles = tr * (tr + 1) / 2;
+            // an XCD (64 workgroup slots) gets ceil(tiles / 8) tiles of every K slice: 36 tiles -> 5 -> 12 slices, not 14
+            int64_t split = tiles >= 512 ? 1 : 64 / ((tiles + 7) / 8);
+            const int64_t max_split = np / 512 > 0 ? np / 512 : 1;       // at least 512 of K per workgroup
+            if (split > max_split) split = max_split;
+            if (split > 1) {
+                rc = ensure_scratch(h, (split * Pp * Pp + 7) / 8); if (rc) return rc;
+                g.split = (int)split; g.split_ws = h->vec;
+            }
+            rc = launch_gemm(h, g); if (rc) return rc;
+            rc = launch_transpose_lower_tiles(h, S_out, lds, S_out, lds, Pp); if (rc) return rc;
         }
         if (var_out) {
-            rc = launch_colsumsq(h, kx, np, ldk, P, k.sig, var_out, 1.0); if (rc) return rc;
+            // v_p = k(x_p,x_p) - |L^-1 k_p|^2 ; stationary kernels: k(x,x) = signal variance
+            rc = launch_rows_sumsq_base(h, KT, np, np, P, k.sig, var_out); if (rc) return rc;
         }
     }
     return 0;

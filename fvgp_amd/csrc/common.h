@@ -59,6 +59,8 @@ struct fvgp_handle {
     double *winv = nullptr;
     size_t winv_cap = 0;
     bool winv_ok = false;
+    int64_t winv_w = 1024;            // width of the inverted diagonal blocks winv holds
+    int64_t posterior_block = 2048;   // block width of the many-point posterior's sweep up to 1024 points (1024 / 2048); 1024 beyond
     int64_t leaf_tiles_rows = 4096;   //   ... while at most this many rows lie below the block
     int panel_recursive = 1;          // option: panels are factored by recursive halving (0: 128-column steps inside `inner_block` sub-panels)
     int leaf_tiles = 1;               // option: the leaf leaves the inverses of its 16x16 diagonal tiles only, the chain's TRSM substitutes
@@ -237,9 +239,6 @@ int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M,
 int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W, int64_t w = 1024);
 int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D);
 int launch_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);
-int64_t kt_alpha_scratch_doubles(int64_t n, int64_t P, int ncol);
-int launch_kt_alpha(fvgp_handle *h, const double *K, int64_t ldk, const double *alpha, int64_t lda, int ncol, int64_t n, int64_t P,
-                    double *scratch, double *out, int64_t ldo, double scale, int accumulate);
 int launch_copy_lower_tiles(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t np);
 int launch_transpose_lower_tiles(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t np);
 int launch_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const double *D, int64_t ldd, const double *b, int64_t ldb, int64_t n,

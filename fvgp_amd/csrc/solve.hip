@@ -471,48 +471,6 @@ __global__ __launch_bounds__(256) void winv_seed_kernel(const double *linv, doub
     }
 }
 
-// posterior mean k^T alpha (gp_posterior.py:158) as a streaming pass over k: partial[chunk][p][c] = sum over the
-// chunk's rows n of K[n][p] * alpha[n][c]; a wave reads 512 contiguous bytes of a row per instruction.  Summed in a
-// fixed order by kt_alpha_reduce_kernel (no atomics: results do not depend on scheduling).
-template <int C>
-__global__ __launch_bounds__(256) void kt_alpha_partial_kernel(const double *K, long ldk, const double *alpha, long lda, int ncol,
-                                                                long n, long P, int rows_per_chunk, double *partial) {
-    __shared__ double sa[256 * C];
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
-    const long r0 = (long)blockIdx.y * rows_per_chunk;
-    const long r1 = r0 + rows_per_chunk < n ? r0 + rows_per_chunk : n;
-    for (int e = threadIdx.x; e < rows_per_chunk * C; e += 256) {
-        const long rr = r0 + e / C; const int c = e % C;
-        sa[e] = (rr < n && c < ncol) ? alpha[rr * lda + c] : 0.0;
-    }
-    __syncthreads();
-    double acc[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = 0.0;
-    if (p < P) {
-        const double *kp = K + r0 * ldk + p;
-        for (long i = 0; i < r1 - r0; ++i) {
-            const double kv = kp[i * ldk];
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = fma(kv, sa[i * C + c], acc[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c) partial[((long)blockIdx.y * P + p) * C + c] = acc[c];
-    }
-}
-
-// out[p * ldo + c] = scale * sum over chunks (+ out's old value if accumulate): mean (scale 1) or S -= V^T V (scale -1)
-__global__ void kt_alpha_reduce_kernel(const double *partial, int nchunks, long P, int C, int ncol, double *out, long ldo,
-                                       double scale, int accumulate) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;       // e = p * ncol + c
-    if (e >= P * ncol) return;
-    const long p = e / ncol; const int c = (int)(e % ncol);
-    double s = 0.0;
-    for (int k = 0; k < nchunks; ++k) s += partial[((long)k * P + p) * C + c];
-    double *o = out + p * ldo + c;
-    *o = accumulate ? *o + scale * s : scale * s;
-}
-
 // copy the 128x128 tiles on and below the block diagonal (np a multiple of 128)
 __global__ void copy_lower_tiles_kernel(const double *src, long lds, double *dst, long ldd) {
     const int tj = blockIdx.x, ti = blockIdx.y;
@@ -827,31 +785,6 @@ int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W
     while ((1L << wshift) < w) ++wshift;
     if ((1L << wshift) != w || w > 8192) { fvgp_set_error("block inverses: the width must be 128 times a power of two"); return -5; }
     hipLaunchKernelGGL(winv_seed_kernel, dim3((unsigned)nblk, 8), dim3(256), 0, h->stream, linv, W, wshift);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-// out (P x ncol, row stride ldo) = or += scale * K[0:n, 0:P]^T alpha[0:n, 0:ncol] (alpha row stride lda);
-// scratch needs kt_alpha_scratch_doubles(n, P, ncol)
-int64_t kt_alpha_scratch_doubles(int64_t n, int64_t P, int ncol) {
-    const int C = ncol <= 1 ? 1 : ncol <= 2 ? 2 : ncol <= 4 ? 4 : 8;
-    return ((n + 255) / 256) * P * C;
-}
-
-int launch_kt_alpha(fvgp_handle *h, const double *K, int64_t ldk, const double *alpha, int64_t lda, int ncol, int64_t n, int64_t P,
-                    double *scratch, double *out, int64_t ldo, double scale, int accumulate) {
-    if (ncol < 1 || ncol > 8) return -5;
-    const int C = ncol <= 1 ? 1 : ncol <= 2 ? 2 : ncol <= 4 ? 4 : 8;
-    const int rpc = 256;
-    const unsigned nchunks = (unsigned)((n + rpc - 1) / rpc);
-    dim3 grid((unsigned)((P + 255) / 256), nchunks), block(256);
-#define GO(CC) hipLaunchKernelGGL((kt_alpha_partial_kernel<CC>), grid, block, 0, h->stream, K, (long)ldk, alpha, (long)lda, ncol, (long)n, (long)P, rpc, scratch)
-    if (C == 1) GO(1); else if (C == 2) GO(2); else if (C == 4) GO(4); else GO(8);
-#undef GO
-    HIPCHK(hipGetLastError());
-    const long tot = (long)P * ncol;
-    hipLaunchKernelGGL(kt_alpha_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
-                       scratch, (int)nchunks, (long)P, C, ncol, out, (long)ldo, scale, accumulate);
     HIPCHK(hipGetLastError());
     return 0;
 }

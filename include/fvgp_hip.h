@@ -85,7 +85,8 @@ int fvgp_hip_stream_destroy(void *stream);
  *   schedule: "lookahead" (0/1) from "lookahead_min" = 4608 padded rows on: the next panel's chain on a high-priority side stream
  *       under the trailing update; "tile_tables" (1: XCD-balanced block -> tile tables instead of the formula map);
  *   solves / posterior / gradient: "bwd_sweep" (1: the backward vector sweep in one launch), "block_inverses" (1: the posterior
- *       substitutes with inverted 1024-blocks) ("order"), "posterior_halves" (1: 512-1024 points as two halves on two streams)
+ *       substitutes with inverted diagonal blocks) ("order"), "posterior_block" (2048 / 1024: width of those blocks up to 1024
+ *       prediction points; 1024 beyond) ("order"), "posterior_halves" (1: 512-1024 points as two halves on two streams)
  *       ("order"), "potri_kminor" (1: POTRI on (M,K) x (N,K) products only) ("order");
  *   measurement: "profile" (0/1: time the trailing-update launches with HIP events -> fvgp_hip_get_profile), "chain_stamps" /
  *       "leaf_stamps" (device pointers, 0 = off: in-kernel timestamps of the panel kernel's hand-offs / the leaf's phases). */
@@ -270,7 +271,8 @@ int fvgp_hip_grad_trace_cols(fvgp_handle *h, int kernel_id, const double *x, int
 /* posterior: GPposterior.posterior_mean / posterior_covariance  gp_posterior.py:139-182,229-288
  *   L: factor (padded), alpha: KVinvY (padded_dim(n), ncol)
  *   kx: scratch of padded_dim(n) x ldk doubles with ldk >= padded_dim(P); contents unspecified on return (the cross
- *       covariance and L^-1 k pass through it -- transposed, padded_dim(P) x padded_dim(n), when P > 4)
+ *       covariance and L^-1 k pass through it transposed, padded_dim(P) x padded_dim(n)).  The first call after a new factor
+ *       also inverts its 2048 x 2048 (P > 1024: 1024 x 1024) diagonal blocks into the handle (fvgp_hip_workspace_bytes)
  *   mean_out (P, ncol) device  = k^T alpha          (prior mean added by the caller)
  *   S_out (padded_dim(P), lds) device or NULL  = kk - k^T KV^-1 k  (full, symmetric)
  *   var_out (P) device  = diag of the above (unclipped; clipping is gp_posterior.py:248-259, caller side) */

@@ -542,8 +542,8 @@ def test_validation_scores_and_information_measures_match_the_reference():
 
 
 @pytest.mark.parametrize("P", [1, 2, 4, 5, 8])
-def test_posterior_few_points_paths_agree_with_the_oracle(P):
-    """A handful of prediction points takes the vector-sweep path (P <= 4), more the GEMM path: same numbers."""
+def test_posterior_few_points_agree_with_the_oracle(P):
+    """A handful of prediction points (acquisition-function optimisers ask for one at a time) runs the same block sweep as many."""
     import fvgp_amd
     fx = load_golden("G2_rbf_n512_d3.npz")
     with warnings.catch_warnings():

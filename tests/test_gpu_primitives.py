@@ -680,8 +680,8 @@ def test_panel_potrf_dev_tall_panel(H, w, extra, n_valid):
 
 @pytest.mark.parametrize("n,P", [(2700, 300), (1024, 130), (3200, 5), (1300, 8200), (2700, 900), (3200, 700)])
 def test_posterior_block_inverse_substitution(H, n, P):
-    """The many-point posterior substitutes with the inverted 1024 x 1024 diagonal blocks (doubling from the 128-block
-    inverses; n = 2700 leaves a last block of 5 x 128, n = 1024 a single full one; P = 8200 has enough output tiles per
+    """The many-point posterior substitutes with the inverted 2048 x 2048 (more than 1024 points: 1024 x 1024) diagonal blocks
+    (doubling from the 128-block inverses; n = 2700 leaves a last block of 5 x 128, n = 1024 a single one; P = 8200 has enough output tiles per
     block that nothing is split over K; P = 900 / 700 pad to 1024 / 768 rows, which run as two halves on two streams):
     against the oracle's cho_solve
     (gp_posterior.py:120-136,229-288) and against the 128-step substitution (option block_inverses = 0)."""
@@ -715,6 +715,18 @@ def test_posterior_block_inverse_substitution(H, n, P):
         finally:
             H.set_option("posterior_halves", 1)
         assert np.max(np.abs(S.cpu().numpy()[:P, :P] - got[1][1])) < 1e-11 * theta[0]
+    if Pp <= 1024:                   # 2048-wide inverted blocks (the default up to 1024 points) against 1024-wide ones
+        try:
+            H.set_option("posterior_block", 1024)
+            kx = H.empty(npad, Pp); mean = H.empty(P, 1); var = H.empty(P); S = H.empty(Pp, Pp)
+            H.posterior(0, xd, theta, KV, alpha, 1, H.to_device(xp), kx, mean, var, S)
+            H.sync()
+        finally:
+            H.set_option("posterior_block", 2048)
+        assert np.max(np.abs(S.cpu().numpy()[:P, :P] - got[1][1])) < 1e-11 * theta[0]
+        assert np.max(np.abs(S.cpu().numpy()[:P, :P] - want_S)) < 1e-10 * theta[0] + 1e-12
+    Sfull = got[1][1]
+    assert np.array_equal(Sfull, Sfull.T)          # the upper part is the mirror of the computed lower tiles
     for mode in (1, 0):
         m, S, v = got[mode]
         np.testing.assert_allclose(m, want_m, rtol=1e-8, atol=1e-9)

@@ -23,7 +23,7 @@ def run():
     y = np.sin(3.0 * x.sum(axis=1)) + 0.1 * rng.standard_normal(n)
     th = np.array([1.0, .3, .3, .3])
     gp = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=np.full(n, 0.01), kernel_function="rbf_ard")
-    xp = np.random.default_rng(2).random((1000, 3))
+    xp = np.random.default_rng(2).random((int(os.environ.get("POSTERIOR_P", "1000")), 3))
     for key, val in (kv.split("=") for kv in sys.argv[1:]):
         gp._H.set_option(key, int(val))
     import time
@@ -31,6 +31,21 @@ def run():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         gp.posterior_covariance(xp)
         torch.cuda.synchronize(); print("call", i, round(1e3 * (time.perf_counter() - t0), 2), "ms", flush=True)
+    ab = os.environ.get("POSTERIOR_AB")          # e.g. POSTERIOR_AB=posterior_block:1024,2048 -- alternate in one process
+    if ab:
+        key, vals = ab.split(":")
+        vals = [int(v) for v in vals.split(",")]
+        res = {v: [] for v in vals}
+        for rep in range(12):
+            for v in vals:
+                gp._H.set_option(key, v)
+                gp.posterior_covariance(xp)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                gp.posterior_covariance(xp)
+                torch.cuda.synchronize(); res[v].append(1e3 * (time.perf_counter() - t0))
+        for v in vals:
+            r = sorted(res[v])
+            print(f"{key}={v}: min {r[0]:.2f} median {r[len(r) // 2]:.2f} ms")
 
 
 def short(name):
