@@ -161,6 +161,7 @@ struct GemmDesc {
     // workgroups per tile, each over K/split, partial tiles into split_ws (split x M x N doubles), then one fixed-order
     // reduction into C -- the result does not depend on scheduling.  Plain K range only.
     int split = 1;
+    int split_tri = 0;                // B (N, K) is lower triangular: tile column tj only has K < 128 (tj + 1); slices beyond are skipped
     double *split_ws = nullptr;
     double *split_out = nullptr; int64_t split_ldo = 0;   // the reduced result beta C + sum goes here instead of over C
     // strided batch of equal problems: problem (y, z), y < batch_y, z < batch_z, takes A + y a_by + z a_bz, B + .., C + ..
@@ -235,7 +236,7 @@ int launch_rows_dot(fvgp_handle *h, const double *KT, int64_t ldk, const double 
                     double *out, int64_t ldo);
 int launch_rows_sumsq_base(fvgp_handle *h, const double *KT, int64_t ldk, int64_t n, int64_t P, double base, double *out);
 int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M, int64_t N, int lower, const double *C, int64_t ldc, double beta,
-                         double *out, int64_t ldo);
+                         double *out, int64_t ldo, int64_t tri_ksplit = 0);
 int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W, int64_t w = 1024);
 int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D);
 int launch_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);

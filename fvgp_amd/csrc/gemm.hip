@@ -47,6 +47,7 @@ struct GemmArgs {
     long ntiles;
     const int *tab;                   // balanced block -> tile table ((ti << 16) | tj, -1 = no tile), or nullptr: formula
     long ksplit, csplit;              // split-K (gridDim.y > 1): block row y takes K elements [y ksplit, (y+1) ksplit), its tile goes to C + y csplit
+    int tri;                          // split-K against a lower-triangular B (N, K): tile column tj stops at K = 128 (tj + 1), slices past that are nobody's
     int ny;                           // strided batch (ksplit == 0, gridDim.y > 1): problem (y, z) = (blockIdx.y % ny, blockIdx.y / ny)
     long ab1, ab2, bb1, bb2, cb1, cb2;   // takes its operands at A + y ab1 + z ab2, B + .., C + ..
     const int *yield;                 // trailing update (ROLE 1): per-CU counters raised by a co-resident workgroup of the panel chain
@@ -191,6 +192,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     long coff = 0;
     const double *gA = g.A, *gB = g.B;
     if (g.ksplit) {
+        if (g.tri) {
+            const long kt = 128L * (tj + 1);
+            if ((long)blockIdx.y * g.ksplit >= kt) return;
+            if (kend > kt) kend = kt;
+        }
         kbeg += (long)blockIdx.y * g.ksplit;
         if (kbeg + g.ksplit < kend) kend = kbeg + g.ksplit;
         coff = (long)blockIdx.y * g.csplit;
@@ -928,7 +934,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
     if ((d.bc_ranks > 1 || d.bc_off) && d.b_nmajor) { fvgp_set_error("gemm: block-cyclic B needs the (N, K) layout"); return -7; }
     g.kb0 = d.kb0; g.kbi = d.kbi; g.kbj = d.kbj; g.ke0 = d.ke0; g.kei = d.kei; g.kej = d.kej;
     g.ntiles = g.lower == 2 ? gemm_grid_tiles_rs(g.tiles_m, g.tiles_n, g.ls, g.lo) : gemm_grid_tiles(g.tiles_m, g.tiles_n, g.lower == 1);
-    g.tab = nullptr; g.ksplit = 0; g.csplit = 0; g.yield = h->cu_yield; g.raise = (h->chain_yield && d.role != 1) ? h->cu_yield : nullptr;
+    g.tab = nullptr; g.ksplit = 0; g.csplit = 0; g.tri = 0; g.yield = h->cu_yield; g.raise = (h->chain_yield && d.role != 1) ? h->cu_yield : nullptr;
     g.ny = 0; g.ab1 = g.ab2 = g.bb1 = g.bb2 = g.cb1 = g.cb2 = 0;
     const bool plain_k = d.kb0 == 0 && d.kbi == 0 && d.kbj == 0 && d.ke0 < 0 && d.kei == 0 && d.kej == 0;
     if (h->tile_tables && plain_k && !d.rev_m && g.tiles_m < 32768 && g.tiles_n < 32768 && g.ntiles >= 64 && !gemm_takes_small_tiles(h, d)) {
@@ -945,6 +951,10 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
         g.ksplit = steps * BK; g.csplit = (long)d.M * d.N;
         g.C = d.split_ws; g.ldc = d.N; g.beta = 0.0;
         grid.y = (unsigned)d.split;
+        if (d.split_tri) {
+            if (d.b_nmajor || d.lower || g.ksplit % 128) { fvgp_set_error("gemm: split_tri needs B (N, K), all tiles, slices of whole 128-blocks"); return -3; }
+            g.tri = 1;
+        }
     }
     const bool batched = (long)d.batch_y * d.batch_z > 1;
     if (batched) {
@@ -984,7 +994,7 @@ int launch_gemm(fvgp_handle *h, const GemmDesc &d) {
 #undef GO
     HIPCHK(hipGetLastError());
     if (split) return launch_splitk_reduce(h, d.split_ws, d.split, d.M, d.N, d.lower, d.C, d.ldc, d.beta,
-                                           d.split_out ? d.split_out : d.C, d.split_out ? d.split_ldo : d.ldc);
+                                           d.split_out ? d.split_out : d.C, d.split_out ? d.split_ldo : d.ldc, g.tri ? g.ksplit : 0);
     return 0;
 }
 

@@ -439,12 +439,14 @@ __global__ __launch_bounds__(256) void rows_sumsq_base_kernel(const double *KT, 
 }
 
 // C = beta C + sum over the splits of the partial products (alpha already applied), splits added in index order
+// tri_ks > 0 (GemmDesc::split_tri): tile column tj only has the slices that start below K = 128 (tj + 1)
 __global__ void splitk_reduce_kernel(const double *ws, int split, long M, long N, int lower, const double *C, long ldc, double beta,
-                                     double *out, long ldo) {
+                                     double *out, long ldo, long tri_ks) {
     const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (e >= M * N) return;
     const long i = e / N, j = e - i * N;
     if (lower && (j >> 7) > (i >> 7)) return;
+    if (tri_ks) { const long nz = (128 * ((j >> 7) + 1) + tri_ks - 1) / tri_ks; if (nz < split) split = (int)nz; }
     double2_t s = *reinterpret_cast<const double2_t *>(ws + e);
     for (int z = 1; z < split; ++z) { const double2_t t = *reinterpret_cast<const double2_t *>(ws + (long)z * M * N + e); s[0] += t[0]; s[1] += t[1]; }
     if (beta != 0.0) {
@@ -771,10 +773,10 @@ int launch_rows_sumsq_base(fvgp_handle *h, const double *KT, int64_t ldk, int64_
 }
 
 int launch_splitk_reduce(fvgp_handle *h, const double *ws, int split, int64_t M, int64_t N, int lower, const double *C, int64_t ldc, double beta,
-                         double *out, int64_t ldo) {
+                         double *out, int64_t ldo, int64_t tri_ksplit) {
     const long pairs = (long)M * N / 2;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, ws, split, (long)M, (long)N, lower,
-                       C, (long)ldc, beta, out, (long)ldo);
+                       C, (long)ldc, beta, out, (long)ldo, (long)tri_ksplit);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -38,7 +38,11 @@ def run():
         res = {v: [] for v in vals}
         for rep in range(12):
             for v in vals:
-                gp._H.set_option(key, v)
+                if key.startswith("FVGP_"):          # an environment switch the library reads per call: 1 = set, 0 = unset
+                    if v: os.environ[key] = "1"
+                    else: os.environ.pop(key, None)
+                else:
+                    gp._H.set_option(key, v)
                 gp.posterior_covariance(xp)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 gp.posterior_covariance(xp)
