@@ -246,9 +246,13 @@ int ensure_linv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl) {
 // every level two strided-batch GEMM launches over all full WB-blocks (T = C inv(A) into the handle scratch, then
 // -inv(B) T into place) plus single launches for the pairs of a narrower last block.  O(N WB^2) flops, a few hundred
 // microseconds; kept until the factor changes or the other width is asked for.
-static int ensure_winv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, int64_t WB = 1024) {
+// `upto` <= WB: the doubling stops at upto x upto blocks (they sit on the diagonal of the WB-wide layout); a later call with a
+// larger `upto` only adds the missing levels.
+static int ensure_winv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, int64_t WB = 1024, int64_t upto = 0) {
+    if (upto <= 0 || upto > WB) upto = WB;
     int rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
-    if (h->winv_ok && h->winv_w == WB) return 0;
+    if (h->winv_ok && h->winv_w == WB && h->winv_level >= upto) return 0;
+    const bool extend = h->winv_ok && h->winv_w == WB;          // the lower levels are there
     h->winv_ok = false;
     const int64_t np = pad128(n), nblk = np / TILE;
     const size_t need = (size_t)np * WB;
@@ -259,11 +263,11 @@ static int ensure_winv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, 
         h->winv_cap = need;
     }
     double *W = h->winv;
-    rc = launch_winv_seed(h, h->linv, nblk, W, WB); if (rc) return rc;
+    if (!extend) { rc = launch_winv_seed(h, h->linv, nblk, W, WB); if (rc) return rc; }
     rc = ensure_scratch(h, np * (WB / 32) + 128); if (rc) return rc;   // T: at most np/2 x WB/2 doubles
     double *T = h->vec;
     const int64_t nfull = np / WB, t0 = nfull * WB, wt = np - t0;
-    for (int64_t hs = TILE; hs < WB; hs *= 2) {
+    for (int64_t hs = extend ? h->winv_level : TILE; hs < upto; hs *= 2) {
         const int64_t ny = WB / (2 * hs);
         if (nfull > 0) {
             GemmDesc a{};   // T[y, z] = C inv(A)
@@ -296,7 +300,7 @@ static int ensure_winv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, 
             rc = launch_gemm(h, b); if (rc) return rc;
         }
     }
-    h->winv_ok = true; h->winv_w = WB;
+    h->winv_ok = true; h->winv_w = WB; h->winv_level = upto;
     return 0;
 }
 
@@ -644,7 +648,7 @@ static int64_t trsm_fwd_scratch(int64_t rows, int64_t slots, int64_t NB) {
 
 // one outer block [J0, J0 + NB) of the sweep for `rows` rows of BT
 static int trsm_fwd_gemm_t_block(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt,
-                                 int64_t slots, double *scratch, int64_t J0, int64_t NB) {
+                                 int64_t slots, double *scratch, int64_t J0, int64_t NB, int64_t WB) {
     const int64_t np = pad128(n);
     const bool winv = h->block_inverses != 0;
     int rc = 0;
@@ -673,7 +677,7 @@ static int trsm_fwd_gemm_t_block(fvgp_handle *h, const double *L, int64_t n, int
             if (!in_tmp) { rc = launch_copy_cols(h, BT + J0, ldbt, tmp, w, rows, w, rows, w); if (rc) return rc; }
             GemmDesc d{};   // X_J^T = B_J^T inv(L_JJ)^T
             d.a_kmajor = 0; d.b_nmajor = 0; d.lower = 0; d.M = rows; d.N = w; d.K = w; d.alpha = 1.0; d.beta = 0.0;
-            d.A = tmp; d.lda = w; d.B = h->winv + J0 * NB; d.ldb = NB; d.C = BT + J0; d.ldc = ldbt;
+            d.A = tmp; d.lda = w; d.B = h->winv + J0 * WB + J0 % WB; d.ldb = WB; d.C = BT + J0; d.ldc = ldbt;      // (NB < WB: a diagonal sub-block of the WB-wide inverses)
             int64_t split = want;
             if (split > w / TILE) split = w / TILE;
             if (split > 1) {
@@ -707,13 +711,17 @@ static int trsm_fwd_gemm_t_block(fvgp_handle *h, const double *L, int64_t n, int
 // product fills the chip while they run.
 static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt) {
     const bool winv = h->block_inverses != 0;
-    const int64_t NB = rows <= 1024 ? h->posterior_block : 1024;     // up to 1024 points the sweep is a chain of dependent launches: half as many
-    int rc = winv ? ensure_winv(h, L, n, ldl, NB) : ensure_linv(h, L, n, ldl); if (rc) return rc;
+    // up to 1024 points the sweep is a chain of dependent launches: 2048-wide blocks, half as many.  Their last doubling level costs
+    // 1.3 ms at N = 20k, more than one sweep gains (0.4 ms at P = 1000, 0.85 at P <= 64): the FIRST sweep on a new factor runs on the
+    // 1024-wide blocks (the diagonal of the same layout), the level is added when a second one follows
+    const int64_t WB = rows <= 1024 ? h->posterior_block : 1024;
+    const int64_t NB = (WB == 2048 && !(h->winv_ok && h->winv_w == 2048)) ? 1024 : WB;
+    int rc = winv ? ensure_winv(h, L, n, ldl, WB, NB) : ensure_linv(h, L, n, ldl); if (rc) return rc;
     const bool halves = h->posterior_halves && winv && rows >= 512 && rows <= 1024 && rows % 256 == 0;    // (2048 rows: +3 %)
     const int64_t np = pad128(n);
     if (!halves) {
         rc = ensure_scratch(h, (trsm_fwd_scratch(rows, 512, NB) + 7) / 8); if (rc) return rc;
-        for (int64_t J0 = 0; J0 < np && !rc; J0 += NB) rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT, rows, ldbt, 512, h->vec, J0, NB);
+        for (int64_t J0 = 0; J0 < np && !rc; J0 += NB) rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT, rows, ldbt, 512, h->vec, J0, NB, WB);
         return rc;
     }
     const int64_t r2 = rows / 2, sc = trsm_fwd_scratch(r2, 256, NB);
@@ -723,10 +731,10 @@ static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t l
     HIPCHK(hipEventRecord(h->ev_cols, mainS));
     HIPCHK(hipStreamWaitEvent(sideS, h->ev_cols, 0));
     for (int64_t J0 = 0; J0 < np && !rc; J0 += NB) {          // the two halves are enqueued block by block (a launch costs the host ~17 us)
-        rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT, r2, ldbt, 256, h->vec, J0, NB);
+        rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT, r2, ldbt, 256, h->vec, J0, NB, WB);
         if (rc) break;
         h->stream = sideS;
-        rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT + r2 * ldbt, r2, ldbt, 256, h->vec + sc, J0, NB);
+        rc = trsm_fwd_gemm_t_block(h, L, n, ldl, BT + r2 * ldbt, r2, ldbt, 256, h->vec + sc, J0, NB, WB);
         h->stream = mainS;
     }
     if (rc) return rc;

@@ -59,7 +59,8 @@ struct fvgp_handle {
     double *winv = nullptr;
     size_t winv_cap = 0;
     bool winv_ok = false;
-    int64_t winv_w = 1024;            // width of the inverted diagonal blocks winv holds
+    int64_t winv_w = 1024;            // width of winv's layout (row stride)
+    int64_t winv_level = 1024;        // size of the inverted diagonal blocks it holds so far (<= winv_w)
     int64_t posterior_block = 2048;   // block width of the many-point posterior's sweep up to 1024 points (1024 / 2048); 1024 beyond
     int64_t leaf_tiles_rows = 4096;   //   ... while at most this many rows lie below the block
     int panel_recursive = 1;          // option: panels are factored by recursive halving (0: 128-column steps inside `inner_block` sub-panels)
