@@ -272,7 +272,8 @@ int fvgp_hip_grad_trace_cols(fvgp_handle *h, int kernel_id, const double *x, int
  *   L: factor (padded), alpha: KVinvY (padded_dim(n), ncol)
  *   kx: scratch of padded_dim(n) x ldk doubles with ldk >= padded_dim(P); contents unspecified on return (the cross
  *       covariance and L^-1 k pass through it transposed, padded_dim(P) x padded_dim(n)).  The first call after a new factor
- *       also inverts its 2048 x 2048 (P > 1024: 1024 x 1024) diagonal blocks into the handle (fvgp_hip_workspace_bytes)
+ *       also inverts its 1024 x 1024 diagonal blocks into the handle, the second (P <= 1024) doubles them to 2048 x 2048
+ *       (fvgp_hip_workspace_bytes counts them)
  *   mean_out (P, ncol) device  = k^T alpha          (prior mean added by the caller)
  *   S_out (padded_dim(P), lds) device or NULL  = kk - k^T KV^-1 k  (full, symmetric)
  *   var_out (P) device  = diag of the above (unclipped; clipping is gp_posterior.py:248-259, caller side) */
