@@ -154,6 +154,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "cols_split")) { h->cols_split = value ? 1 : 0; return 0; }
     if (!strcmp(key, "cols_split_rows")) { h->cols_split_rows = value; return 0; }
     if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
+    if (!strcmp(key, "fwd_sweep")) { h->fwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "posterior_halves")) { h->posterior_halves = (int)value; return 0; }
     if (!strcmp(key, "posterior_block")) { if (value != 1024 && value != 2048) return -3; h->posterior_block = value; return 0; }
     if (!strcmp(key, "outer_block_small")) { if (value < 0 || value % TILE) return -3; h->outer_block_small = value; return 0; }
@@ -576,6 +577,9 @@ static int potrs_vec(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, do
     const int c = (int)nrhs;
     const int C = c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : 8;
     double *Y = h->vec;
+    if (h->fwd_sweep && c == 1) {               // one launch for the whole sweep (B is not touched)
+        rc = launch_fwd_sweep(h, L, ldl, np, h->linv, B, ldb, Y); if (rc) return rc;
+    } else
     for (int64_t k0 = 0; k0 < np; k0 += TILE) {
         rc = launch_fwd_step(h, L, ldl, np, k0, h->linv + (k0 / TILE) * LEAF_DOUBLES, B, ldb, Y, c);
         if (rc) return rc;

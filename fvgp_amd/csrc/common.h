@@ -97,7 +97,7 @@ struct fvgp_handle {
     int *cu_yield = nullptr; int leaf_yield = 1, chain_yield = 1;      // chain_yield 2: the resident panel kernel's block rows below the square raise it too
     // backward sweep in one launch (solve.hip, bwd_sweep_kernel): granules of {value, tag}, the launch counter the tags come from,
     // the column ticket; option "bwd_sweep"
-    double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1;
+    double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1, fwd_sweep = 1;
     // the panel chain as one resident kernel per panel (chain.hip): flag words, the launch tag and ticket bases; option "panel_chain"
     unsigned long long *chain_flags = nullptr, chain_tag = 0, chain_tick = 0; int panel_chain = 1; int streams_concurrent = -1;   // -1: not probed yet (chain.hip, chain_streams_concurrent)
     int cols_split = 1; int64_t cols_split_rows = 8192;   // (potrf_driver: the next panel's square is updated first, the rows below it beside its chain, while at most this many rows remain)
@@ -215,6 +215,7 @@ int launch_fwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, in
                     double *B, int64_t ldb, double *Y, int c);
 int launch_neg_log_sum(fvgp_handle *h, const double *v, int64_t n, double *out_dev);
 int launch_bwd_sweep(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, const double *linv, const double *Yres, double *X, int64_t ldx, int c);
+int launch_fwd_sweep(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, const double *linv, const double *B, int64_t ldb, double *Y);
 int launch_bwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,
                     double *Yres, double *X, int64_t ldx, int c);
 int launch_diag_logsum(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *out_dev);

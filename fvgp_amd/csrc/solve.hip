@@ -296,6 +296,137 @@ __global__ __launch_bounds__(256) void bwd_sweep_kernel(BwdSweepArgs g) {      /
     if (tid == 0 && atomicAdd(g.ticket + 1, 1) == (int)gridDim.x - 1) { atomicExch(g.ticket, 0); atomicExch(g.ticket + 1, 0); }
 }
 
+// Sums of 32 per-lane values over the 64 lanes of a wave by halving: at distance 32, 16, 8, 4, 2 a lane keeps one half of its
+// list and adds the partner's copy of that half (31 exchanges instead of 32 x 6), distance 1 completes the pair.  Row
+// u = 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1 (b_k = bit k of the lane) ends up, complete, in both lanes of its pair.  Fixed order.
+__device__ __forceinline__ double wave_sums32(const double (&a)[32][1], const int lane) {
+    double v16[16], v8[8], v4[4], v2[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const double keep = b5 ? a[16 + k][0] : a[k][0], give = b5 ? a[k][0] : a[16 + k][0]; v16[k] = keep + __shfl_xor(give, 32, 64); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const double keep = b4 ? v16[8 + k] : v16[k], give = b4 ? v16[k] : v16[8 + k]; v8[k] = keep + __shfl_xor(give, 16, 64); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const double keep = b3 ? v8[4 + k] : v8[k], give = b3 ? v8[k] : v8[4 + k]; v4[k] = keep + __shfl_xor(give, 8, 64); }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const double keep = b2 ? v4[2 + k] : v4[k], give = b2 ? v4[k] : v4[2 + k]; v2[k] = keep + __shfl_xor(give, 4, 64); }
+    const double keep = b1 ? v2[1] : v2[0], give = b1 ? v2[0] : v2[1];
+    const double v1 = keep + __shfl_xor(give, 2, 64);
+    return v1 + __shfl_xor(v1, 1, 64);
+}
+
+// The forward sweep L y = b in ONE launch (one right-hand side): the mirror image of bwd_sweep_kernel.  Workgroup r owns block ROW r
+// of L -- 128 contiguous rows, streamed left to right, the next 128 x 128 block in flight before the y it meets has arrived -- and
+// keeps, per thread, the partial sums of its wave's 32 rows over the two columns its lane reads; they are reduced across the
+// lanes once, when the row is through (every sum in a fixed order: nothing depends on timing).  Then t = b_r - sum, y_r =
+// inv(L_rr) t with the inverse fetched like one more block of the row, and y_r is PUBLISHED to the workgroups right of it as
+// 16-byte {value, tag ^ hash(value)} granules exactly as the backward sweep hands its x to the left.  Rows are handed out by a
+// ticket in start order (r = ticket): a workgroup only waits for workgroups that started before it.  Replaces N/128 dependent
+// launches of 8-20 us each (the path of a size that leaves no padding row for the fused solve, n % 128 == 0: N = 4096 2.91 ms
+// against 2.46 at N = 4000, same factorisation).
+struct FwdSweepArgs {
+    const double *L; long ldl; long np;
+    const double *linv;
+    const double *B; long ldb;    // right-hand side, column 0 (np rows, padding rows zero)
+    double *Y;                    // np doubles: y = L^-1 b
+    double *gran;
+    unsigned long long tag;
+    int *ticket;
+};
+
+__global__ __launch_bounds__(256) void fwd_sweep_kernel(FwdSweepArgs g) {
+    __shared__ double sy[2][128];
+    __shared__ double ssum[128];
+    __shared__ double st[128];
+    __shared__ int s_r, s_fail;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_r = atomicAdd(g.ticket, 1); s_fail = 0; }
+    __syncthreads();
+    const int r = s_r;
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(g.gran, 0, 0xffffffff, 0x00020000);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    u32x4 l2[32];
+    // this wave's 32 rows of a 128 x 128 block (row stride `rowb` bytes): lane l takes columns 2 l, 2 l + 1 of each
+    auto load_rows = [&](const double *blk, const long stride) {
+        const double *base = uniform_ptr(blk + (long)wave_u * 32 * stride);
+        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, 0xffffffff, 0x00020000);
+        const int rowb = (int)(stride * 8);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) l2[u] = __builtin_amdgcn_raw_buffer_load_b128(src, 16 * lane, u * rowb, 0);
+    };
+    const double *Lrow = g.L + (long)r * 128 * g.ldl;
+    const double *inv = g.linv + (long)r * 128 * 128;
+    if (r > 0) load_rows(Lrow, g.ldl); else load_rows(inv, 128);
+    const double bval = tid < 128 ? g.B[((long)r * 128 + tid) * g.ldb] : 0.0;
+    double acc[32][1];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) acc[u][0] = 0.0;
+    for (int c = 0; c < r; ++c) {
+        if (tid < 128) {
+            const int off = (int)(((long)c * 128 + tid) * 16);
+            u32x4 v;
+            int spins = 0;
+            for (;;) {
+                v = __builtin_amdgcn_raw_buffer_load_b128(gsrc, off, 0, 16);          // sc1: served past this CU's L1
+                const unsigned long long vb = (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
+                const unsigned long long t = ((unsigned long long)v[2] | ((unsigned long long)v[3] << 32)) ^ (vb * 0x9E3779B97F4A7C15ull);
+                if (t == g.tag) break;
+                if (++spins > (1 << 22)) { s_fail = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+                for (int k = r - 1 - c < 24 ? r - 1 - c : 24; k > 0; --k) __builtin_amdgcn_s_sleep(6);      // far behind the frontier: rare polls
+                asm volatile("" ::: "memory");
+            }
+            const unsigned long long bits = (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
+            double yv;
+            __builtin_memcpy(&yv, &bits, 8);
+            sy[c & 1][tid] = yv;
+        }
+        __syncthreads();
+        const double y0 = sy[c & 1][2 * lane], y1 = sy[c & 1][2 * lane + 1];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            double2_t lv;
+            __builtin_memcpy(&lv, &l2[u], 16);
+            acc[u][0] = fma(lv[0], y0, acc[u][0]);
+            acc[u][0] = fma(lv[1], y1, acc[u][0]);
+        }
+        if (c + 1 < r) load_rows(Lrow + (long)(c + 1) * 128, g.ldl); else load_rows(inv, 128);      // on its way while the next y is awaited
+    }
+    const int urow = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    {
+        const double tot = wave_sums32(acc, lane);
+        if (!(lane & 1)) ssum[wave * 32 + urow] = tot;
+    }
+    __syncthreads();
+    if (tid < 128) st[tid] = bval - ssum[tid];
+    __syncthreads();
+    {
+        const double t0 = st[2 * lane], t1 = st[2 * lane + 1];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            double2_t lv;
+            __builtin_memcpy(&lv, &l2[u], 16);
+            acc[u][0] = fma(lv[1], t1, lv[0] * t0);
+        }
+    }
+    {
+        const double tot = wave_sums32(acc, lane);
+        if (!(lane & 1)) ssum[wave * 32 + urow] = tot;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const double yv = s_fail ? __builtin_nan("") : ssum[tid];
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &yv, 8);
+        const unsigned long long tw = g.tag ^ (bits * 0x9E3779B97F4A7C15ull);
+        const u32x4 v = {(unsigned)bits, (unsigned)(bits >> 32), (unsigned)tw, (unsigned)(tw >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, gsrc, (int)(((long)r * 128 + tid) * 16), 0, 16);      // one sc1 store per granule
+        g.Y[(long)r * 128 + tid] = yv;
+    }
+    if (tid == 0 && atomicAdd(g.ticket + 1, 1) == (int)gridDim.x - 1) { atomicExch(g.ticket, 0); atomicExch(g.ticket + 1, 0); }
+}
+
 __global__ void diag_logsum_kernel(const double *L, long n, long ldl, double *out) {
     __shared__ double sw[16];
     double s = 0.0;
@@ -678,9 +809,8 @@ int launch_bwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, in
     return 0;
 }
 
-// the whole backward sweep in one launch (bwd_sweep_kernel, one right-hand side); Yres is only read
-int launch_bwd_sweep(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, const double *linv, const double *Yres, double *X, int64_t ldx, int c) {
-    if (c != 1) { fvgp_set_error("bwd_sweep: one right-hand side"); return -9; }
+// granules (16 bytes per row, tags of earlier launches never match) and the ticket words of the one-launch sweeps
+static int sweep_buffers(fvgp_handle *h, int64_t np) {
     const size_t need = (size_t)np * 2;                              // doubles: 16 bytes per granule
     if (need > h->sweep_gran_cap) {
         if (h->sweep_gran) HIPCHK(hipFree(h->sweep_gran));
@@ -693,8 +823,24 @@ int launch_bwd_sweep(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, c
         HIPCHK(hipMalloc((void **)&h->sweep_ticket, 2 * sizeof(int)));
         HIPCHK(hipMemset(h->sweep_ticket, 0, 2 * sizeof(int)));
     }
+    return 0;
+}
+
+// the whole backward sweep in one launch (bwd_sweep_kernel, one right-hand side); Yres is only read
+int launch_bwd_sweep(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, const double *linv, const double *Yres, double *X, int64_t ldx, int c) {
+    if (c != 1) { fvgp_set_error("bwd_sweep: one right-hand side"); return -9; }
+    int rc = sweep_buffers(h, np); if (rc) return rc;
     BwdSweepArgs g{L, (long)ldl, (long)np, linv, Yres, X, (long)ldx, h->sweep_gran, ++h->sweep_tag, h->sweep_ticket};
     hipLaunchKernelGGL(bwd_sweep_kernel, dim3((unsigned)(np / 128)), dim3(256), 0, h->stream, g);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// the whole forward sweep in one launch (fwd_sweep_kernel, one right-hand side): Y (np doubles) <- L^-1 B[:, 0]; B is only read
+int launch_fwd_sweep(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, const double *linv, const double *B, int64_t ldb, double *Y) {
+    int rc = sweep_buffers(h, np); if (rc) return rc;
+    FwdSweepArgs g{L, (long)ldl, (long)np, linv, B, (long)ldb, Y, h->sweep_gran, ++h->sweep_tag, h->sweep_ticket};
+    hipLaunchKernelGGL(fwd_sweep_kernel, dim3((unsigned)(np / 128)), dim3(256), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -84,7 +84,8 @@ int fvgp_hip_stream_destroy(void *stream);
  *       their compute unit; chain_yield 2: also for the resident kernel's rows below the square);
  *   schedule: "lookahead" (0/1) from "lookahead_min" = 4608 padded rows on: the next panel's chain on a high-priority side stream
  *       under the trailing update; "tile_tables" (1: XCD-balanced block -> tile tables instead of the formula map);
- *   solves / posterior / gradient: "bwd_sweep" (1: the backward vector sweep in one launch), "block_inverses" (1: the posterior
+ *   solves / posterior / gradient: "bwd_sweep" / "fwd_sweep" (1: the backward / forward vector sweep with one right-hand side in
+ *       one launch), "block_inverses" (1: the posterior
  *       substitutes with inverted diagonal blocks) ("order"), "posterior_block" (2048 / 1024: width of those blocks up to 1024
  *       prediction points; 1024 beyond) ("order"), "posterior_halves" (1: 512-1024 points as two halves on two streams)
  *       ("order"), "potri_kminor" (1: POTRI on (M,K) x (N,K) products only) ("order");

@@ -115,6 +115,49 @@ def test_backward_sweep_in_one_launch_matches_the_step_kernels(H, n):
         assert np.max(np.abs(out[1][0] - ref)) / np.max(np.abs(ref)) < 1e-11
 
 
+@pytest.mark.parametrize("n", [100, 128, 1024, 3333, 8192, 36000])
+def test_forward_sweep_in_one_launch(H, n):
+    """L y = b with one right-hand side (fvgp_hip_trsm_lower; the solve of a log-likelihood whose size leaves no padding row for
+    the fused one, n % 128 == 0): the single-launch forward sweep (workgroup r owns block row r and hands y_r to the right through
+    tagged granules) against the per-block launches (option fwd_sweep = 0: another order of the same sums) and scipy; the same
+    bits run after run; the right-hand side is not modified beyond the result."""
+    from fvgp_amd._lib import pad128
+    import torch
+    rng = np.random.default_rng(n + 1)
+    npad = pad128(n)
+    A = H.empty(npad, npad)
+    A.zero_()
+    g = torch.Generator(device=A.device); g.manual_seed(n + 1)
+    blk = 4096
+    for r0 in range(0, npad, blk):
+        r1 = min(npad, r0 + blk)
+        A[r0:r1, :r1] = 0.02 * torch.randn(r1 - r0, r1, dtype=torch.float64, device=A.device, generator=g) / np.sqrt(npad)
+    A.diagonal().copy_(1.0 + torch.rand(npad, dtype=torch.float64, device=A.device, generator=g))
+    A[n:, :] = 0.0
+    A.diagonal()[n:] = 1.0
+    H.invalidate_factor()
+    rhs = rng.standard_normal((n, 1))
+    out = {}
+    try:
+        for mode in (0, 1, 1):
+            H.set_option("fwd_sweep", mode)
+            B = _padded(H, rhs, cols_pad=1, fill=3.0)
+            H.trsm_lower(A, n, B, 1)
+            H.sync()
+            got = B.cpu().numpy()[:n, 0]
+            assert np.all(np.isfinite(got))
+            out.setdefault(mode, []).append(got)
+    finally:
+        H.set_option("fwd_sweep", 1)
+    assert np.array_equal(out[1][0], out[1][1])
+    scale = np.max(np.abs(out[0][0]))
+    assert np.max(np.abs(out[1][0] - out[0][0])) / scale < 1e-13
+    if n <= 8192:
+        L = np.tril(A.cpu().numpy()[:n, :n])
+        ref = sla.solve_triangular(L, rhs[:, 0], lower=True)
+        assert np.max(np.abs(out[1][0] - ref)) / np.max(np.abs(ref)) < 1e-12
+
+
 def test_launch_shape_options_keep_the_result(H):
     """The options that only pick a launch shape: `tile_tables` (XCD-balanced block -> tile table vs the formula map) and
     the diagnostic stamp buffers change WHERE and WHEN a tile runs, never its arithmetic: same bits.  `lookahead_min` (look-ahead
