@@ -1187,12 +1187,34 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
     HIPCHK(hipSetDevice(h->device));
     KmatDesc k{};
     rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &k); if (rc) return rc;
+    if (P == 1 && h->fwd_sweep && ncol <= FVGP_MAX_RHS_VEC) {
+        // ---- ONE prediction point (gradient-based acquisition optimisers ask for one at a time): the cross covariance is a
+        //      column, L^-1 k the one-launch forward sweep (N = 20k: 0.85 ms against 1.7 ms of the block sweep below, and no
+        //      inverted blocks to build after a new factor); fixed-order sums throughout
+        k.x1 = x; k.n1 = n; k.x2 = xpred; k.n2 = 1; k.vdiag = nullptr; k.K = kx; k.ldk = ldk; k.uplo = FVGP_FULL; k.pad = 2;
+        rc = launch_kmat(h, k); if (rc) return rc;
+        if (mean_out)
+            for (int cc = 0; cc < ncol; ++cc) { rc = launch_dot_rows(h, kx, ldk, alpha + cc, ncol, n, 1, mean_out + cc); if (rc) return rc; }
+        if (var_out || S_out) {
+            rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
+            rc = ensure_scratch(h, np / 8 + 16); if (rc) return rc;
+            rc = launch_fwd_sweep(h, L, ldl, np, h->linv, kx, ldk, h->vec); if (rc) return rc;          // h->vec <- L^-1 k
+            if (var_out) { rc = launch_colsumsq(h, h->vec, np, 1, 1, k.sig, var_out, 1.0); if (rc) return rc; }
+            if (S_out) {
+                KmatDesc kk = k;
+                kk.x1 = xpred; kk.n1 = 1; kk.x2 = xpred; kk.n2 = 1; kk.K = S_out; kk.ldk = lds; kk.uplo = FVGP_FULL; kk.pad = 2;
+                rc = launch_kmat(h, kk); if (rc) return rc;
+                rc = launch_colsumsq(h, h->vec, np, 1, 1, 0.0, h->red + 4, 1.0); if (rc) return rc;          // -|L^-1 k|^2
+                rc = launch_add_matrix(h, S_out, lds, h->red + 4, 1, 1, 1, 1.0); if (rc) return rc;
+            }
+        }
+        return 0;
+    }
     // ---- every product runs on the TRANSPOSED cross covariance k(x_pred, x_data), Pp x np with leading dimension np
     //      in the caller's scratch: the substitution then runs on the factorisation's own (M,K) x (N,K) kernels
-    //      (trsm_fwd_gemm_t) and S -= V^T V is A A^T of contiguous rows.  Also for a handful of points (acquisition-function
-    //      optimisers ask for one at a time): the sweep over 2048-blocks is ten dependent steps at N = 20k, 1.7 ms whatever
-    //      P <= 64, where vector sweeps took 3.0 / 4.6 / 9.0 ms at P = 1 / 2 / 4 (they do not need the inverted blocks: the
-    //      first call after a new factor is 1 ms dearer here)
+    //      (trsm_fwd_gemm_t) and S -= V^T V is A A^T of contiguous rows.  Also for a handful of points: the sweep over
+    //      2048-blocks is ten dependent steps at N = 20k, 1.7 ms whatever P <= 64, where per-block vector launches took
+    //      4.6 / 9.0 ms at P = 2 / 4
     double *KT = kx;
     k.x1 = xpred; k.n1 = P; k.x2 = x; k.n2 = n; k.vdiag = nullptr; k.K = KT; k.ldk = np; k.uplo = FVGP_FULL; k.pad = 2;
     rc = launch_kmat(h, k); if (rc) return rc;
