@@ -558,3 +558,17 @@ def test_posterior_few_points_agree_with_the_oracle(P):
     np.testing.assert_allclose(gp.posterior_mean(xp)["m(x)"], o.posterior_mean(xp)["m(x)"], rtol=1e-9)
     gotn = gp.posterior_covariance(xp, add_noise=True)
     np.testing.assert_allclose(gotn["S"], o.posterior_covariance(xp, add_noise=True)["S"], rtol=0, atol=1e-10)
+
+
+def test_posterior_at_one_point_with_two_columns_of_y():
+    """One prediction point takes the column + forward-sweep path; with y of shape (N, 2) the mean has one entry per column
+    (gp_posterior.py:158) -- against the reference's own output for the first point of fixture G6."""
+    fx = load_golden("G6_rbf_2col_n300_d3.npz")
+    gp = _make(fx, {})
+    xp = fx["x_pred"][:1]
+    np.testing.assert_allclose(gp.posterior_mean(xp)["m(x)"], fx["pm"][:1], rtol=1e-8, atol=1e-10)
+    pc = gp.posterior_covariance(xp)
+    assert np.max(np.abs(pc["v(x)"] - fx["pv"][:1])) <= 1e-10 * fx["theta"][0] + 1e-12
+    assert np.max(np.abs(pc["S"] - fx["pS"][:1, :1])) <= 1e-10 * fx["theta"][0] + 1e-12
+    pv = gp.posterior_covariance(xp, variance_only=True)
+    assert np.max(np.abs(pv["v(x)"] - fx["pv"][:1])) <= 1e-10 * fx["theta"][0] + 1e-12
