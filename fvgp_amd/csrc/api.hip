@@ -1189,7 +1189,7 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
     rc = kmat_desc_from_theta(kernel_id, d, theta, ntheta, &k); if (rc) return rc;
     if (P == 1 && h->fwd_sweep && ncol <= FVGP_MAX_RHS_VEC) {
         // ---- ONE prediction point (gradient-based acquisition optimisers ask for one at a time): the cross covariance is a
-        //      column, L^-1 k the one-launch forward sweep (N = 20k: 0.85 ms against 1.7 ms of the block sweep below, and no
+        //      column, L^-1 k the one-launch forward sweep (N = 20k: 1.1 ms against 1.7 ms of the block sweep below, and no
         //      inverted blocks to build after a new factor); fixed-order sums throughout
         k.x1 = x; k.n1 = n; k.x2 = xpred; k.n2 = 1; k.vdiag = nullptr; k.K = kx; k.ldk = ldk; k.uplo = FVGP_FULL; k.pad = 2;
         rc = launch_kmat(h, k); if (rc) return rc;
@@ -1199,12 +1199,12 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
             rc = ensure_linv(h, L, n, ldl); if (rc) return rc;
             rc = ensure_scratch(h, np / 8 + 16); if (rc) return rc;
             rc = launch_fwd_sweep(h, L, ldl, np, h->linv, kx, ldk, h->vec); if (rc) return rc;          // h->vec <- L^-1 k
-            if (var_out) { rc = launch_colsumsq(h, h->vec, np, 1, 1, k.sig, var_out, 1.0); if (rc) return rc; }
+            if (var_out) { rc = launch_rows_sumsq_base(h, h->vec, np, np, 1, k.sig, var_out); if (rc) return rc; }      // sigma^2 - |L^-1 k|^2
             if (S_out) {
                 KmatDesc kk = k;
                 kk.x1 = xpred; kk.n1 = 1; kk.x2 = xpred; kk.n2 = 1; kk.K = S_out; kk.ldk = lds; kk.uplo = FVGP_FULL; kk.pad = 2;
                 rc = launch_kmat(h, kk); if (rc) return rc;
-                rc = launch_colsumsq(h, h->vec, np, 1, 1, 0.0, h->red + 4, 1.0); if (rc) return rc;          // -|L^-1 k|^2
+                rc = launch_rows_sumsq_base(h, h->vec, np, np, 1, 0.0, h->red + 4); if (rc) return rc;       // -|L^-1 k|^2
                 rc = launch_add_matrix(h, S_out, lds, h->red + 4, 1, 1, 1, 1.0); if (rc) return rc;
             }
         }
