@@ -1062,10 +1062,17 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     // leave z^T = (L^-1 (y-m))^T in those rows and quad = |z|^2.  Needs ncol free padding rows.
     const bool fused = (np - n) >= ncol;
     if (fused) { rc = launch_rhs_rows(h, KV, n, ld, ymean, ncol, vdiag); if (rc) return rc; }
+    // ONE host round trip per evaluation: the factorisation is only enqueued, its info word comes back with the scalars at the end
+    // (what follows a failed factorisation computes on garbage and is thrown away; the profile option times the factorisation with
+    // events and keeps the round trip in the middle)
     int info = 0;
-    rc = potrf_driver(h, KV, n, ld, &info); if (rc) return rc;
-    if (info_host) *info_host = info;
-    if (info != 0) { out_host[0] = out_host[1] = out_host[2] = NAN; return 0; }
+    const bool defer = !h->profile;
+    if (defer) { rc = potrf_driver(h, KV, n, ld, nullptr, nullptr, true); if (rc) return rc; }
+    else {
+        rc = potrf_driver(h, KV, n, ld, &info); if (rc) return rc;
+        if (info_host) *info_host = info;
+        if (info != 0) { out_host[0] = out_host[1] = out_host[2] = NAN; return 0; }
+    }
     if (h->profile) HIPCHK(hipEventRecord(h->ev_stage[2], h->stream));
     rc = launch_neg_log_sum(h, h->logdet_parts, np, h->red); if (rc) return rc;       // sum log L_ii from the leaves' 1 / L_ii
     if (fused) {
@@ -1098,7 +1105,16 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     }
     if (h->profile) HIPCHK(hipEventRecord(h->ev_stage[3], h->stream));
     double r[2];
+    int *hinfo = reinterpret_cast<int *>(h->hpin + RED_SLOTS - 2);
+    if (defer) HIPCHK(hipMemcpyAsync(hinfo, h->dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     rc = fvgp_read_back(h, h->red, r, 2); if (rc) return rc;
+    if (defer) {
+        info = *hinfo;
+        if (info == 0x7fffffff) { fvgp_set_error("panel chain: a workgroup waited longer than 3 s for a hand-off and the launch was abandoned"); return 1999; }
+        if (info > n) info = 0;   // cannot happen: the padding is an identity block
+        if (info_host) *info_host = info;
+        if (info != 0) { out_host[0] = out_host[1] = out_host[2] = NAN; return 0; }
+    }
     if (h->profile) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, h->ev_stage[0], h->ev_stage[1])); h->prof_kmat_ms = ms;
