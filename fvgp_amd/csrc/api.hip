@@ -1370,6 +1370,18 @@ int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t
     GemmDesc g{};
     g.a_kmajor = a_kmajor; g.b_nmajor = b_nmajor; g.lower = lower; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    // few output tiles and a long K (the Schur complement of an append, c - v^T v with K = N: ONE tile walking 4096 of K took
+    // 564 us; k^T KV^-1 k of the callables' posterior): K split over workgroups, partials added in a fixed order (handle scratch).
+    // An XCD (64 slots) gets ceil(tiles / 8) tiles of every slice; at least 256 of K per slice.
+    if (K >= 1024 && M > 0 && N > 0 && M % TILE == 0 && N % TILE == 0 && !(ldc & 1) && !((uintptr_t)C & 15)) {      // (shorter K: the small-tile kernels)
+        const int64_t tm = M / TILE, tn = N / TILE, tiles = lower == 1 ? tm * (tm + 1) / 2 : tm * tn;
+        int64_t split = tiles >= 256 ? 1 : 64 / ((tiles + 7) / 8);
+        if (split > K / 256) split = K / 256;
+        if (split > 1 && lower != 2) {
+            int rc = ensure_scratch(h, (split * M * N + 7) / 8); if (rc) return rc;
+            g.split = (int)split; g.split_ws = h->vec;
+        }
+    }
     return launch_gemm(h, g);
 }
 
