@@ -287,7 +287,9 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
  * C (M,N) = alpha * opA * opB + beta * C on fp64 MFMA.  M, N multiples of 128, K of 16.
  *   a_kmajor == 0: A stored (M,K) row-major;  != 0: A stored (K,M) row-major (A^T product)
  *   b_nmajor == 0: B stored (N,K) row-major (C = A B^T); != 0: B stored (K,N) row-major
- *   lower != 0: only 128x128 tiles with row-tile >= col-tile are computed (SYRK-style) */
+ *   lower != 0: only 128x128 tiles with row-tile >= col-tile are computed (SYRK-style)
+ * With fewer than 256 output tiles and K >= 1024 the K range is split over workgroups and the partial tiles added in a fixed
+ * order (handle scratch): same result on every run, another rounding than the unsplit product. */
 int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t M, int64_t N, int64_t K,
                   double alpha, const double *A, int64_t lda, const double *B, int64_t ldb,
                   double beta, double *C, int64_t ldc);
