@@ -1,11 +1,7 @@
 // fp64 MFMA GEMM / SYRK for gfx950:  C = alpha * opA * opB + beta * C  on 128x128 tiles.
-//
-// This is the kernel the metric lives in: the trailing update of the blocked Cholesky
-// (dsyrk/dgemm inside LAPACK dpotrf, reached from fvgp/gp_lin_alg.py:245) is
-//     A22 -= L21 * L21^T          (a_kmajor = 0, b_nmajor = 0, lower = 1, ROLE 1)
-// and every other level-3 step of the path (panel products, POTRI, posterior cross products) is one of the four operand
-// layouts below.
-//
+// This is the kernel the metric lives in: the trailing update of the blocked Cholesky (dsyrk/dgemm inside LAPACK dpotrf, reached
+// from fvgp/gp_lin_alg.py:245) is A22 -= L21 * L21^T (a_kmajor = 0, b_nmajor = 0, lower = 1, ROLE 1); every other level-3 step
+// of the path (panel products, POTRI, posterior cross products) is one of the four operand layouts below.
 // Design (CDNA4):
 //   * v_mfma_f64_16x16x4_f64; one 256-thread workgroup = 4 waves in a 2x2 grid, each wave owns 64x64 of C = 16 MFMA tiles =
 //     64 fp64 accumulators per lane; 2 workgroups per CU (<= 228 VGPR, 76 KB LDS each), so one workgroup's C read-modify-write
@@ -122,10 +118,8 @@ __host__ __device__ inline long xcd_remap(long b, long nwg, int tiles_n) {
     return full * per + (k >= 0 ? k : 0);
 }
 
-
-// epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile.  The read-modify-write of C
-// is done in two batches of 32 loads per lane, all issued before the first use, so a tile pays two
-// memory round trips instead of sixteen.
+// epilogue: lane holds D[row = q + 4v][col = r] of each 16x16 MFMA tile.  The read-modify-write of C is done in two batches of
+// 32 loads per lane, all issued before the first use, so a tile pays two memory round trips instead of sixteen.
 __device__ __forceinline__ void store_tile(double4_t (&acc)[4][4], double *cbase, long ldc, double alpha, double beta) {
     if (beta != 0.0) {
 #pragma unroll
@@ -184,7 +178,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 15, q = lane >> 4;
-
     long kbeg = g.kb0 + g.kbi * ti + g.kbj * tj;
     long kend = (g.ke0 < 0 ? g.K : g.ke0 + g.kei * ti + g.kej * tj);
     if (kbeg < 0) kbeg = 0;
@@ -205,11 +198,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         gA += y * g.ab1 + z * g.ab2; gB += y * g.bb1 + z * g.bb2; coff = y * g.cb1 + z * g.cb2;
     }
     const int nk = kend > kbeg ? (int)((kend - kbeg) / BK) : 0;
-
     const long m0 = (long)ti * 128, n0 = (long)tj * 128;
     long nb0 = n0;                    // first row of this tile's B block
     if (!BNM) { const int idx = tj + g.bco; nb0 = ((long)(idx % g.bcr) * g.bcb + idx / g.bcr) * 128; }
-
     // both operands k-minor: unpadded [128][16] images whose 16-byte chunks are XOR-swizzled within their row by
     // s(row) = bit1(row) | bit2(row) << 2.  ds_read_b128 serves a wave in four groups of sixteen lanes, {0-3,12-15,20-27},
     // {4-11,16-19,28-31} and the same +32: every group holds each r = lane & 15 once, with lane group q = lane >> 4 alternating
@@ -243,13 +234,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     const long astep = AKM ? (long)BK * g.lda : BK;
     const long bstep = BNM ? (long)BK * g.ldb : BK;
-
     double4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
     double2_t ra[4], rb[4];
     if (nk > 0) {
 #pragma unroll
@@ -264,7 +253,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
     }
     __syncthreads();
-
     if constexpr (KM) {
         // K loop without vector-ALU work.  fp64 MFMA and the vector ALU do not execute side by side on a SIMD
         // (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in this kernel): every pointer bump, every LDS base recomputed per step comes straight
