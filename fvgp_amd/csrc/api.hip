@@ -79,6 +79,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     if (h->red) (void)hipFree(h->red);
     if (h->dinfo) (void)hipFree(h->dinfo);
     if (h->cu_yield) (void)hipFree(h->cu_yield);
+    if (h->tr_ws) (void)hipFree(h->tr_ws);
     if (h->sweep_gran) (void)hipFree(h->sweep_gran);
     if (h->sweep_ticket) (void)hipFree(h->sweep_ticket);
     if (h->chain_flags) (void)hipFree(h->chain_flags);
@@ -911,6 +912,21 @@ int fvgp_hip_trsm_lower(fvgp_handle *h, const double *L, int64_t n, int64_t ldl,
     if (np > n) { rc = launch_copy_cols(h, B, ldb, B + n * ldb, ldb, 0, 0, np - n, nrhs); if (rc) return rc; }
     if (nrhs <= FVGP_MAX_RHS_VEC) return potrs_vec(h, L, n, ldl, B, nrhs, ldb, false);
     if (nrhs % 128 || (ldb & 1) || ((uintptr_t)B & 15)) { fvgp_set_error("trsm with nrhs > 8 needs nrhs % 128 == 0, even ldb, 16-byte aligned B"); return -6; }
+    if (h->block_inverses && nrhs <= 1024 && np >= 2048) {
+        // few columns against a long factor (the new rows of an append, gp_lin_alg.py:1310-1477; the callables' posterior): the
+        // posterior's block sweep on the TRANSPOSED right-hand sides (N / 1024 steps with inverted diagonal blocks instead of
+        // N / 128 steps of two latency-bound launches: append of 4 points at N = 20k 10.0 -> 7 ms), two transposes around it
+        const size_t need = (size_t)nrhs * np;
+        if (need > h->tr_ws_cap) {
+            if (h->tr_ws) HIPCHK(hipFree(h->tr_ws));
+            h->tr_ws = nullptr; h->tr_ws_cap = 0;
+            HIPCHK(hipMalloc((void **)&h->tr_ws, need * sizeof(double)));
+            h->tr_ws_cap = need;
+        }
+        rc = launch_transpose(h, B, ldb, h->tr_ws, np, np, nrhs); if (rc) return rc;
+        rc = trsm_fwd_gemm_t(h, L, n, ldl, h->tr_ws, nrhs, np); if (rc) return rc;
+        return launch_transpose(h, h->tr_ws, np, B, ldb, nrhs, np);
+    }
     return trsm_fwd_gemm(h, L, n, ldl, B, nrhs, ldb);
 }
 

@@ -106,6 +106,7 @@ struct fvgp_handle {
     int posterior_halves = 1;         // posterior covariance at >= 512 points: two halves of the points side by side on two streams (api.hip)
     int64_t outer_block_small = 512, small_threshold = 12288;   // panel width for the last `small_threshold` rows (potrf_driver)
     int lookahead = 1;
+    double *tr_ws = nullptr; size_t tr_ws_cap = 0;    // trsm_lower with few columns: the right-hand sides transposed
     hipStream_t side = nullptr;       // high-priority stream for the look-ahead panel
     hipEvent_t ev_panel = nullptr, ev_cols = nullptr;
     // profile of the last potrf
@@ -243,6 +244,7 @@ int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W
 int launch_mfma_selftest(fvgp_handle *h, const double *A, const double *B, double *D);
 int launch_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);
 int launch_copy_lower_tiles(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t np);
+int launch_transpose(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t rows, int64_t cols);
 int launch_transpose_lower_tiles(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t np);
 int launch_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const double *D, int64_t ldd, const double *b, int64_t ldb, int64_t n,
                      double *partial, int *nblocks);

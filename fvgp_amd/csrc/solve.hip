@@ -616,6 +616,16 @@ __global__ void copy_lower_tiles_kernel(const double *src, long lds, double *dst
     }
 }
 
+// dst (cols x rows) <- src^T for a rows x cols matrix, both multiples of 32, in 32 x 32 pieces through LDS
+__global__ void transpose_kernel(const double *src, long lds, double *dst, long ldd) {
+    __shared__ double t[32][33];
+    const long bj = blockIdx.x, bi = blockIdx.y;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int rr = ty; rr < 32; rr += 8) t[rr][tx] = src[(bi * 32 + rr) * lds + bj * 32 + tx];
+    __syncthreads();
+    for (int rr = ty; rr < 32; rr += 8) dst[(bj * 32 + rr) * ldd + bi * 32 + tx] = t[tx][rr];
+}
+
 // dst tile (tj, ti) <- transpose of src tile (ti, tj) for the 128 x 128 tiles on and below the block diagonal, in 32 x 32
 // pieces through LDS (the upper part of src's diagonal tiles is explicit zeros, so dst's diagonal tiles come out with a zero
 // lower part): W = inv(L) (lower, k-major for W^T W) becomes W^T (upper, k-minor: the (M,K) x (N,K) layout of the fast GEMM)
@@ -933,6 +943,14 @@ int launch_winv_seed(fvgp_handle *h, const double *linv, int64_t nblk, double *W
     while ((1L << wshift) < w) ++wshift;
     if ((1L << wshift) != w || w > 8192) { fvgp_set_error("block inverses: the width must be 128 times a power of two"); return -5; }
     hipLaunchKernelGGL(winv_seed_kernel, dim3((unsigned)nblk, 8), dim3(256), 0, h->stream, linv, W, wshift);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_transpose(fvgp_handle *h, const double *src, int64_t lds, double *dst, int64_t ldd, int64_t rows, int64_t cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    if (rows % 32 || cols % 32) { fvgp_set_error("transpose: multiples of 32"); return -5; }
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(cols / 32), (unsigned)(rows / 32)), dim3(256), 0, h->stream, src, (long)lds, dst, (long)ldd);
     HIPCHK(hipGetLastError());
     return 0;
 }

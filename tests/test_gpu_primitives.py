@@ -372,6 +372,38 @@ def test_potrf_solve_logdet(H, n, outer):
     H.set_option("outer_block", 512)
 
 
+@pytest.mark.parametrize("n,nrhs", [(2500, 128), (4200, 384), (2048, 1024)])
+def test_trsm_lower_few_columns_against_a_long_factor(H, n, nrhs):
+    """fvgp_hip_trsm_lower with 128 .. 1024 columns and at least 2048 rows (the new rows of an append, gp_lin_alg.py:1310-1477):
+    the right-hand sides are transposed and swept with the inverted diagonal blocks; against scipy and against the per-128-block
+    substitution (option block_inverses = 0)."""
+    from fvgp_amd._lib import pad128
+    M = _spd(n, n + 3)
+    npad = pad128(n)
+    buf = np.zeros((npad, npad))
+    buf[:n, :n] = np.tril(M)
+    buf[n:, n:] = np.eye(npad - n)
+    A = H.to_device(buf)
+    assert H.potrf(A, n) == 0
+    Lref = np.tril(sla.cho_factor(M, lower=True)[0])
+    rhs = np.random.default_rng(n).standard_normal((n, nrhs))
+    ref = sla.solve_triangular(Lref, rhs, lower=True)
+    got = {}
+    try:
+        for mode in (1, 0):
+            H.set_option("block_inverses", mode)
+            B = _padded(H, rhs, fill=5.0)
+            H.trsm_lower(A, n, B, nrhs)
+            H.sync()
+            got[mode] = B.cpu().numpy()
+            assert np.all(got[mode][n:] == 0)
+    finally:
+        H.set_option("block_inverses", 1)
+    for mode in (1, 0):
+        assert np.max(np.abs(got[mode][:n] - ref)) / np.max(np.abs(ref)) < 1e-12
+    assert np.max(np.abs(got[1] - got[0])) / np.max(np.abs(ref)) < 1e-12
+
+
 @pytest.mark.parametrize("sched", [dict(outer_block=512, outer_block_big=1024, big_threshold=0, inner_block=256, lookahead=1),
                                    dict(outer_block=256, outer_block_big=1024, big_threshold=1500, inner_block=128, lookahead=1),
                                    dict(outer_block=256, outer_block_big=768, big_threshold=0, inner_block=512, lookahead=1),
