@@ -1,0 +1,43 @@
+"""Fuzz of the posterior covariance over (n, P) around every switch of its sweep -- one point (column + forward sweep), one tile
+row, the two-stream halves (512..1024 rows), 2048- / 1024-wide inverted blocks, the adaptive first / second / third call on a
+factor, blocks that end inside the last 2048 columns -- against numpy / scipy on the same inputs.   python tools/fuzz_posterior.py"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import scipy.linalg as sla
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fvgp_amd  # noqa: E402
+
+warnings.simplefilter("ignore")
+rng = np.random.default_rng(11)
+worst = 0.0
+for n in (700, 2047, 2048, 2049, 3100, 4224, 6500):
+    x = rng.random((n, 3)); y = np.sin(3 * x.sum(1)) + 0.1 * rng.standard_normal(n)
+    th = np.array([1.2, 0.3, 0.35, 0.4]); nv = np.full(n, 0.01)
+    gp = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function="rbf_ard")
+
+    def kern(a, b):
+        d2 = ((a[:, None, :] - b[None, :, :]) / th[1:]) ** 2
+        return th[0] * np.exp(-0.5 * d2.sum(-1))
+    c = sla.cho_factor(kern(x, x) + np.diag(nv), lower=True)
+    alpha = sla.cho_solve(c, y - y.mean())
+    for P in (1, 2, 5, 127, 128, 129, 511, 512, 640, 1023, 1024, 1025, 1100):
+        xp = rng.random((P, 3))
+        k = kern(x, xp)
+        S_ref = kern(xp, xp) - k.T @ sla.cho_solve(c, k)
+        m_ref = y.mean() + k.T @ alpha
+        errs = []
+        for call in range(3):                      # first call on the factor's blocks, the one that adds the 2048 level, a plain one
+            got = gp.posterior_covariance(xp)
+            errs.append(np.max(np.abs(got["S"] - S_ref)))
+            assert np.array_equal(got["S"], got["S"].T)
+        em = np.max(np.abs(gp.posterior_mean(xp)["m(x)"] - m_ref)) / np.max(np.abs(m_ref))
+        ev = np.max(np.abs(gp.posterior_covariance(xp, variance_only=True)["v(x)"] - np.clip(np.diag(S_ref), 0, None)))
+        worst = max(worst, max(errs) / th[0], em, ev / th[0])
+        print(f"n {n:5d} P {P:5d}: |S - ref| / sigma^2 over three calls {max(errs) / th[0]:.2e}  mean rel {em:.2e}  variance {ev / th[0]:.2e}", flush=True)
+        gp.set_hyperparameters(th)                 # a new factor: the next P starts from the first call again
+print(f"worst {worst:.2e}")
+assert worst < 1e-9
