@@ -572,3 +572,22 @@ def test_posterior_at_one_point_with_two_columns_of_y():
     assert np.max(np.abs(pc["S"] - fx["pS"][:1, :1])) <= 1e-10 * fx["theta"][0] + 1e-12
     pv = gp.posterior_covariance(xp, variance_only=True)
     assert np.max(np.abs(pv["v(x)"] - fx["pv"][:1])) <= 1e-10 * fx["theta"][0] + 1e-12
+
+
+@pytest.mark.parametrize("n,m", [(2500, 4), (2048, 1)])
+def test_append_matches_a_fresh_gp_on_a_long_factor(n, m):
+    """update_gp_data(append=True) (gp_kv.py:462-476: bordering, v = L^-1 b by fvgp_hip_trsm_lower with few columns against at least
+    2048 rows -> the transposed block sweep) against a fresh GP on the concatenated data."""
+    import fvgp_amd
+    rng = np.random.default_rng(n + m)
+    x = rng.random((n + m, 3)); y = np.sin(3 * x.sum(1)) + 0.1 * rng.standard_normal(n + m)
+    th = np.array([1.1, 0.3, 0.35, 0.4]); nv = np.full(n + m, 0.01)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = fvgp_amd.GP(x[:n], y[:n], init_hyperparameters=th, noise_variances=nv[:n], kernel_function="rbf_ard")
+        a.update_gp_data(x[n:], y[n:], noise_variances_new=nv[n:], append=True)
+        b = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function="rbf_ard")
+    xp = rng.random((7, 3))
+    np.testing.assert_allclose(a.log_likelihood(), b.log_likelihood(), rtol=1e-10)
+    assert np.max(np.abs(a.posterior_covariance(xp)["S"] - b.posterior_covariance(xp)["S"])) < 1e-10 * th[0]
+    np.testing.assert_allclose(a.posterior_mean(xp)["m(x)"], b.posterior_mean(xp)["m(x)"], rtol=1e-8, atol=1e-10)
