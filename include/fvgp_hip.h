@@ -132,7 +132,9 @@ int fvgp_hip_potrf_dev(fvgp_handle *h, double *A, int64_t n, int64_t lda, int64_
 int fvgp_hip_potrs(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb);
 int fvgp_hip_logdet(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *out_host);
 int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *work, int64_t ldw);
-/* forward half only: B <- L^-1 B (used by the posterior covariance, gp_posterior.py:120-136) */
+/* forward half only: B <- L^-1 B (the new rows of an append, gp_lin_alg.py:1310-1477; the posterior covariance of kernel callables,
+ * gp_posterior.py:120-136).  One column: the one-launch forward sweep; 128 .. 1024 columns against >= 2048 rows: the right-hand
+ * sides are transposed into handle scratch (nrhs x padded_dim(n) doubles) and swept with the inverted diagonal blocks. */
 int fvgp_hip_trsm_lower(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb);
 
 /* backward half only: B <- L^-T B, nrhs a multiple of 128 (GEMM path) */
