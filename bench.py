@@ -71,10 +71,13 @@ def cpu_baseline(n_full, d, sample_n):
     threads = _blas_threads()
     theta = np.array([1.0] + [0.3] * d)
 
+    last = {}
+
     def run(n):
         x, y = synth(n, d)
         t0 = time.perf_counter()
-        _, st = orc.log_likelihood_once(x, y, np.full(n, 0.01), theta, "rbf_ard")
+        ll, st = orc.log_likelihood_once(x, y, np.full(n, 0.01), theta, "rbf_ard")
+        last.update(n=n, loglik=float(ll))          # kept: the HIP path is checked against it (headline_parity)
         return time.perf_counter() - t0, st
 
     def scaled(st, r):
@@ -92,7 +95,8 @@ def cpu_baseline(n_full, d, sample_n):
                                f"{st['kmat']:.1f}s addKV {st['addKV']:.1f}s potrf {st['potrf']:.1f}s solve+logdet "
                                f"{st['solve_logdet']:.1f}s = {wall:.1f}s wall (BLAS threads {threads}, host cpus {os.cpu_count()}, "
                                f"RAM {ram:.0f} GB); measured, not extrapolated"),
-                    "measured_seconds": wall, "extrapolated": False}
+                    "measured_seconds": wall, "extrapolated": False, "oracle_n": last["n"], "oracle_loglik": last["loglik"],
+                    "oracle_theta": theta.tolist()}
         sample_n = 18000
     wall, st = run(sample_n)
     est = scaled(st, n_full / sample_n)
@@ -101,7 +105,33 @@ def cpu_baseline(n_full, d, sample_n):
                        f"{st['addKV']:.2f}s potrf {st['potrf']:.2f}s solve+logdet {st['solve_logdet']:.2f}s "
                        f"(wall {wall:.1f}s, BLAS threads {threads}, host cpus {os.cpu_count()}, RAM {ram:.0f} GB); scaled to "
                        f"N={n_full} with N^2 (assembly, addKV, solve) and N^3 (potrf) -> {est:.0f}s per evaluation"),
-            "measured_seconds_at_sample": wall, "extrapolated": True}
+            "measured_seconds_at_sample": wall, "extrapolated": True, "oracle_n": last["n"], "oracle_loglik": last["loglik"],
+            "oracle_theta": theta.tolist()}
+
+
+def headline_parity(cb, n, d, hip_at_n, device):
+    """The HIP path against the log-likelihood the CPU leg's oracle run computed -- same synthetic inputs, same theta, outside the
+    timed region.  When the oracle ran the full workload the HIP value is the one evaluated on the bench's own resident buffers
+    (`hip_at_n`); when it ran a bounded sample the HIP path is evaluated once at that sample's size.  Tolerance: rel 1e-10
+    (log-likelihood)."""
+    from fvgp_amd import _lib
+    theta, on = np.array(cb["oracle_theta"]), int(cb["oracle_n"])
+    if on == n and hip_at_n is not None:
+        hip = hip_at_n
+    else:
+        H = _lib.Handle(device)
+        x, y = synth(on, d)
+        npad = _lib.pad128(on)
+        KV, alpha = H.empty(npad, npad), H.empty(npad, 1)
+        hip, _, _, info = H.loglik(0, H.to_device(x), theta, H.to_device(np.full(on, 0.01)), H.to_device((y - np.mean(y)).reshape(on, 1)), KV, alpha)
+        del KV, alpha
+        H.close()
+        if info != 0:
+            hip = float("nan")
+    ref = float(cb["oracle_loglik"])
+    rel = abs(hip - ref) / abs(ref)
+    return {"workload": f"N={on} d={d} RBF log_likelihood(theta), the bench's synthetic data" + ("" if on == n else " (the CPU leg's sample size)"),
+            "theta": theta.tolist(), "hip": hip, "oracle": ref, "rel_diff": rel, "tolerance": 1e-10, "ok": bool(rel <= 1e-10)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -402,6 +432,7 @@ def main():
     ap.add_argument("--sharded-timeout", type=float, default=600.0)
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="0 = the full workload if the host can hold it, else N=18000 scaled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inject-sharded-failure", action="store_true", help=argparse.SUPPRESS)   # tests: the sharded run raises on every rank
     ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C3 / C5 records measured after the timed region")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
@@ -433,6 +464,8 @@ def main():
     sharded_error = None
     if args.mode == "sharded" or (args.mode == "auto" and world > 1):
         try:
+            if args.inject_sharded_failure:
+                raise RuntimeError("injected failure of the row-sharded evaluation (test hook)")
             return sharded_main(args, x, y, world, rank, local, dist)
         except Exception as e:              # noqa: BLE001 -- an exception (not a hang: the watchdog owns those) on the sharded path
             if args.mode == "sharded" or dist is None:
@@ -487,6 +520,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     H.set_option("profile", 0)
+    # outside the timed region: one evaluation at the theta the CPU leg's oracle runs, on the same resident buffers (headline_parity)
+    hip_theta0 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        hip_theta0, _, _, info0 = H.loglik(0, xd, theta0, vd, ymd, KV, alpha)
+        if info0 != 0:
+            hip_theta0 = float("nan")
 
     out = None
     if rank == 0:
@@ -539,16 +578,26 @@ def main():
                 out["configs"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline:                                # the CPU leg is timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_sample_n)
+            out["headline_parity"] = headline_parity(out["cpu_baseline"], n, d, hip_theta0, local)
     if rank == 0:
         if sharded_error is not None:
-            out["sharded_error"] = ("the row-sharded evaluation raised on this node, the line reports the replicas instead: "
-                                    + sharded_error)[:600]
+            # same shape as the watchdog's line: the headline of an N > 1 run is ONE evaluation sharded over the ranks; it raised, so
+            # the line says value 0.0 + error and the replicas measured here ride along as a side record (exit code 4 below)
+            out = {"metric": out["metric"], "value": 0.0, "unit": out["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": out["config"]["workload"], "n": n, "d": d, "kernel": "rbf_ard",
+                              "parallelism": f"one evaluation row-sharded over {world} GPUs (block-cyclic 128-row blocks)"},
+                   "error": ("the row-sharded evaluation raised: " + sharded_error)[:600],
+                   "replicas": {"value": out["value"], "unit": out["unit"], "scaling": "weak", "ms_per_step": out["ms_per_step"],
+                                "parallelism": out["config"]["parallelism"], "roofline": out["roofline"]}}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None and not out.get("headline_parity", {"ok": True})["ok"]:
+        raise SystemExit(5)                 # the metric's own workload disagrees with the oracle: the number above does not count
     if sharded_error is not None:
-        # the line above is the replicas record, NOT the sharded headline the launch asked for: the launcher must not read a clean exit
+        # the sharded headline the launch asked for did not complete: the launcher must not read a clean exit
         raise SystemExit(4)
 
 

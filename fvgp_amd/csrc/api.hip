@@ -413,7 +413,8 @@ static int panel_factor_nested(fvgp_handle *h, double *A, int64_t n, int64_t np,
 // one panel, every row from its first column down: the resident panel kernel (chain.hip) while enough rows remain for a
 // trailing update to run beside it, else the three launches per 128 columns
 static int panel_factor_any(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
-    if (h->panel_chain && np - J0 >= h->panel_chain_min) return launch_panel_chain(h, A, n, np, lda, J0, Jend);
+    // (the resident kernel has flag words for 32 block columns: a wider panel -- `outer_block` above 4096 -- takes the nested chain)
+    if (h->panel_chain && np - J0 >= h->panel_chain_min && (Jend - J0) / TILE <= FVGP_CHAIN_MAX_BLOCKS) return launch_panel_chain(h, A, n, np, lda, J0, Jend);
     return panel_factor_nested(h, A, n, np, lda, J0, Jend);
 }
 
@@ -501,7 +502,8 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             // updated before its chain starts; the rows below it follow on the main stream beside the chain, whose block rows
             // below the square wait for a flag in memory that a one-thread kernel raises behind that update (chain.hip) -- the
             // update of (rows below) x (panel) leaves the critical path: one launch + one stream hand-over per panel
-            const bool split = can_split && np - Jend >= h->panel_chain_min && np - Jend <= h->cols_split_rows && np > Nend;
+            const bool split = can_split && np - Jend >= h->panel_chain_min && np - Jend <= h->cols_split_rows && np > Nend &&
+                               (Nend - Jend) / TILE <= FVGP_CHAIN_MAX_BLOCKS;
             unsigned long long cols_tag = 0;
             if (split) {
                 GemmDesc s{};          // rows and columns [Jend, Nend): lower tiles
@@ -714,13 +716,15 @@ static int trsm_fwd_gemm_t_block(fvgp_handle *h, const double *L, int64_t n, int
 // by side on the two streams of the handle, each with launches of 256 workgroups: a step of the sweep is three dependent
 // launches with two reductions between them (~66 us of fixed cost per block, 10 blocks at N = 20k), and the other half's
 // product fills the chip while they run.
-static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt) {
+static int trsm_fwd_gemm_t(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *BT, int64_t rows, int64_t ldbt, int64_t block = 0) {
     const bool winv = h->block_inverses != 0;
-    // up to 1024 points the sweep is a chain of dependent launches: 2048-wide blocks, half as many.  Their last doubling level costs
-    // 1.3 ms at N = 20k, more than one sweep gains (0.4 ms at P = 1000, 0.85 at P <= 64): the FIRST sweep on a new factor runs on the
-    // 1024-wide blocks (the diagonal of the same layout), the level is added when a second one follows
-    const int64_t WB = rows <= 1024 ? h->posterior_block : 1024;
-    const int64_t NB = (WB == 2048 && !(h->winv_ok && h->winv_w == 2048)) ? 1024 : WB;
+    // up to 1024 points the sweep is a chain of dependent launches: 2048-wide blocks, half as many (`posterior_block`).  The block
+    // width is a function of the call alone (number of rows, the option, `block` of the caller): the same call gives the same bits
+    // whether it is the first on a factor or the tenth.  The last doubling level of the inverted blocks costs 1.3 ms at N = 20k, once
+    // per factor: a posterior pays it on its first call (the sweeps that follow gain 0.4 ms each at P = 1000, 0.85 at P <= 64);
+    // fvgp_hip_trsm_lower, whose callers solve once per factor (the new rows of an append), asks for 1024.
+    const int64_t WB = block ? block : (rows <= 1024 ? h->posterior_block : 1024);
+    const int64_t NB = WB;
     int rc = winv ? ensure_winv(h, L, n, ldl, WB, NB) : ensure_linv(h, L, n, ldl); if (rc) return rc;
     const bool halves = h->posterior_halves && winv && rows >= 512 && rows <= 1024 && rows % 256 == 0;    // (2048 rows: +3 %)
     const int64_t np = pad128(n);
@@ -924,7 +928,7 @@ int fvgp_hip_trsm_lower(fvgp_handle *h, const double *L, int64_t n, int64_t ldl,
             h->tr_ws_cap = need;
         }
         rc = launch_transpose(h, B, ldb, h->tr_ws, np, np, nrhs); if (rc) return rc;
-        rc = trsm_fwd_gemm_t(h, L, n, ldl, h->tr_ws, nrhs, np); if (rc) return rc;
+        rc = trsm_fwd_gemm_t(h, L, n, ldl, h->tr_ws, nrhs, np, 1024); if (rc) return rc;
         return launch_transpose(h, h->tr_ws, np, B, ldb, nrhs, np);
     }
     return trsm_fwd_gemm(h, L, n, ldl, B, nrhs, ldb);

@@ -480,10 +480,11 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
 
     __builtin_amdgcn_s_setprio(2);
     int *yslot = nullptr;
-    if (g.yield_below && g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
     const int stride = (int)gridDim.x - n;
     double4_t xt[8];
-    if (g.cols_tag && !chain_wait(g, F_COLS, g.cols_tag, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
+    // (the yield counter goes up AFTER this wait: the update these rows wait for polls that counter on the same compute units)
+    if (g.cols_tag && !chain_wait(g, F_COLS, g.cols_tag, &s_i[1])) return;
+    if (g.yield_below && g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
     for (int row = t; row < g.rows; row += stride) {
         // ---- a block row below the square, left-looking ----
         double *Ar = g.A + (long)row * 128 * g.lda;
@@ -566,7 +567,7 @@ int launch_chain_cols_ready(fvgp_handle *h, unsigned long long tag) {
 // cols_tag_out != nullptr: the block rows below the square wait for launch_chain_cols_ready(*cols_tag_out) on another stream.
 int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, int64_t lda, int64_t J0, int64_t Jend, unsigned long long *cols_tag_out) {
     const int64_t w = Jend - J0;
-    if (w <= 0 || w % TILE || J0 % TILE || np % TILE || Jend > np || w / TILE > 32) { fvgp_set_error("panel chain: bad panel"); return -5; }
+    if (w <= 0 || w % TILE || J0 % TILE || np % TILE || Jend > np || w / TILE > FVGP_CHAIN_MAX_BLOCKS) { fvgp_set_error("panel chain: bad panel"); return -5; }
     if (lda >= (1L << 21) || (lda & 1) || ((uintptr_t)A & 15)) { fvgp_set_error("panel chain: leading dimension / alignment"); return -4; }
     if (!h->chain_flags) {
         HIPCHK(hipMalloc((void **)&h->chain_flags, 80 * 16 * sizeof(unsigned long long)));

@@ -328,7 +328,11 @@ static int dist_after_factor_check(fvgp_handle *h, const fvgp_dist_desc *d) {
         fvgp_set_error("no collectives bound to this handle: call fvgp_hip_comm_init first"); return 2003;
     }
     if (!d->keep_factor) { fvgp_set_error("dist: the last evaluation did not keep its factor (keep_factor = 0)"); return -2; }
-    return 0;
+    // the handle scratch the sweeps below draw on (split-K partials of fvgp_hip_gemm: at most 512 tiles; the block sweep of
+    // fvgp_hip_trsm_lower: as much again) is sized ONCE here: growing it later means hipFree + hipMalloc, a device-wide
+    // synchronisation in the middle of a multi-rank sequence of collectives
+    HIPCHK(hipSetDevice(h->device));
+    return ensure_scratch(h, 2 * 512 * (int64_t)LEAF_DOUBLES / 8 + 1024);
 }
 
 int64_t fvgp_hip_dist_scratch(const fvgp_dist_desc *d, int what, int64_t npred, int64_t slab) {

@@ -299,11 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         // 64-cycle MFMA: 130-250 us for a leaf instead of 37.  It raises its CU's counter; every wave here reads that word once
         // per K step with a scalar load (no vector-ALU work: issued behind the step's LDS reads, long landed when the step's
         // MFMAs are through) and sleeps while it is up.  Bounded: a wave sleeps at most ~1 ms per tile whatever the counter says.
-#ifdef FVGP_NO_YIELD
-        constexpr bool YIELD = false;             // (A/B build: tools/build_variant.sh noyield -DFVGP_NO_YIELD)
-#else
         constexpr bool YIELD = ROLE == 1;
-#endif
         const int *yp = nullptr;
         int ybudget = 256;
         if constexpr (YIELD) yp = cu_yield_slot(const_cast<int *>(g.yield));
@@ -719,9 +715,12 @@ __device__ __forceinline__ void trsm_tiles_chunk(const TrsmTilesArgs &g, const i
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]), a_src, vo, (2 * p + wave_u) * arow, 0);
 }
 
-// at most 256 registers: under look-ahead a workgroup must fit beside the ONE trailing-update wave (224) a SIMD keeps when the other
-// update workgroup of its compute unit retires (with 362 the kernel waited for the whole update to drain: 5 ms at 20k rows)
-__global__ __launch_bounds__(128, 2) void trsm_tiles_kernel(TrsmTilesArgs g) {
+// 236 VGPR + 54 AGPR = 296 registers per lane (two of the four phases of L in registers at a time: 362 with all four), i.e. one
+// wave per SIMD: beside a trailing update whose waves hold 224 each a workgroup starts once BOTH update workgroups of a compute
+// unit have retired.  Used by the launch-per-step chain only -- panels with fewer than 4096 rows below them, where no large
+// update runs beside the chain, and the row-sharded driver's stacked panel; the resident panel kernel (chain.hip) solves by
+// trsm_sub at <= 128 registers.
+__global__ __launch_bounds__(128) void trsm_tiles_kernel(TrsmTilesArgs g) {
     constexpr int LDS_ = 130;
     __shared__ double sX[32 * LDS_];
     __shared__ double sL[32 * LDS_];

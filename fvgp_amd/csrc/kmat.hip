@@ -34,7 +34,10 @@ struct KArgs {
 // exp(-r) (max. relative error 2e-17 of the polynomial, below 1 ulp with the rounding of the Horner steps), the scaling by one
 // v_ldexp_f64 (which flushes through the subnormals to 0 by itself: no range checks).  17 fp64 operations, no comparison, no
 // select (the library call carries four of each for arguments that cannot occur here).
-__device__ __forceinline__ double exp_neg(const double a) {
+__device__ __forceinline__ double exp_neg(const double a0) {
+    // beyond 800 the result is 0 whatever the argument (+inf included: the reduction below would make inf - inf of it); a NaN
+    // fails the comparison and stays a NaN, as numpy's exp leaves it (kernels.py:16-33)
+    const double a = a0 > 800.0 ? 800.0 : a0;
     const double n = __builtin_rint(a * 1.4426950408889634074);          // a / ln 2
     double r = fma(n, -6.93147180369123816490e-01, a);                    // ln2 in two pieces: r = a - n ln2, exact product
     r = fma(n, -1.90821492927058770002e-10, r);
@@ -60,7 +63,7 @@ __device__ __forceinline__ double exp_neg(const double a) {
 // scaled distances need none of it).  x is first raised to 1e-300, so the diagonal (x = 0) gives 1e-150, which every radial function
 // here maps to the same bits as 0.
 __device__ __forceinline__ double sqrt_pos(const double x0) {
-    const double x = __builtin_fmax(x0, 1e-300);
+    const double x = x0 < 1e-300 ? 1e-300 : x0;          // (not fmax: a NaN distance stays a NaN, kernels.py:461-481)
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);

@@ -52,6 +52,7 @@ enum fvgp_uplo { FVGP_FULL = 0, FVGP_LOWER = 1 };
 #define FVGP_TILE 128
 #define FVGP_MAX_DIM 16     /* input dimension limit of the assembly kernels */
 #define FVGP_MAX_RHS_VEC 8  /* potrs switches from the GEMV path to the GEMM path above this */
+#define FVGP_CHAIN_MAX_BLOCKS 32   /* widest panel (in 128-column blocks) the resident panel kernel takes; wider ones use the launch-per-step chain */
 
 int fvgp_hip_version(void);
 const char *fvgp_hip_last_error_string(void);
@@ -72,7 +73,8 @@ int fvgp_hip_stream_create(void **out_stream, int device, int high_priority, con
 int fvgp_hip_stream_destroy(void *stream);
 /* Every key has a default and a test (tests/test_gpu_primitives.py); none changes a result except where noted "order": another,
  * equally valid order of the same sums (LAPACK accuracy either way).
- *   panel widths ("order"): "outer_block" (1024: panel width = K of the trailing update, multiple of 128),
+ *   panel widths ("order"): "outer_block" (1024: panel width = K of the trailing update, multiple of 128; any multiple is accepted,
+ *       panels wider than 4096 are factored by the launch-per-step chain whatever "panel_chain" says),
  *       "outer_block_big" / "big_threshold" (2048 while more than 24576 rows remain), "outer_block_small" / "small_threshold"
  *       (512 for the last 12288 rows), "inner_block" / "panel_recursive" (how the three-launch chain splits a panel);
  *   panel chain: "panel_chain" (1: one resident kernel per panel, csrc/chain.hip, for panels with at least "panel_chain_min" = 4096
@@ -134,7 +136,7 @@ int fvgp_hip_logdet(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, dou
 int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *work, int64_t ldw);
 /* forward half only: B <- L^-1 B (the new rows of an append, gp_lin_alg.py:1310-1477; the posterior covariance of kernel callables,
  * gp_posterior.py:120-136).  One column: the one-launch forward sweep; 128 .. 1024 columns against >= 2048 rows: the right-hand
- * sides are transposed into handle scratch (nrhs x padded_dim(n) doubles) and swept with the inverted diagonal blocks. */
+ * sides are transposed into handle scratch (nrhs x padded_dim(n) doubles) and swept with the inverted 1024 x 1024 diagonal blocks. */
 int fvgp_hip_trsm_lower(fvgp_handle *h, const double *L, int64_t n, int64_t ldl, double *B, int64_t nrhs, int64_t ldb);
 
 /* backward half only: B <- L^-T B, nrhs a multiple of 128 (GEMM path) */
@@ -275,8 +277,9 @@ int fvgp_hip_grad_trace_cols(fvgp_handle *h, int kernel_id, const double *x, int
  *   L: factor (padded), alpha: KVinvY (padded_dim(n), ncol)
  *   kx: scratch of padded_dim(n) x ldk doubles with ldk >= padded_dim(P); contents unspecified on return (the cross
  *       covariance and L^-1 k pass through it transposed, padded_dim(P) x padded_dim(n)).  The first call after a new factor
- *       also inverts its 1024 x 1024 diagonal blocks into the handle, the second (P <= 1024) doubles them to 2048 x 2048
- *       (fvgp_hip_workspace_bytes counts them)
+ *       also inverts its diagonal blocks into the handle (2048 x 2048 up to 1024 points, option "posterior_block"; 1024 x 1024
+ *       beyond; fvgp_hip_workspace_bytes counts them).  The block width depends on P and the option only: the same call returns
+ *       the same bits whether it is the first on a factor or a later one
  *   mean_out (P, ncol) device  = k^T alpha          (prior mean added by the caller)
  *   S_out (padded_dim(P), lds) device or NULL  = kk - k^T KV^-1 k  (full, symmetric)
  *   var_out (P) device  = diag of the above (unclipped; clipping is gp_posterior.py:248-259, caller side) */
@@ -291,7 +294,9 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
  *   b_nmajor == 0: B stored (N,K) row-major (C = A B^T); != 0: B stored (K,N) row-major
  *   lower != 0: only 128x128 tiles with row-tile >= col-tile are computed (SYRK-style)
  * With fewer than 256 output tiles and K >= 1024 the K range is split over workgroups and the partial tiles added in a fixed
- * order (handle scratch): same result on every run, another rounding than the unsplit product. */
+ * order (handle scratch, at most 64 MB): same result on every run, another rounding than the unsplit product.  The split needs
+ * C 16-byte aligned with an even ldc; a C that is not takes the unsplit product (state it if rounding must not depend on where a
+ * buffer lies: pass aligned buffers). */
 int fvgp_hip_gemm(fvgp_handle *h, int a_kmajor, int b_nmajor, int lower, int64_t M, int64_t N, int64_t K,
                   double alpha, const double *A, int64_t lda, const double *B, int64_t ldb,
                   double beta, double *C, int64_t ldc);

@@ -28,7 +28,7 @@ def cpu_abi():
     """the CPU twin of the ABI, loaded once (built by __graft_entry__.build(); built here if missing)"""
     global _CPU
     if _CPU is None:
-        path = os.path.join(ROOT, "oracle", "_cpu", "libfvgp_cpu.so")
+        path = os.environ.get("FVGP_CPU_LIB") or os.path.join(ROOT, "oracle", "_cpu", "libfvgp_cpu.so")     # (make -C oracle asan-test: the sanitizer build)
         if not os.path.exists(path):
             subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
         _CPU = _lib.bind_dist(ctypes.CDLL(path))

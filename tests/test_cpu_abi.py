@@ -14,7 +14,7 @@ import pytest
 
 from conftest import ROOT, load_golden
 
-LIB = os.path.join(ROOT, "oracle", "_cpu", "libfvgp_cpu.so")
+LIB = os.environ.get("FVGP_CPU_LIB") or os.path.join(ROOT, "oracle", "_cpu", "libfvgp_cpu.so")     # (make -C oracle asan-test: the sanitizer build)
 REF = "/root/reference"
 c_i, c_l, c_d, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
 KID = {"rbf_ard": 0, "matern32_ard": 1, "matern52_ard": 2}

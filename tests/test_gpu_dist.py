@@ -259,3 +259,75 @@ def test_bench_multi_rank_line_is_the_sharded_evaluation(tmp_path):
     assert out["collectives"]["all_gather"]["bytes_received_per_rank_per_eval"] > 0
     assert out["roofline"]["launches"] > 0 and 0.0 < out["roofline"]["frac"] < 1.0
     assert out["replicas"]["value"] > 0 and out["replicas"]["scaling"] == "weak"
+
+
+def test_bench_line_when_the_sharded_evaluation_raises(tmp_path):
+    """bench.py with 2 ranks whose sharded evaluation raises (test hook): the ONE line says value 0.0 + error like the watchdog's,
+    the replicas ride along as a side record, the exit code is 4."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, FVGP_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--npoints", "4000", "--backend", "gloo",
+                          "--inject-sharded-failure"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert res.returncode != 0
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads(lines[0])
+    assert out["value"] == 0.0 and out["scaling"] == "strong" and "injected failure" in out["error"]
+    assert out["replicas"]["value"] > 0 and out["replicas"]["scaling"] == "weak"
+
+
+WORKER_FULL = r'''
+import os, sys, json
+os.environ["FVGP_DEVICE"] = "0"          # every rank on the one GPU of the test box
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from conftest import synth
+from fvgp_amd.dist import ShardedGP
+torch.cuda.set_device(0)
+dist.init_process_group(backend="gloo")
+n, d = {n}, 3
+x, y = synth(n, d)
+theta = np.array([1.0, 0.3, 0.3, 0.3])
+gp = ShardedGP(x, y, np.full(n, 0.01), kernel={kernel!r}, panel={panel})
+lls = [gp.log_likelihood(theta * (1 + 0.02 * t))[0] for t in range(2)]
+ev = gp.evaluate(theta, want_alpha=True)
+xp = np.random.default_rng(3).random(({npred}, d))
+mean, S = gp.posterior(xp)
+g = gp.gradient()
+if dist.get_rank() == 0:
+    np.savez({out!r}, lls=np.array(lls), ev=np.array(ev), alpha=gp.alpha[:n, 0].cpu().numpy(), mean=mean, S=S, g=g)
+    print("RESULT " + json.dumps(dict(ok=True)))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,n,panel,kernel,npred", [
+    (4, 3000, 512, "rbf_ard", 150),            # one 128-block per rank and panel: the diagonal block is gathered IN PLACE (dist_driver.h, chain step 1)
+    (2, 20000, 1024, "rbf_ard", 200),          # C2's size at the default panel width
+])
+def test_default_panel_shapes_over_gloo_against_the_oracle(tmp_path, world, n, panel, kernel, npred):
+    """The row-sharded path at the panel shapes an 8-GPU run takes by default -- 1024-wide panels, and the in-place gather of the
+    diagonal block (ranks == blocks per panel) -- on the HIP ops with more than one rank (ranks share the box's GPU, gloo
+    callbacks): log-likelihood, KVinvY, posterior mean / covariance and gradient against the oracle on the same inputs."""
+    out = str(tmp_path / "full.npz")
+    _spawn(tmp_path, WORKER_FULL.format(root=ROOT, n=n, panel=panel, kernel=kernel, npred=npred, out=out), world)
+    r = np.load(out)
+    x, y = synth(n, 3)
+    nv = np.full(n, 0.01)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    for t, ll in enumerate(r["lls"]):
+        ref, _ = orc.log_likelihood_once(x, y, nv, theta * (1 + 0.02 * t), kernel)
+        np.testing.assert_allclose(ll, ref, rtol=1e-10)
+    ref = orc.OracleGP(x, y, theta, nv, kernel=kernel)
+    np.testing.assert_allclose(r["ev"][0], ref.log_likelihood(), rtol=1e-10)
+    np.testing.assert_allclose(r["ev"][1], ref.logdet_KV, rtol=1e-10)
+    assert np.max(np.abs(r["alpha"] - ref.KVinvY[:, 0])) <= 1e-8 * np.max(np.abs(ref.KVinvY))
+    xp = np.random.default_rng(3).random((npred, 3))
+    np.testing.assert_allclose(r["mean"][:, 0] + np.mean(y), ref.posterior_mean(xp)["m(x)"], rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(r["S"] - ref.posterior_covariance(xp)["S"])) <= 1e-10
+    g_ref = ref.neg_log_likelihood_gradient_potri(theta) if n > 4000 else ref.neg_log_likelihood_gradient(theta)
+    np.testing.assert_allclose(r["g"], g_ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(g_ref)))

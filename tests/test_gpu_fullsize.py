@@ -94,6 +94,43 @@ def test_config2_n20000_against_the_oracle():
     np.testing.assert_allclose(gp.log_likelihood(t2), ref.log_likelihood(t2), rtol=1e-10)
 
 
+def test_headline_n50000_rbf():
+    """The metric's own workload (BASELINE.json: N=50k d=3 RBF, bench.py's synthetic data and theta): residual of
+    KV alpha = y - m with K re-assembled in full, entries of L L^T against assembled entries, the log-likelihood's pieces, and
+    a second evaluation at another theta that must leave the state alone (gp_marginal_likelihood.py:137-179).  bench.py itself
+    compares this workload with the oracle's value on the box's host (`headline_parity`)."""
+    import fvgp_amd
+    import torch
+    n = 50000
+    x, y = synth(n, 3)
+    nv = np.full(n, 0.01)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    gp = fvgp_amd.GP(x, y, init_hyperparameters=theta, noise_variances=nv, kernel_function="rbf_ard")
+    H = gp._H
+    K = H.empty(n, n)
+    H.kmat(0, gp._x_dev, gp._x_dev, theta, K)
+    H.sync()
+    alpha = gp._alpha[:n, 0]
+    ym = H.to_device(y - np.mean(y))
+    res = K @ alpha + H.to_device(nv) * alpha - ym
+    assert float(res.norm() / ym.norm()) < 1e-9
+    rng = np.random.default_rng(1)
+    pairs = [(int(a), int(b)) for a, b in rng.integers(0, n, (64, 2))] + [(n - 1, n - 1), (0, 0), (n - 1, 0), (n - 1, n - 2)]
+    got = _entries_of_LLt(gp, pairs)
+    want = np.array([float(K[i, j].item()) + (nv[i] if i == j else 0.0) for i, j in pairs])
+    assert np.max(np.abs(got - want)) < 1e-11
+    del K
+    torch.cuda.empty_cache()
+    quad = float((ym * alpha).sum().item())
+    ll = -0.5 * (quad + gp.logdet_KV + n * np.log(2 * np.pi))
+    np.testing.assert_allclose(gp.log_likelihood(), ll, rtol=1e-12)
+    # log|KV| = 2 sum log L_ii from the factor itself
+    np.testing.assert_allclose(gp.logdet_KV, 2.0 * float(torch.log(gp._L.diagonal()[:n]).sum().item()), rtol=1e-12)
+    l2 = gp.log_likelihood(theta * 1.02)
+    assert np.isfinite(l2) and l2 != ll
+    np.testing.assert_allclose(gp.log_likelihood(theta), ll, rtol=1e-12)
+
+
 def test_config3_n50000_matern52_value_and_gradient():
     """C3: N=50k d=3 Matern-5/2: log marginal likelihood + hyperparameter gradient on one MI355X."""
     import fvgp_amd

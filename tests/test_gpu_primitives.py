@@ -301,6 +301,34 @@ def test_kmat_rectangular(H, name, d):
     assert np.all(gp[300:, :] == 0) and np.all(gp[:, 201:] == 0)
 
 
+@pytest.mark.parametrize("name", ["rbf_ard", "matern32_ard", "matern52_ard"])
+def test_kmat_nan_and_far_points_follow_numpy(H, name):
+    """What numpy's exp / sqrt make of unusual inputs (kernels.py:16-33,98-118,166-188,461-481), the device assembly makes too:
+    a NaN coordinate gives a NaN row and column (not a finite covariance), points so far apart that the squared scaled distance
+    overflows give exactly 0 for the RBF (exp(-inf)) and numpy's own inf * 0 = NaN for the Matern forms, large finite distances
+    give exactly 0."""
+    from fvgp_amd import _lib
+    rng = np.random.default_rng(15)
+    x1 = rng.random((260, 3)); x2 = rng.random((140, 3))
+    x1[7, 1] = np.nan                      # a NaN point
+    x1[9] = 1e160                          # squared distance overflows to inf
+    x2[3, 0] = -1e100                      # huge but finite distance
+    x2[5, 2] = np.nan
+    theta = np.array([1.3, 0.3, 0.4, 0.5])
+    with np.errstate(all="ignore"):
+        ref = orc.KERNELS[name](x1, x2, theta)
+    K = H.to_device(np.full((260, 140), 7.0))
+    H.kmat(_lib.KERNEL_IDS[name], H.to_device(x1), H.to_device(x2), theta, K, pad=_lib.PAD_NONE)
+    H.sync()
+    got = K.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.all(np.isnan(got[7])) and np.all(np.isnan(got[:, 5]))
+    ok = ~np.isnan(ref)
+    assert np.max(np.abs(got[ok] - ref[ok])) <= 8 * EPS * theta[0]
+    far = np.zeros_like(ok); far[:, 3] = True; far &= ok
+    assert np.all(got[far] == 0.0) and np.all(ref[far] == 0.0)
+
+
 @pytest.mark.parametrize("name,d", KERNEL_CASES[:4])
 def test_kmat_lower_padded_with_noise(H, name, d):
     from fvgp_amd import _lib
@@ -369,7 +397,7 @@ def test_potrf_solve_logdet(H, n, outer):
     H.sync()
     ref = sla.solve_triangular(Lref, rhs, lower=True)
     assert np.max(np.abs(B.cpu().numpy()[:n] - ref)) / np.max(np.abs(ref)) < 1e-12
-    H.set_option("outer_block", 512)
+    H.set_option("outer_block", 1024)          # the library default (common.h)
 
 
 @pytest.mark.parametrize("n,nrhs", [(2500, 128), (4200, 384), (2048, 1024)])
@@ -448,10 +476,37 @@ def test_potrf_panel_schedules_agree(H, sched):
         want = sla.cho_solve((Lref, True), b[:n, 0])
         assert np.max(np.abs(B.cpu().numpy()[:n, 0] - want)) / np.max(np.abs(want)) < 1e-9
     finally:
-        for k, v in dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=1,
-                         leaf_tiles_rows=8192, panel_recursive=1, panel_chain=1, panel_chain_min=4096, outer_block_small=512,
-                         small_threshold=12288, lookahead_min=4608, cols_split=1, cols_split_rows=8192).items():
+        _restore_schedule_defaults(H)
+
+
+def _restore_schedule_defaults(H):
+    """the library's own defaults (fvgp_amd/csrc/common.h) for every key the schedule tests touch: the handle is shared by the module"""
+    for k, v in dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=1,
+                     leaf_tiles_rows=4096, panel_recursive=1, panel_chain=1, panel_chain_min=4096, outer_block_small=512,
+                     small_threshold=12288, lookahead_min=4608, cols_split=1, cols_split_rows=8192).items():
+        H.set_option(k, v)
+
+
+def test_panels_wider_than_the_resident_kernel_takes(H):
+    """outer_block accepts any multiple of 128; the resident panel kernel has flag words for 32 block columns (4096): a wider
+    panel -- here ONE panel of 8192 columns over a 9000-row matrix, with enough rows below it for the resident kernel to be
+    chosen -- is factored by the launch-per-step chain instead of failing the factorisation, and matches LAPACK."""
+    from fvgp_amd._lib import pad128
+    n = 9000
+    M = _spd(n, 23)
+    Lref = np.tril(sla.cho_factor(M, lower=True)[0])
+    try:
+        for k, v in dict(outer_block=8192, outer_block_big=0, outer_block_small=0).items():
             H.set_option(k, v)
+        npad = pad128(n)
+        buf = np.zeros((npad, npad))
+        buf[:n, :n] = np.tril(M)
+        A = H.to_device(buf)
+        assert H.potrf(A, n) == 0
+        L = np.tril(A.cpu().numpy()[:n, :n])
+        assert np.max(np.abs(L - Lref)) / np.max(np.abs(Lref)) < 1e-13
+    finally:
+        _restore_schedule_defaults(H)
 
 
 def test_potrf_nonpd_info(H):
@@ -626,6 +681,39 @@ def test_scheduling_mechanisms_do_not_change_a_bit(H):
     assert info == 0
     assert abs(ll - out[0][0]) <= 1e-12 * abs(ll) and abs(logdet - out[0][1]) <= 1e-12 * abs(logdet)
     assert np.max(np.abs(alpha[:n, 0].cpu().numpy() - out[0][3])) <= 1e-9 * np.max(np.abs(out[0][3]))
+
+
+@pytest.mark.parametrize("n", [8000, 12000])
+def test_resident_panel_kernel_soak(H, n):
+    """30 evaluations of the same theta with look-ahead on (the resident panel kernel of chain.hip beside a full trailing update:
+    uneven load, consumers with warm caches), the matrix buffer poisoned with NaN before each: log-likelihood, log-det, quadratic
+    form, alpha and every entry of L must come out with the same bits each time -- a stale or torn in-launch hand-off would change
+    some of them -- and agree with LAPACK's answer (the oracle) to rounding."""
+    import torch
+    from fvgp_amd import _lib
+    from oracle import fvgp_oracle as orc
+    x, y = synth(n, 3)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    npad = _lib.pad128(n)
+    xd = H.to_device(x); vd = H.to_device(np.full(n, 0.01))
+    ymd = H.zeros(npad, 1); ymd[:n, 0] = H.to_device(y - np.mean(y))
+    KV = H.empty(npad, npad); alpha = H.empty(npad, 1)
+    ref = None
+    differ = 0
+    for _ in range(30):
+        KV.fill_(float("nan"))
+        out = H.loglik(0, xd, theta, vd, ymd, KV, alpha)
+        H.sync()
+        assert out[3] == 0
+        a, L = alpha[:n, 0].clone(), KV[:n, :n].tril()
+        if ref is None:
+            ref = (out, a, L)
+        elif not (out == ref[0] and torch.equal(a, ref[1]) and torch.equal(L, ref[2])):
+            differ += 1
+        del a, L
+    assert differ == 0
+    want, _ = orc.log_likelihood_once(x, y, np.full(n, 0.01), theta, "rbf_ard")
+    np.testing.assert_allclose(ref[0][0], want, rtol=1e-10)
 
 
 def test_serialised_kernels_do_not_hang_the_split_update(tmp_path):
