@@ -23,7 +23,7 @@ MAX_RHS_VEC = 8
 # every symbol include/fvgp_hip.h declares (tests check the library exports each of them)
 SYMBOLS = [
     "fvgp_hip_version", "fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_workspace_bytes", "fvgp_hip_create",
-    "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_stream_create", "fvgp_hip_stream_destroy", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_kmat",
+    "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_stream_create", "fvgp_hip_stream_destroy", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_chain_verify_counts", "fvgp_hip_kmat",
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_grad_trace", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower", "fvgp_hip_trace_dot", "fvgp_hip_colsumsq", "fvgp_hip_add_matrix", "fvgp_hip_dot", "fvgp_hip_coldot",
@@ -167,6 +167,7 @@ def lib():
     L.fvgp_hip_stream_destroy.argtypes = [c_p]
     L.fvgp_hip_set_option.argtypes = [c_p, ctypes.c_char_p, c_l]
     L.fvgp_hip_get_profile.argtypes = [c_p, P_d]
+    L.fvgp_hip_chain_verify_counts.argtypes = [c_p, ctypes.POINTER(ctypes.c_int64)]
     L.fvgp_hip_invalidate_factor.argtypes = [c_p]
     L.fvgp_hip_kmat.argtypes = [c_p, c_i, c_p, c_l, c_p, c_l, c_i, P_d, c_i, c_p, c_p, c_l, c_i, c_i]
     L.fvgp_hip_potrf.argtypes = [c_p, c_p, c_l, c_l, P_i]
@@ -264,7 +265,7 @@ class Handle(DistCalls):
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(lib().fvgp_hip_create(ctypes.byref(self._h), self.device, ctypes.c_void_p(stream)), "fvgp_hip_create")
-        for key in ("lookahead", "outer_block", "outer_block_big", "big_threshold", "inner_block", "small_tile_max", "small_tile_max_update", "tile_tables", "block_inverses", "k128_kernels", "leaf_tiles", "leaf_tiles_rows", "panel_recursive", "potri_kminor", "leaf_yield", "chain_yield", "lookahead_min", "posterior_halves", "posterior_block", "outer_block_small", "small_threshold", "panel_chain", "panel_chain_min", "cols_split", "cols_split_rows", "bwd_sweep", "fwd_sweep"):        # tuning overrides, e.g. FVGP_OUTER_BLOCK=512
+        for key in ("lookahead", "outer_block", "outer_block_big", "big_threshold", "inner_block", "small_tile_max", "small_tile_max_update", "tile_tables", "block_inverses", "k128_kernels", "leaf_tiles", "leaf_tiles_rows", "panel_recursive", "potri_kminor", "leaf_yield", "chain_yield", "lookahead_min", "posterior_halves", "posterior_block", "outer_block_small", "small_threshold", "panel_chain", "panel_chain_min", "cols_split", "cols_split_rows", "bwd_sweep", "fwd_sweep", "chain_verify"):        # tuning overrides, e.g. FVGP_OUTER_BLOCK=512
             val = os.environ.get("FVGP_" + key.upper())
             if val is not None:
                 self.set_option(key, int(val))
@@ -317,6 +318,12 @@ class Handle(DistCalls):
         _check(lib().fvgp_hip_get_profile(self._h, out), "fvgp_hip_get_profile")
         return {"launches": out[0], "ms": out[1], "flops": out[2], "potrf_ms": out[3],
                 "kmat_ms": out[4], "kmat_bytes": out[5], "tail_ms": out[6], "host_enqueue_ms": out[7]}
+
+    def chain_verify_counts(self):
+        """(mismatches, comparisons) of the resident panel kernel's hand-off checksums since the last call (option "chain_verify")"""
+        out = (ctypes.c_int64 * 2)()
+        _check(lib().fvgp_hip_chain_verify_counts(self._h, out), "fvgp_hip_chain_verify_counts")
+        return int(out[0]), int(out[1])
 
     # -- ABI calls -----------------------------------------------------------------------------
     def kmat(self, kernel_id, x1, x2, theta, K, vdiag=None, uplo=FULL, pad=PAD_NONE):

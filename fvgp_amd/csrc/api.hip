@@ -83,6 +83,7 @@ int fvgp_hip_destroy(fvgp_handle *h) {
     if (h->sweep_gran) (void)hipFree(h->sweep_gran);
     if (h->sweep_ticket) (void)hipFree(h->sweep_ticket);
     if (h->chain_flags) (void)hipFree(h->chain_flags);
+    if (h->chain_vhash) (void)hipFree(h->chain_vhash);
     if (h->vec) (void)hipFree(h->vec);
     if (h->hpin) (void)hipHostFree(h->hpin);
     delete h;
@@ -153,6 +154,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "panel_chain")) { if (value < 0 || value > 2) return -3; h->panel_chain = (int)value; return 0; }
     if (!strcmp(key, "panel_chain_min")) { h->panel_chain_min = value; return 0; }
     if (!strcmp(key, "cols_split")) { h->cols_split = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "chain_verify")) { h->chain_verify = value ? 1 : 0; return 0; }
     if (!strcmp(key, "cols_split_rows")) { h->cols_split_rows = value; return 0; }
     if (!strcmp(key, "bwd_sweep")) { h->bwd_sweep = (int)value; return 0; }
     if (!strcmp(key, "fwd_sweep")) { h->fwd_sweep = (int)value; return 0; }
@@ -168,6 +170,16 @@ int fvgp_hip_invalidate_factor(fvgp_handle *h) {
     if (!h) return -1;
     h->winv_ok = false; h->linv_L = nullptr;
     return 0;
+}
+
+int fvgp_hip_chain_verify_counts(fvgp_handle *h, int64_t *out2_host) {
+    if (!h) return -1;
+    if (!out2_host) return -2;
+    HIPCHK(hipSetDevice(h->device));
+    unsigned long long w[2];
+    const int rc = chain_verify_counts(h, w);
+    out2_host[0] = (int64_t)w[0]; out2_host[1] = (int64_t)w[1];
+    return rc;
 }
 
 int fvgp_hip_get_profile(fvgp_handle *h, double *out) {

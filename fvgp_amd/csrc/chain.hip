@@ -51,7 +51,15 @@ struct ChainArgs {
     int leaf_factor, leaf_tiles;      // 1, 1 (run-time values: as constants they change the leaf's code, and its register allocation, for the worse)
     unsigned long *leaf_stamps;       // diagnostics (option "leaf_stamps"): phase times of the runner's leaves
     unsigned long long *stamps; int seq;      // diagnostics (option "chain_stamps"): {launch, code, ticket << 16 | row << 8 | step, 100 MHz time} per event
+    unsigned long long *vhash;        // option "chain_verify" (chain_kernel<true>): payload sums of the hand-offs, see VH_* below
 };
+
+// "chain_verify": every hand-off of the launch carries a checksum of its payload -- the sum of the 64-bit patterns of every double
+// handed over, taken by the producer from the registers / LDS it stores from, published (sc1) before the flag; every consumer sums
+// the bytes as they ARRIVED (the LDS images its LDS-DMA loads filled, the registers its buffer loads returned) and compares.  A
+// stale or torn line changes a sum: VH_BAD counts mismatches, VH_CHECKS comparisons.  The words of a launch: row_done payloads
+// [row][step] (32 x 32), leaf payloads [block] (32), the two counters; zeroed by the host per launch.
+constexpr int VH_ROW = 0, VH_LEAF = 32 * 32, VH_BAD = VH_LEAF + 32, VH_CHECKS = VH_BAD + 1, VH_WORDS = VH_CHECKS + 1;
 
 constexpr int FL = 16;                // 64-bit words between two flags
 constexpr int F_TICKET = 0, F_LEAF = 1, F_ABORT = 2, F_ROW = 3, F_COLS = 40;
@@ -113,12 +121,34 @@ __device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }
 
+__device__ __forceinline__ unsigned long long bits_of(const double v) { return (unsigned long long)__double_as_longlong(v); }
+// sum over the workgroup (chain_verify only)
+__device__ __forceinline__ unsigned long long wg_sum(const unsigned long long v, unsigned long long *s_acc) {
+    __syncthreads();
+    if (threadIdx.x == 0) *s_acc = 0ull;
+    __syncthreads();
+    atomicAdd(s_acc, v);
+    __syncthreads();
+    const unsigned long long r = *s_acc;
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ void verify_compare(const ChainArgs &g, const unsigned long long got, const unsigned long long want) {
+    if (threadIdx.x == 0) {
+        atomicAdd(g.vhash + VH_CHECKS, 1ull);
+        if (got != want) atomicAdd(g.vhash + VH_BAD, 1ull);
+    }
+}
+
 // acc (128 x 128 over eight waves, 2 x 4, 64 x 32 each) = sum_k Aop[row][k] Bop[col][k], k < 16 nk.  Both operands k-minor,
 // row-major; the K loop of the trailing update (gemm.hip): unpadded [128][16] images with XOR-swizzled 16-byte chunks filled
 // by LDS-DMA, lane group q owns k = 4q .. 4q+3 of a step, every address loop-invariant.  All loads sc1.
 // With C given the sum starts at -C (entries above the diagonal of a `lower` block at 0, never read): the caller stores -acc = C - sum.
+// VERIFY: *bsum receives the sum of the bit patterns of every double of the B operand as it landed in LDS (per thread; the caller adds them up)
+template <bool VERIFY = false>
 __device__ __forceinline__ void product(double4_t (&acc)[4][2], const double *Aop, const long lda, const double *Bop, const long ldb,
-                                        const int nk, double *smem, const double *C = nullptr, const long ldc = 0, const bool lower = false) {
+                                        const int nk, double *smem, const double *C = nullptr, const long ldc = 0, const bool lower = false,
+                                        unsigned long long *bsum = nullptr) {
     typedef __attribute__((address_space(3))) void lds_void;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));                  // opaque: the addressing of one product is not kept alive across the others
@@ -174,6 +204,10 @@ __device__ __forceinline__ void product(double4_t (&acc)[4][2], const double *Ao
         constexpr int CUR = decltype(curc)::value;
         if (more) { soff += 128; dma(std::integral_constant<int, CUR ^ 1>{}, soff); }
         const double *ps = &smem[CUR * 2 * IMGD];
+        if constexpr (VERIFY) {           // this step's B image, 2048 doubles: four per thread (a sum does not mind the swizzle)
+            const unsigned long long *pb = reinterpret_cast<const unsigned long long *>(ps + IMGD) + 4 * tid;
+            *bsum += (pb[0] + pb[1]) + (pb[2] + pb[3]);
+        }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             double2_t a2[4], b2[2];
@@ -256,8 +290,11 @@ __device__ __forceinline__ void trsm_load(double4_t (&xt)[8], const double *Ablk
     }
 }
 
-template <bool SC1_STORE>
-__device__ __forceinline__ void trsm_sub(double4_t (&xt)[8], double *Ablk, const long lda, const double *L, const long ldl, const double *dinv, double *sT) {
+// VERIFY: *lsum receives this thread's share of the sum of the bit patterns of L's strictly lower tiles and the tile inverses as they
+// arrived in LDS (the leaf hand-off's payload)
+template <bool SC1_STORE, bool VERIFY = false>
+__device__ __forceinline__ void trsm_sub(double4_t (&xt)[8], double *Ablk, const long lda, const double *L, const long ldl, const double *dinv, double *sT,
+                                         unsigned long long *lsum = nullptr) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -297,6 +334,13 @@ __device__ __forceinline__ void trsm_sub(double4_t (&xt)[8], double *Ablk, const
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA'd tiles have landed
     __syncthreads();
+    if constexpr (VERIFY) {                              // 36 x 256 doubles: eighteen per thread
+        const unsigned long long *pt = reinterpret_cast<const unsigned long long *>(sT);
+        unsigned long long a = 0ull;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) a += pt[tid + 512 * i];
+        *lsum = a;
+    }
     const int pr = 4 * (r & 3) + (r >> 2);           // the row of a 16 x 16 tile this lane supplies as MFMA row r
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -327,8 +371,13 @@ __device__ __forceinline__ void trsm_sub(double4_t (&xt)[8], double *Ablk, const
         u32x4 lo, hi;
         const double2_t d0 = {xt[t][0], xt[t][1]}, d1 = {xt[t][2], xt[t][3]};
         __builtin_memcpy(&lo, &d0, 16); __builtin_memcpy(&hi, &d1, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(lo, a_src, vo, t * 128, SC1_STORE ? 16 : 0);
-        __builtin_amdgcn_raw_buffer_store_b128(hi, a_src, vo, t * 128 + 16, SC1_STORE ? 16 : 0);
+        // (the tile's byte offset goes into the instruction's immediate, NOT the scalar offset operand: with an SGPR there the compiler
+        // assumes that a 16-byte store's data registers may be overwritten by the very next vector instruction -- the documented
+        // exception of the ">64-bit store data" hazard -- and on gfx950 they may not: the checksummed build of this kernel put the
+        // sum for the next store right behind one, and the last lanes of that store went out with the NEW register contents, in one
+        // run of ten (tools/chain_verify_stress.py).  With no SGPR offset the hazard recogniser inserts the wait state.)
+        __builtin_amdgcn_raw_buffer_store_b128(lo, a_src, vo + t * 128, 0, SC1_STORE ? 16 : 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, a_src, vo + t * 128 + 16, 0, SC1_STORE ? 16 : 0);
     }
 }
 
@@ -419,9 +468,11 @@ __device__ __forceinline__ void diag_fused(const ChainArgs &g, const double4_t (
     __syncthreads();
 }
 
+template <bool VERIFY>
 __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
-    __shared__ double smem[NT * TSZ + 128];      // the leaf's packed triangle + 1 / L_aa (74,752 B); the products use the first 64 KB
+    __shared__ double smem[NT * TSZ + LEAF_SRD];      // the leaf's packed triangle + its small arrays (75,792 B); the products use the first 64 KB
     __shared__ int s_i[2];
+    __shared__ unsigned long long s_acc;         // chain_verify: workgroup sums
     const int tid = threadIdx.x;
     if (tid == 0) s_i[0] = (int)(atomicAdd(g.flags + F_TICKET * FL, 1ull) - g.tick0);
     __syncthreads();
@@ -444,7 +495,19 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
             trsm_load(xt, Ar + j * 128, g.lda);
             if (!chain_wait(g, F_LEAF, tag + j + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
             chain_stamp(g, 3, t, row, j);
-            trsm_sub<true>(xt, Ar + j * 128, g.lda, g.A + (long)j * 128 * g.lda + j * 128, g.lda, g.linv + (long)j * LEAF_DOUBLES, smem);
+            if constexpr (!VERIFY) trsm_sub<true>(xt, Ar + j * 128, g.lda, g.A + (long)j * 128 * g.lda + j * 128, g.lda, g.linv + (long)j * LEAF_DOUBLES, smem);
+            else {
+                unsigned long long vs = 0ull;
+                trsm_sub<true, true>(xt, Ar + j * 128, g.lda, g.A + (long)j * 128 * g.lda + j * 128, g.lda, g.linv + (long)j * LEAF_DOUBLES, smem, &vs);
+                // what arrived of leaf j against what leaf j said it stored; then this row's own payload for step j: the solved
+                // block as the registers hold it (exactly the bytes trsm_sub has just stored), published before row_done
+                verify_compare(g, wg_sum(vs, &s_acc), flag_load(g.vhash + VH_LEAF + j));
+                unsigned long long mine = 0ull;
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) mine += (bits_of(xt[tt][0]) + bits_of(xt[tt][1])) + (bits_of(xt[tt][2]) + bits_of(xt[tt][3]));
+                mine = wg_sum(mine, &s_acc);
+                if (tid == 0) flag_store(g.vhash + VH_ROW + row * 32 + j, mine);
+            }
             if (j + 1 == row) {                    // the step the next leaf waits for: its diagonal block straight into the leaf's tiles
                 double4_t res[5];
                 diag_load(res, Ar + row * 128, g.lda);
@@ -458,7 +521,13 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
             chain_stamp(g, 4, t, row, j);
             for (int k = j + 1; k <= row; ++k) {
                 if (k < row && !chain_wait(g, F_ROW + k, tag + j + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
-                product(acc, Ar + j * 128, g.lda, g.A + (long)k * 128 * g.lda + j * 128, g.lda, 8, smem, Ar + k * 128, g.lda, k == row);
+                if constexpr (!VERIFY) product(acc, Ar + j * 128, g.lda, g.A + (long)k * 128 * g.lda + j * 128, g.lda, 8, smem, Ar + k * 128, g.lda, k == row);
+                else {
+                    unsigned long long bs = 0ull;
+                    product<true>(acc, Ar + j * 128, g.lda, g.A + (long)k * 128 * g.lda + j * 128, g.lda, 8, smem, Ar + k * 128, g.lda, k == row, &bs);
+                    bs = wg_sum(bs, &s_acc);
+                    if (k < row) verify_compare(g, bs, flag_load(g.vhash + VH_ROW + k * 32 + j));
+                }
                 epilogue<true, true>(acc, Ar + k * 128, g.lda, k == row);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -471,8 +540,15 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
         la.do_factor = g.leaf_factor; la.a_stride = 0; la.linv_stride = 0; la.stamps = g.leaf_stamps; la.tiles_only = g.leaf_tiles; la.yield = g.yield; la.preloaded = row > 0 ? g.leaf_preloaded : 0;
         const int nv = g.nvalid - 128 * row;
         la.nvalid = nv >= 128 ? 128 : (nv > 0 ? nv : 0);
-        leaf_body<true>(la, Ar + row * 128, g.linv + (long)row * LEAF_DOUBLES, g.logdet + row * 128, g.info_base + 128 * row,
-                        smem, smem + NT * TSZ, tid);
+        if constexpr (!VERIFY) leaf_body<true>(la, Ar + row * 128, g.linv + (long)row * LEAF_DOUBLES, g.logdet + row * 128, g.info_base + 128 * row,
+                                               smem, smem + NT * TSZ, tid);
+        else {
+            unsigned long long ls = 0ull;
+            leaf_body<true, true>(la, Ar + row * 128, g.linv + (long)row * LEAF_DOUBLES, g.logdet + row * 128, g.info_base + 128 * row,
+                                  smem, smem + NT * TSZ, tid, &ls);
+            ls = wg_sum(ls, &s_acc);
+            if (tid == 0) flag_store(g.vhash + VH_LEAF + row, ls);
+        }
         chain_publish(g, F_LEAF, tag + row + 1);
         chain_stamp(g, 2, t, row, row);
         return;
@@ -492,7 +568,14 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
             if (k > 0) {
                 if (!chain_wait(g, F_ROW + k, tag + k, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
                 chain_stamp(g, 6, t, row, k);
-                product(acc, Ar, g.lda, g.A + (long)k * 128 * g.lda, g.lda, 8 * k, smem, Ar + k * 128, g.lda);
+                if constexpr (!VERIFY) product(acc, Ar, g.lda, g.A + (long)k * 128 * g.lda, g.lda, 8 * k, smem, Ar + k * 128, g.lda);
+                else {                            // the B operand is row k's solved blocks of steps 0 .. k-1
+                    unsigned long long bs = 0ull;
+                    product<true>(acc, Ar, g.lda, g.A + (long)k * 128 * g.lda, g.lda, 8 * k, smem, Ar + k * 128, g.lda, false, &bs);
+                    unsigned long long want = 0ull;
+                    if (tid == 0) for (int jj = 0; jj < k; ++jj) want += flag_load(g.vhash + VH_ROW + k * 32 + jj);
+                    verify_compare(g, wg_sum(bs, &s_acc), want);
+                }
                 epilogue<true, false>(acc, Ar + k * 128, g.lda);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -501,7 +584,12 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
             trsm_load(xt, Ar + k * 128, g.lda);
             if (!chain_wait(g, F_LEAF, tag + k + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
             chain_stamp(g, 8, t, row, k);
-            trsm_sub<false>(xt, Ar + k * 128, g.lda, g.A + (long)k * 128 * g.lda + k * 128, g.lda, g.linv + (long)k * LEAF_DOUBLES, smem);
+            if constexpr (!VERIFY) trsm_sub<false>(xt, Ar + k * 128, g.lda, g.A + (long)k * 128 * g.lda + k * 128, g.lda, g.linv + (long)k * LEAF_DOUBLES, smem);
+            else {
+                unsigned long long vs = 0ull;
+                trsm_sub<false, true>(xt, Ar + k * 128, g.lda, g.A + (long)k * 128 * g.lda + k * 128, g.lda, g.linv + (long)k * LEAF_DOUBLES, smem, &vs);
+                verify_compare(g, wg_sum(vs, &s_acc), flag_load(g.vhash + VH_LEAF + k));
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             chain_stamp(g, 9, t, row, k);
@@ -511,6 +599,12 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
 }
 
 __global__ void chain_cols_ready_kernel(unsigned long long *flag, unsigned long long tag) { flag_store(flag, tag); }
+
+// before a verifying launch: its checksum words <- 0, the last launch's counters added to the running totals behind them
+__global__ void chain_verify_begin_kernel(unsigned long long *v) {
+    for (int i = threadIdx.x; i < VH_BAD; i += blockDim.x) v[i] = 0ull;
+    if (threadIdx.x == 0) { v[VH_WORDS] += v[VH_BAD]; v[VH_WORDS + 1] += v[VH_CHECKS]; v[VH_BAD] = 0ull; v[VH_CHECKS] = 0ull; }
+}
 
 // one lane waits up to ~20 ms for *flag to become `tag`: do kernels of two streams really run side by side here?
 __global__ void chain_probe_wait_kernel(const unsigned long long *flag, unsigned long long tag, int *seen) {
@@ -589,7 +683,33 @@ int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, i
     int grid = g.rows < 480 ? g.rows : 480;       // one block row per ticket (the first n: the square), the rows below dealt round-robin beyond 480
     if (grid < g.n) grid = g.n;
     h->chain_tick += (unsigned long long)grid;
-    hipLaunchKernelGGL(chain_kernel, dim3((unsigned)grid), dim3(512), 0, h->stream, g);
+    g.vhash = nullptr;
+    if (h->chain_verify) {
+        // per launch: VH_WORDS checksum words, zeroed on the launch's stream; the counters of all launches add up in the handle's
+        // pair of words behind them (read by fvgp_hip_chain_verify_counts)
+        if (!h->chain_vhash) {
+            HIPCHK(hipMalloc((void **)&h->chain_vhash, (size_t)(VH_WORDS + 2) * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(h->chain_vhash, 0, (size_t)(VH_WORDS + 2) * sizeof(unsigned long long), h->stream));
+        }
+        g.vhash = h->chain_vhash;
+        hipLaunchKernelGGL(chain_verify_begin_kernel, dim3(1), dim3(256), 0, h->stream, h->chain_vhash);
+        hipLaunchKernelGGL(chain_kernel<true>, dim3((unsigned)grid), dim3(512), 0, h->stream, g);
+    } else {
+        hipLaunchKernelGGL(chain_kernel<false>, dim3((unsigned)grid), dim3(512), 0, h->stream, g);
+    }
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// chain_verify: {mismatches, comparisons} over every resident panel kernel launched on this handle since the last call
+int chain_verify_counts(fvgp_handle *h, unsigned long long *out2) {
+    out2[0] = out2[1] = 0;
+    if (!h->chain_vhash) return 0;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(hipStreamSynchronize(h->side));
+    unsigned long long w[4];
+    HIPCHK(hipMemcpy(w, h->chain_vhash + VH_BAD, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    out2[0] = w[0] + w[2]; out2[1] = w[1] + w[3];
+    HIPCHK(hipMemset(h->chain_vhash + VH_BAD, 0, 4 * sizeof(unsigned long long)));
     return 0;
 }

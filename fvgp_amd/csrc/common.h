@@ -100,6 +100,7 @@ struct fvgp_handle {
     double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1, fwd_sweep = 1;
     // the panel chain as one resident kernel per panel (chain.hip): flag words, the launch tag and ticket bases; option "panel_chain"
     unsigned long long *chain_flags = nullptr, chain_tag = 0, chain_tick = 0; int panel_chain = 1; int streams_concurrent = -1;   // -1: not probed yet (chain.hip, chain_streams_concurrent)
+    int chain_verify = 0; unsigned long long *chain_vhash = nullptr;   // option "chain_verify": payload checksums on every hand-off of the resident panel kernel (chain.hip, VH_*)
     int cols_split = 1; int64_t cols_split_rows = 8192;   // (potrf_driver: the next panel's square is updated first, the rows below it beside its chain, while at most this many rows remain)
     int64_t panel_chain_min = 4096;   // ... for panels with at least this many rows from their first column down (below that the chain runs alone on the chip and the three launches per step are as fast)
     int64_t lookahead_min = 4608;     // look-ahead from this many (padded) rows on (a stream switch costs ~12 us: N=4000 +5 % with it, N=4800 -2.5 %, N=6000 -5 %)
@@ -205,6 +206,7 @@ int launch_grad_trace(fvgp_handle *h, const GradDesc &g, int *nblocks_out);
 int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, int64_t lda, int64_t J0, int64_t Jend, unsigned long long *cols_tag_out = nullptr);
 int launch_chain_cols_ready(fvgp_handle *h, unsigned long long tag);
 int chain_streams_concurrent(fvgp_handle *h);
+int chain_verify_counts(fvgp_handle *h, unsigned long long *out2);
 int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid,
                 int tiles_only = 0);
 // X = A inv(L)^T in place for `rows` (a multiple of 32) rows of 128 columns, by substitution over the eight 16-column tiles of

@@ -711,8 +711,8 @@ __device__ __forceinline__ void trsm_tiles_chunk(const TrsmTilesArgs &g, const i
     }
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]), a_src, vo, (2 * p + wave_u) * arow, 0);
+    for (int p = 0; p < 16; ++p)      // (row offset in the VECTOR offset: a 16-byte store with an SGPR offset gets no wait state before its data registers are reused, chain.hip trsm_sub)
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(&sX[(2 * p + wave) * LDS_ + 2 * lane]), a_src, vo + (2 * p + wave) * arow, 0, 0);
 }
 
 // 236 VGPR + 54 AGPR = 296 registers per lane (two of the four phases of L in registers at a time: 362 with all four), i.e. one

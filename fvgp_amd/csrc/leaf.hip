@@ -32,7 +32,7 @@ namespace {
 
 __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
     __shared__ double sT[NT * TSZ];      // 73,728 B
-    __shared__ double srd[128];          // 1 / L_aa
+    __shared__ double srd[LEAF_SRD];     // 1 / L_aa, the W operands of the diagonal tile at hand, the solvers' counter (leaf_body.h)
     leaf_body<false>(g, g.A + (long)blockIdx.x * g.a_stride, g.linv + (long)blockIdx.x * g.linv_stride,
                      g.logdet_part ? g.logdet_part + (long)blockIdx.x * 128 : nullptr, g.info_base + (int)blockIdx.x * 128, sT, srd, (int)threadIdx.x);
 }

@@ -8,6 +8,7 @@ namespace {
 
 constexpr int TSZ = 256;          // a packed 16x16 tile, unpadded: 36 tiles = exactly 72 KB
 constexpr int NT = 36;            // tiles (i,j), j <= i < 8
+constexpr int LEAF_SRD = 128 + 2;      // doubles behind the tiles: 1 / L_aa; the solvers' counter of the factor loop
 
 // element (a, b) of a tile: columns XOR-swizzled by an even mask so that both MFMA fragment read
 // patterns (16 rows x one column pair, one row pair x 16 columns) are LDS bank-conflict free
@@ -86,10 +87,15 @@ __device__ __forceinline__ double sqrt_from(double d, double y) {
 // (r, q) holds D[q + 4v][r] = D[r][q + 4v], so accumulator slot B of lane (r, q) IS the panel entry (row r, panel column q).
 //   1. the 4x4 diagonal block is factored as wave-uniform scalars (its ten entries by readlane): the pivot chain -- four
 //      reciprocal square roots in sequence -- waits for nothing else;
-//   2. every row of the panel is solved against it, column c in lane group c; a finished column reaches the other lane
-//      groups by two gfx950 row swaps per 32-bit half (bcast_block);
+//   2. its inverse W (4x4, lower) follows from the same scalars, column q in lane group q (a dozen flops), and lane (r < 4, q)
+//      keeps W[r][q]: that register IS the A operand of ONE MFMA that solves every row of the panel against the block,
+//      X^T = W R^T (B operand: the accumulator slot as it stands), the result landing in slot 0 of the same lanes.  W's six
+//      entries below its diagonal also go to LDS, transposed into the (free) strict upper half of the 4x4 diagonal block they
+//      invert; its diagonal is 1 / L_rr (srd): the other waves solve their 16 x 16 tiles of the rows below with the same MFMA
+//      (tile_trsm) instead of a per-row substitution, and the inverse of the whole tile follows the same way at the end;
 //   3. the factored panel is both operands of ONE rank-4 MFMA update of the rest of the tile.
-// (The first version swept 16 columns with 15 - J broadcast-and-FMA updates behind each pivot: 7.4k cycles per tile.)
+// (Versions before: 16 columns swept with 15 - J broadcast-and-FMA updates behind each pivot, 7.4k cycles per tile; the panel
+// rows solved per lane group with three dependent cross-lane broadcasts, 4.6k.)
 template <int B>
 struct PanelBlock {
     static __device__ __forceinline__ void step(double4_t &acc, double *sT, double &ykeep, int r, int q, int lane, int &bad) {
@@ -114,16 +120,22 @@ struct PanelBlock {
         const double e33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
         if (!(e33 > 0.0) && bad < 0) bad = R0 + 3;
         const double y3 = rsqrt_nr(e33);
-        // rows of the panel: x_c = (raw_c - sum_{k<c} x_k L[c][k]) y_c, valid in lane group c
-        const double x0 = x * y0;
-        const double X0 = bcast_block<0>(x0);
-        const double x1 = fma(-X0, l10, x) * y1;
-        const double X1 = bcast_block<1>(x1);
-        const double x2 = fma(-X1, l21, fma(-X0, l20, x)) * y2;
-        const double X2 = bcast_block<2>(x2);
-        const double x3 = fma(-X2, l32, fma(-X1, l31, fma(-X0, l30, x))) * y3;
+        // column q of W = inv(L_bb) by forward substitution on the unit vector e_q, in lane group q
         const bool g0 = q == 0, g1 = q == 1, g2 = q == 2;
-        double xf = g0 ? x0 : (g1 ? x1 : (g2 ? x2 : x3));
+        const double w0 = g0 ? y0 : 0.0;
+        const double w1 = ((g1 ? 1.0 : 0.0) - l10 * w0) * y1;
+        const double w2 = fma(-l21, w1, fma(-l20, w0, g2 ? 1.0 : 0.0)) * y2;
+        const double w3 = fma(-l32, w2, fma(-l31, w1, fma(-l30, w0, (q == 3) ? 1.0 : 0.0))) * y3;
+#ifdef EXP_B
+        const double wop = w3;
+#else
+        const double wop = r == 0 ? w0 : (r == 1 ? w1 : (r == 2 ? w2 : (r == 3 ? w3 : 0.0)));      // W[r][q], rows >= 4 of the operand: 0
+#endif
+        if (r < 4 && q < r) sT[el(R0 + q, R0 + r)] = wop;
+        // every row of the panel: X[r][R0 + q] = sum_k W[q][k] R[r][R0 + k], one MFMA, result in slot 0
+        double4_t xs = {0.0, 0.0, 0.0, 0.0};
+        xs = mfma(wop, x, xs);
+        double xf = xs[0];
         // the diagonal entries with one correction step (on this lane group's pivot), zeros above them
         const double eq = g0 ? d00 : (g1 ? e11 : (g2 ? e22 : e33));
         const double yq = g0 ? y0 : (g1 ? y1 : (g2 ? y2 : y3));
@@ -138,13 +150,18 @@ struct PanelBlock {
     }
 };
 
-// one wave: Cholesky of the 16x16 tile at sT (lower part), in place; 1/diag -> srd[0..15]
-// returns the first bad pivot column or -1
-__device__ __forceinline__ int diag_factor(double *sT, double *srd, int lane) {
-    const int r = lane & 15, q = lane >> 4;
+// the symmetric 16 x 16 tile at sT (lower part valid) in the accumulator layout diag_factor works on
+__device__ __forceinline__ double4_t load_sym_tile(const double *sT, int r, int q) {
     double4_t acc;
 #pragma unroll
     for (int v = 0; v < 4; ++v) { const int i = q + 4 * v; acc[v] = (i >= r) ? sT[el(i, r)] : sT[el(r, i)]; }
+    return acc;
+}
+
+// one wave: Cholesky of the symmetric 16x16 tile in `acc` into sT (lower part; the inverses of its 4x4 diagonal blocks into their
+// strict upper halves); 1/diag -> srd[0..15].  Returns the first bad pivot column or -1
+__device__ __forceinline__ int diag_factor_acc(double4_t acc, double *sT, double *srd, int lane) {
+    const int r = lane & 15, q = lane >> 4;
     int bad = -1;
     double ykeep = 0.0;
     PanelBlock<0>::step(acc, sT, ykeep, r, q, lane, bad);
@@ -152,6 +169,43 @@ __device__ __forceinline__ int diag_factor(double *sT, double *srd, int lane) {
     return bad;
 }
 
+// the W operand of block b of the factored diagonal tile Lp (PanelBlock, step 2) as lane (r, q) supplies it: W[r][q] for r < 4
+__device__ __forceinline__ double w_operand(const double *Lp, const double *srdp, const int b, const int r, const int q) {
+    double w = 0.0;
+    if (r < 4) {
+        if (q < r) w = Lp[el(4 * b + q, 4 * b + r)];
+        else if (q == r) w = srdp[4 * b + r];
+    }
+    return w;
+}
+
+// one wave: the 16 x 16 tile of the rows below the diagonal tile L_pp <- tile inv(L_pp)^T, four columns at a time: the MFMA of
+// PanelBlock step 2 with the inverted 4x4 diagonal blocks wave 0 left beside L_pp (Lp: the factored diagonal tile, srdp: its
+// 1 / L_rr), then a rank-4 update of the remaining columns with L_pp's own columns.  The tile is kept transposed in the
+// accumulator layout: on entry lane (a, q) slot v = T[a][q + 4v]; on return xres[b] = X[a][4b + q].  (Lp's entries above its
+// diagonal only ever meet accumulator rows that are finished.)
+__device__ __forceinline__ void tile_trsm_acc(double4_t acc, const double *Lp, const double *srdp, const int r, const int q, double (&xres)[4]) {
+    double wop[4], lc[3];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) wop[b] = w_operand(Lp, srdp, b, r, q);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) lc[b] = Lp[el(r, 4 * b + q)];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        double4_t xs = {0.0, 0.0, 0.0, 0.0};
+        xs = mfma(wop[b], acc[b], xs);
+        xres[b] = xs[0];
+        if (b < 3) acc = mfma(-lc[b], xres[b], acc);
+    }
+}
+__device__ __forceinline__ void tile_trsm(double *Ti, const double *Lp, const double *srdp, const int r, const int q, double (&xres)[4]) {
+    double4_t acc;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] = Ti[el(r, q + 4 * v)];
+    tile_trsm_acc(acc, Lp, srdp, r, q, xres);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Ti[el(r, q + 4 * b)] = xres[b];
+}
 
 __device__ __forceinline__ double *uniform_ptr_rw(double *p) { return const_cast<double *>(uniform_ptr(p)); }
 // 16 bytes through a buffer descriptor with sc1 (served past this compute unit's L1): data another workgroup of the SAME launch wrote
@@ -173,14 +227,15 @@ __device__ __forceinline__ void st_linv(double *p, double v) {
 // first bad pivot -> g.info as info_base + column + 1.  sT: 36 x 256 doubles, srd: 128 doubles of LDS; 512 threads.
 // The caller synchronises the workgroup before it reuses sT / srd.  `tid` = threadIdx.x (a caller that loops over blocks passes it
 // through an opaque move per iteration, so that the compiler does not hoist every address of the body out of the loop).
-template <bool CHAIN>
-__device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *linv, double *logdet_part, const int info_base, double *sT, double *srd, const int tid) {
+// VERIFY (chain.hip, option "chain_verify"): *vsum receives this thread's share of the sum of the bit patterns of what the block hands
+// to the other workgroups of the launch -- L's strictly lower 16 x 16 tiles and the inverses of its diagonal tiles, as stored
+template <bool CHAIN, bool VERIFY = false>
+__device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *linv, double *logdet_part, const int info_base, double *sT, double *srd, const int tid,
+                                          unsigned long long *vsum = nullptr) {
 
     // the leaf sits on the critical path of the panel chain and shares its SIMDs with trailing-update waves
     // (look-ahead): its instructions go first
     __builtin_amdgcn_s_setprio(3);
-    const int lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
     int nst = 0;
     // this compute unit is the leaf's while it runs: the co-resident trailing-update workgroup sleeps (gemm.hip, YIELD)
     int *const yslot = g.yield ? cu_yield_slot(g.yield) : nullptr;      // wave-uniform: lives in scalar registers
@@ -189,153 +244,176 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
     FVGP_STAMP();
 
     if (!(CHAIN && g.preloaded))
-    // ---- load the lower triangle into packed tiles; strict upper of diagonal tiles <- 0 (kept inline: as a function of its own the
-    //      same lines made the kernel spill 463 registers instead of 2) ----------
+    // ---- load the lower triangle into the packed tiles by LDS-DMA: a wave instruction lands 1 KB = rows 8 u .. 8 u + 7 of one tile
+    //      (lane l at 16 l bytes: row 8 u + (l >> 3), position l & 7 of the row's eight 16-byte pieces, which holds piece
+    //      (l & 7) ^ ((row >> 1) & 7) of the tile's row: the tiles' own column swizzle, el()); 72 half-tiles, nine per wave, all in
+    //      flight: ONE memory round trip and no staging registers (as register loads in two batches the phase took 6.3 thousand
+    //      cycles).  The strict upper halves of the diagonal tiles -- whatever the matrix holds there -- are then zeroed.
     {
-    // eight loads of a thread in flight per LDS-write batch (two memory round trips instead of sixteen)
-    const int c2 = (tid & 63) * 2, tj = c2 >> 4, rbase = tid >> 6;
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(A)), 0, 0xffffffff, 0x00020000);
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+        const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(A)), 0, 0xffffffff, 0x00020000);
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-        double2_t v[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = rbase + 8 * (8 * hb + it);
-            v[it] = (double2_t){0.0, 0.0};
-            if (tj <= (row >> 4)) {
-                if constexpr (CHAIN) v[it] = ld_b128_sc1(a_src, (int)(((long)row * g.lda + c2) * 8));
-                else v[it] = *reinterpret_cast<const double2_t *>(A + (long)row * g.lda + c2);
-            }
+        for (int it = 0; it < 9; ++it) {
+            const int hx = wave_u + 8 * it;                      // half-tile 0 .. 71: lower tile hx >> 1 (row-major over the triangle), rows 8 (hx & 1) ..
+            const int pt = hx >> 1, u = hx & 1;
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= pt) ++ti;
+            const int tj = pt - ti * (ti + 1) / 2;
+            const int a = 8 * u + (ln >> 3);
+            const int piece = (ln & 7) ^ ((a >> 1) & 7);
+            const int voff = (int)(((long)(16 * ti + a) * g.lda + 16 * tj + 2 * piece) * 8);
+            lds_void *dst = (lds_void *)&sT[pt * TSZ + 8 * u * 16];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_src, dst, 16, voff, 0, 0, CHAIN ? 16 : 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        double *Td = &sT[tix(wave_u, wave_u)];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = rbase + 8 * (8 * hb + it), ti = row >> 4;
-            if (tj > ti) continue;
-            if (c2 + 1 > row) v[it][1] = 0.0;
-            if (c2 > row) v[it][0] = 0.0;
-            double *dst = &sT[tix(ti, tj)];
-            dst[el(row & 15, c2 & 15)] = v[it][0]; dst[el(row & 15, (c2 & 15) + 1)] = v[it][1];
+        for (int k = 0; k < 4; ++k) {
+            const int e = 4 * ln + k, a = e >> 4, c = e & 15;
+            if (c > a) Td[el(a, c)] = 0.0;
         }
     }
-    }
+    if (tid == 0) *reinterpret_cast<int *>(srd + 128) = 0;      // the solvers' counter of the factor loop
     __syncthreads();
     FVGP_STAMP();
+    // the lane coordinates of everything below come from an opaque copy of the thread index: derived from `tid` itself the compiler
+    // hoists the factor loop's per-lane addresses above the load phase, and the registers they hold there push its sixteen loads in
+    // flight out to scratch (458 spilled registers)
+    int tid_f = tid;
+    asm volatile("" : "+v"(tid_f));
+    const int lane = tid_f & 63, wave = __builtin_amdgcn_readfirstlane(tid_f >> 6);
+    const int r = lane & 15, q = lane >> 4;
 
-    if (g.do_factor) {
-        if (wave == 0) {
-            const int bad = diag_factor(&sT[tix(0, 0)], &srd[0], lane);
-            if (bad >= 0 && lane == 0 && bad < g.nvalid) atomicCAS(g.info, 0, info_base + bad + 1);
-        }
-        __syncthreads();
-        for (int p = 0; p < 8; ++p) {
-            // ---- TRSM: rows below the diagonal tile, one thread per row, x <- a * L_pp^-T ------------
-            const int R = 112 - 16 * p;
-            if (tid < R) {
-                const int i = p + 1 + (tid >> 4), a = tid & 15;
-                double *rowp = &sT[tix(i, p)];
-                const double *Lp = &sT[tix(p, p)];
-                double x[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] = rowp[el(a, c)];
-                // column sweep: a finished x[j] is applied to all later entries at once (independent FMAs), so the dependent
-                // path is 16 x (scale, one FMA) instead of a j-term dot product per entry
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    x[j] *= srd[16 * p + j];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) if (c > j) x[c] = fma(-x[j], Lp[el(c, j)], x[c]);
-                }
-#pragma unroll
-                for (int c = 0; c < 16; ++c) rowp[el(a, c)] = x[c];
-            }
-            __syncthreads();
-            FVGP_STAMP();
-            // ---- trailing update C_ij -= X_i X_j^T, p < j <= i <= 7 ---------------------------------------
-            const int T = 7 - p;
-            const int ntile = T * (T + 1) / 2;
-            // wave 0: tile (p+1,p+1) only, then it factors that tile; waves 1..7 share the rest
-            for (int idx = wave; idx < ntile; idx += (wave == 0 ? 1000 : 7)) {
-                int ii = 0;
-                while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
-                const int jj = idx - ii * (ii + 1) / 2;
-                const int i = p + 1 + ii, j = p + 1 + jj;
-                double *C = &sT[tix(i, j)];
-                const double *Xi = &sT[tix(i, p)], *Xj = &sT[tix(j, p)];
-                double4_t acc;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[v] = C[el(q + 4 * v, r)];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = mfma(-Xi[el(r, 4 * s + q)], Xj[el(r, 4 * s + q)], acc);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) if (i != j || r <= q + 4 * v) C[el(q + 4 * v, r)] = acc[v];
-            }
-            FVGP_STAMP();
-            if (wave == 0 && p < 7) {
-                const int bad = diag_factor(&sT[tix(p + 1, p + 1)], &srd[16 * (p + 1)], lane);
-                if (bad >= 0 && lane == 0 && 16 * (p + 1) + bad < g.nvalid)
-                    atomicCAS(g.info, 0, info_base + 16 * (p + 1) + bad + 1);
-            }
-            __syncthreads();
-            FVGP_STAMP();
-        }
-        // ---- L back to global (lower triangle only), tile by tile: a wave's store covers four 128-byte row segments ----
+    // one finished 16 x 16 tile (ti, tj) of L from LDS to global memory (lower triangle of the block only)
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t s_src = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr_rw(A), 0, 0xffffffff, 0x00020000);
+    auto store_tile = [&](const int ti, const int tj) {
+        const double *T = &sT[tix(ti, tj)];
         if constexpr (CHAIN) {
             // write-through (sc1) stores of 16 bytes: lane l of a wave takes the column pair 2 (l & 7) of rows l >> 3 and 8 + (l >> 3)
             // of a tile (the other workgroups of the launch read L with sc1 loads; 8-byte sc1 stores are one fabric write each)
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            const __amdgpu_buffer_rsrc_t s_src = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr_rw(A), 0, 0xffffffff, 0x00020000);
-            for (int t = wave; t < NT; t += 8) {
-                int ti = 0;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                const int tj = t - ti * (ti + 1) / 2;
-                const double *T = &sT[t * TSZ];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int a = 8 * u + (lane >> 3), c = 2 * (lane & 7);
-                    const double2_t pr = *reinterpret_cast<const double2_t *>(&T[el(a, c)]);
-                    const int off = (int)((((long)(16 * ti + a)) * g.lda + 16 * tj + c) * 8);
-                    if (ti != tj || c + 1 <= a) {
-                        u32x4 raw;
-                        __builtin_memcpy(&raw, &pr, 16);
-                        __builtin_amdgcn_raw_buffer_store_b128(raw, s_src, off, 0, 16);
-                    } else if (c == a) {
-                        __hip_atomic_store(A + (long)(16 * ti + a) * g.lda + 16 * tj + c, pr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+            for (int u = 0; u < 2; ++u) {
+                const int a = 8 * u + (lane >> 3), c = 2 * (lane & 7);
+                const double2_t pr = *reinterpret_cast<const double2_t *>(&T[el(a, c)]);
+                const int off = (int)((((long)(16 * ti + a)) * g.lda + 16 * tj + c) * 8);
+                if (ti != tj || c + 1 <= a) {
+                    u32x4 raw;
+                    __builtin_memcpy(&raw, &pr, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, s_src, off, 0, 16);
+                } else if (c == a) {
+                    __hip_atomic_store(A + (long)(16 * ti + a) * g.lda + 16 * tj + c, pr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         } else {
-        for (int t = wave; t < NT; t += 8) {
-            int ti = 0;
-            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-            const int tj = t - ti * (ti + 1) / 2;
-            const double *T = &sT[t * TSZ];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int a = 4 * u + q;
                 if (ti != tj || r <= a) A[(long)(16 * ti + a) * g.lda + 16 * tj + r] = T[el(a, r)];
             }
         }
+    };
+
+    double4_t xb0;          // inv(L_ww)[4s + q][r] of this wave's diagonal tile (the seed of the block-column inverse below)
+    if (g.do_factor) {
+        // Schedule of the eight 16-column steps.  Wave 0 owns the chain of diagonal tiles and never waits inside a step: behind the
+        // step's barrier it solves tile (p+1, p) against L_pp (tile_trsm), applies the solved rows -- still in its registers, the
+        // accumulator layout is both MFMA operands of X X^T -- to the symmetric tile (p+1, p+1) and factors it on the spot.  Waves
+        // 1, 2, 3, 5, 6, 7 solve the other tiles of column p, meet at a counter in LDS (wave 0 adds to it once its tile is
+        // stored), send the finished column p to global memory and update the tiles to the right.  Wave 4 shares wave 0's SIMD --
+        // fp64 MFMA and the vector ALU share a pipe -- and takes no work during the steps.  ONE workgroup barrier per step.
+        int *const s_cnt = reinterpret_cast<int *>(srd + 128);         // (zeroed before the barrier behind the load phase)
+        const int slot = (wave == 0 || wave == 4) ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+        if (wave == 0) {
+            const int bad = diag_factor_acc(load_sym_tile(&sT[tix(0, 0)], r, q), &sT[tix(0, 0)], &srd[0], lane);
+            if (bad >= 0 && lane == 0 && bad < g.nvalid) atomicCAS(g.info, 0, info_base + bad + 1);
         }
+        FVGP_STAMP();
+        __syncthreads();
+        FVGP_STAMP();
+#pragma nounroll
+        for (int p = 0; p < 7; ++p) {
+            const double *Lp = &sT[tix(p, p)];
+            const double *srdp = &srd[16 * p];
+            if (wave == 0) {
+                double *Td = &sT[tix(p + 1, p + 1)];
+                double4_t dacc = load_sym_tile(Td, r, q);             // (issued before the solve: its latency hides under it)
+                double xres[4];
+                tile_trsm(&sT[tix(p + 1, p)], Lp, srdp, r, q, xres);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                FVGP_STAMP();
+#pragma unroll
+                for (int b = 0; b < 4; ++b) dacc = mfma(-xres[b], xres[b], dacc);
+                FVGP_STAMP();
+                const int bad = diag_factor_acc(dacc, Td, &srd[16 * (p + 1)], lane);
+                if (bad >= 0 && lane == 0 && 16 * (p + 1) + bad < g.nvalid)
+                    atomicCAS(g.info, 0, info_base + 16 * (p + 1) + bad + 1);
+                FVGP_STAMP();
+            } else if (slot >= 0) {
+                const int it = p + 2 + slot;
+                if (it < 8) { double xr[4]; tile_trsm(&sT[tix(it, p)], Lp, srdp, r, q, xr); }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // every solved tile of column p is in LDS once the seven solvers of this step have added to the counter
+                while (__hip_atomic_load(s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 7 * (p + 1)) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // ---- trailing update C_ij -= X_i X_j^T, p < j <= i <= 7, without (p+1, p+1) (wave 0 has it in registers) ----
+                const int T = 7 - p;
+                const int ntile = T * (T + 1) / 2;
+                for (int idx = 1 + slot; idx < ntile; idx += 6) {
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
+                    const int jj = idx - ii * (ii + 1) / 2;
+                    const int i = p + 1 + ii, j = p + 1 + jj;
+                    double *C = &sT[tix(i, j)];
+                    const double *Xi = &sT[tix(i, p)], *Xj = &sT[tix(j, p)];
+                    double4_t acc;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[v] = C[el(q + 4 * v, r)];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) acc = mfma(-Xi[el(r, 4 * s4 + q)], Xj[el(r, 4 * s4 + q)], acc);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) if (i != j || r <= q + 4 * v) C[el(q + 4 * v, r)] = acc[v];
+                }
+                // ---- column p is final: its 8 - p tiles go to global memory while wave 0 factors the next diagonal tile ----
+                for (int i = p + slot; i < 8; i += 6) store_tile(i, p);
+            }
+            __syncthreads();
+            FVGP_STAMP();
+        }
+        if (wave == 1) store_tile(7, 7);
         // ---- the reciprocal diagonal, for the log-determinant: the logarithms are taken once, by one kernel over all blocks
         //      (neg_log_sum_kernel), not 128 at a time behind a barrier on the chain's critical path (1.4 thousand cycles) ------
         if (logdet_part != nullptr && tid < 128) logdet_part[tid] = tid < g.nvalid ? srd[tid] : 1.0;
         FVGP_STAMP();
+        // ---- inverse of the 8 diagonal tiles, wave w its tile (w, w): inv(L_ww)^T = I inv(L_ww)^T is the tile solve of the factor loop
+        //      applied to the identity; its strictly lower part goes, transposed, into the tile's strict upper half (over the 4x4
+        //      block inverses, which every lane has read by then), the diagonal is srd ----
+        {
+            double4_t id;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) id[v] = (r == q + 4 * v) ? 1.0 : 0.0;
+            double xinv[4];
+            double *Tw = &sT[tix(wave, wave)];
+            tile_trsm_acc(id, Tw, &srd[16 * wave], r, q, xinv);     // xinv[b] = inv(L_ww)[4b + q][r]
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { xb0[b] = xinv[b]; if (4 * b + q > r) Tw[el(r, 4 * b + q)] = xinv[b]; }
+        }
+        __syncthreads();
+        FVGP_STAMP();
     } else {
         if (tid < 128) srd[tid] = 1.0 / sT[tix(tid >> 4, tid >> 4) + el(tid & 15, tid & 15)];
         __syncthreads();
-    }
-
-    // ---- inverse of the 8 diagonal tiles: wave w inverts tile (w,w); its strictly-lower part goes,
-    //      transposed, into the tile's (unused) strict upper half, the diagonal is srd -------------------
-    double x[16];
-    {
+        // ---- inverse of the 8 diagonal tiles of a given factor: wave w inverts tile (w,w); its strictly-lower part goes,
+        //      transposed, into the tile's (unused) strict upper half, the diagonal is srd -------------------
         // lane c solves L x = e_c (column c of the inverse) by a COLUMN sweep: a finished x[k] goes into every later row at once
-        // (independent FMAs; L[i][k] is a broadcast LDS read), so the dependent path is 16 x (scale, one FMA) -- the row-by-row
-        // form waited for a k-term chain of FMAs fed by two readlanes each, 6.3 of the leaf's 86 thousand cycles.  Every sum
-        // receives its terms in the same order (k ascending): same bits.
+        // (independent FMAs; L[i][k] is a broadcast LDS read), so the dependent path is 16 x (scale, one FMA)
         const int c = lane & 15;
         const double *Tw = &sT[tix(wave, wave)];
-        double sv[16];
+        double x[16], sv[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) sv[i] = (i == c) ? 1.0 : 0.0;
 #pragma unroll
@@ -349,14 +427,20 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
 #pragma unroll
             for (int i = 0; i < 16; ++i) if (i > c) Tm[el(c, i)] = x[i];      // Dinv[i][c] at [c][i]
         }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const double v0 = x[4 * s4], v1 = x[4 * s4 + 1], v2 = x[4 * s4 + 2], v3 = x[4 * s4 + 3];
+            xb0[s4] = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
+        }
+        __syncthreads();
+        FVGP_STAMP();
     }
-    __syncthreads();
-    FVGP_STAMP();
 
     if (g.tiles_only) {
         // the chain's TRSM substitutes tile column by tile column (trsm_tiles_kernel) and needs these only; the full
         // 128 x 128 inverses come from one batched launch after the factorisation (launch_leaf_inverse_batched)
         const double *Tw = &sT[tix(wave, wave)];
+        [[maybe_unused]] unsigned long long vs = 0ull;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int a = 4 * u + q;
@@ -364,6 +448,17 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
             if (a > r) d = Tw[el(r, a)];
             else if (a == r) d = srd[16 * wave + a];
             st_linv<CHAIN>(&linv[wave * 256 + a * 16 + r], d);
+            if constexpr (VERIFY) vs += (unsigned long long)__double_as_longlong(d);
+        }
+        if constexpr (VERIFY) {           // the 28 strictly lower tiles: 7168 doubles, fourteen per thread
+            for (int e = tid; e < 28 * TSZ; e += 512) {
+                const int p = e / TSZ;
+                int ti = 1;
+                while (ti * (ti + 1) / 2 <= p) ++ti;
+                const int tj = p - ti * (ti - 1) / 2;
+                vs += (unsigned long long)__double_as_longlong(sT[tix(ti, tj) + (e - p * TSZ)]);
+            }
+            *vsum = vs;
         }
         FVGP_STAMP();
         if (yslot && tid == 0) atomicAdd(yslot, -1);
@@ -373,12 +468,7 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
     {
         const int j = wave;
         double4_t xb[8];
-        // X_jj[4s+q][r]: lane (q, r) holds column r of inv(L_jj) in x[]; pick rows 4s+q
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double v0 = x[4 * s], v1 = x[4 * s + 1], v2 = x[4 * s + 2], v3 = x[4 * s + 3];
-            xb[0][s] = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
-        }
+        xb[0] = xb0;        // X_jj[4s+q][r]
 #pragma unroll
         for (int m = 1; m < 8; ++m) {
             const int i = j + m;

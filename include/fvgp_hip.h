@@ -83,7 +83,7 @@ int fvgp_hip_stream_destroy(void *stream);
  *       its resident kernel starts; the rows below follow on the main stream and the kernel's block rows wait for a flag in memory),
  *       "leaf_tiles" / "leaf_tiles_rows" / "k128_kernels" / "small_tile_max" / "small_tile_max_update" (kernels of the three-launch
  *       chain) ("order"), "leaf_yield" / "chain_yield" (1: the trailing update's waves sleep while a workgroup of the chain shares
- *       their compute unit; chain_yield 2: also for the resident kernel's rows below the square);
+ *       their compute unit; chain_yield 2: also for the resident kernel's rows below the square), "chain_verify" (see fvgp_hip_chain_verify_counts);
  *   schedule: "lookahead" (0/1) from "lookahead_min" = 4608 padded rows on: the next panel's chain on a high-priority side stream
  *       under the trailing update; "tile_tables" (1: XCD-balanced block -> tile tables instead of the formula map);
  *   solves / posterior / gradient: "bwd_sweep" / "fwd_sweep" (1: the backward / forward vector sweep with one right-hand side in
@@ -94,6 +94,12 @@ int fvgp_hip_stream_destroy(void *stream);
  *   measurement: "profile" (0/1: time the trailing-update launches with HIP events -> fvgp_hip_get_profile), "chain_stamps" /
  *       "leaf_stamps" (device pointers, 0 = off: in-kernel timestamps of the panel kernel's hand-offs / the leaf's phases). */
 int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value);
+/* Option "chain_verify" (0/1, default 0): every in-launch hand-off of the resident panel kernel (csrc/chain.hip: a solved block row,
+ * a factored diagonal block with its tile inverses) carries a checksum of its payload, taken by the producer from what it stores and
+ * compared by every consumer with what ARRIVED (LDS images of its LDS-DMA loads, registers of its buffer loads).  out2_host[0] =
+ * mismatches, [1] = comparisons since the last call; synchronises.  A verifying run is slower (LDS reductions on the chain's critical
+ * path) and returns the same bits.  The dpotrf it guards: gp_lin_alg.py:245. */
+int fvgp_hip_chain_verify_counts(fvgp_handle *h, int64_t *out2_host);
 /* out[0] = number of trailing-update launches of the last potrf, out[1] = their summed
  * duration in ms, out[2] = their summed algorithmic flops, out[3] = whole-potrf ms; of the last fused
  * evaluation (fvgp_hip_loglik): out[4] = covariance-assembly ms, out[5] = its algorithmic bytes (lower

@@ -712,6 +712,23 @@ def test_resident_panel_kernel_soak(H, n):
             differ += 1
         del a, L
     assert differ == 0
+    # the same evaluation with a checksum on every hand-off of the resident kernel (option "chain_verify": the producer sums the bit
+    # patterns of what it stores, every consumer sums what ARRIVED in its LDS images / registers): no mismatch in thousands of
+    # comparisons, and the same bits as the plain runs
+    try:
+        H.set_option("chain_verify", 1)
+        H.chain_verify_counts()
+        vdiffer = []
+        for t in range(10):
+            KV.fill_(float("nan"))
+            out = H.loglik(0, xd, theta, vd, ymd, KV, alpha)
+            H.sync()
+            if not (out == ref[0] and torch.equal(alpha[:n, 0], ref[1]) and torch.equal(KV[:n, :n].tril(), ref[2])):
+                vdiffer.append((t, out, int((KV[:n, :n].tril() != ref[2]).sum().item())))
+        bad, checks = H.chain_verify_counts()
+    finally:
+        H.set_option("chain_verify", 0)
+    assert bad == 0 and checks > 1000 and not vdiffer, (bad, checks, vdiffer, ref[0])
     want, _ = orc.log_likelihood_once(x, y, np.full(n, 0.01), theta, "rbf_ard")
     np.testing.assert_allclose(ref[0][0], want, rtol=1e-10)
 

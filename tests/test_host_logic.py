@@ -265,3 +265,28 @@ def test_user_proposal_distributions_drive_the_mcmc():
     assert abs(res["mean(x)"][0] - 1.0) < 0.6 and abs(res["mean(x)"][1] - 0.7) < 0.6
     with pytest.raises(Exception, match="No proposal distribution"):
         T.ProposalDistribution([0], proposal_dist=3)
+
+
+def test_no_wide_buffer_store_with_a_scalar_offset(tmp_path):
+    """A 16-byte (or 12-byte) buffer store whose data registers the next vector instruction overwrites needs a wait state; the
+    compiler inserts it unless the store carries an SGPR offset (the documented exception of that hazard) -- and on gfx950 such a
+    store was seen going out with the NEW register contents in its last lanes (profiles/r05_store_hazard_chain_verify.txt).
+    No kernel of the library may contain a wide buffer store with a scalar offset register: scan the ISA hipcc generates."""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "fvgp_amd", "csrc")
+    bad = []
+    for f in sorted(os.listdir(src)):
+        if not f.endswith(".hip"):
+            continue
+        text = open(os.path.join(src, f)).read()
+        if "buffer_store" not in text and "leaf_body.h" not in text:
+            continue                                   # no buffer stores in this unit
+        out = tmp_path / (f + ".s")
+        res = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                              "-Wno-unused-function", os.path.join(src, f), "-o", str(out)], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        for line in open(out):
+            if re.search(r"buffer_store_dwordx[34] .*\], s[0-9]+ ", line):
+                bad.append((f, line.strip()))
+    assert not bad, bad[:5]

@@ -17,12 +17,10 @@ for rep in range(3):
 torch.cuda.synchronize()
 H.set_option("leaf_stamps", 0)
 s = stamps.cpu().numpy()
-names = ["load", "diag tile 0 + TRSM p=0"]
-for p in range(8):
-    names += [f"p={p} updates (wave 0: its tile)", f"p={p} diag tile {p + 1} + sync"]
-    if p < 7:
-        names += [f"p={p + 1} TRSM rows + sync"]
-names += ["store L + logdet", "diag-tile inverses", "block-column inverse + store"]
+names = ["load (LDS-DMA) + zero upper + sync", "diag tile 0 (wave 0)", "sync"]
+for p in range(7):
+    names += [f"p={p} wave 0: solve tile ({p + 1},{p})", f"p={p} wave 0: update tile ({p + 1},{p + 1})", f"p={p} wave 0: factor tile {p + 1}", f"p={p} sync"]
+names += ["last tile store + logdet", "diag-tile inverses + sync", "tile inverses / block-column inverse store"]
 d = np.diff(s[:len(names) + 1])
 for nme, c in zip(names, d):
     print(f"{nme:36s} {c:8d} cycles")
