@@ -61,3 +61,12 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+#ifdef FVGP_LEAF_FINE
+// diagnostic build: every wave's event times in the factor loop (leaf_body.h, FVGP_WFINE)
+extern "C" int fvgp_hip_debug_fine(unsigned long *out_host, int n) {
+    if (n > 512) n = 512;
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_wfine), (size_t)n * sizeof(unsigned long)) != hipSuccess) return -1;
+    return n;
+}
+#endif

@@ -2,6 +2,7 @@
 // panel kernel calls it once per 128 columns).  See leaf.hip for the algorithm and the resource shape.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -83,6 +84,18 @@ __device__ __forceinline__ double sqrt_from(double d, double y) {
     return fma(fma(-p, p, d), 0.5 * y, p);
 }
 
+// diagnostic build only (tools/build_variant.sh fine -DFVGP_LEAF_FINE; tools/leaf_fine.py): cycle stamps inside PanelBlock
+#ifdef FVGP_LEAF_FINE
+__device__ unsigned long g_fine[512];
+__device__ int g_fine_n;
+#define FVGP_FINE() do { } while (0)
+__device__ unsigned long g_wfine[8 * 8 * 8];          // [wave][step][event]: s_memtime of every wave's events in the factor loop
+#define FVGP_WFINE(p, k) do { if (lane == 0) g_wfine[(wave * 8 + (p)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FVGP_FINE() do { } while (0)
+#define FVGP_WFINE(p, k) do { } while (0)
+#endif
+
 // Four-column block B of a 16x16 tile.  The tile is kept as the full symmetric matrix in the MFMA accumulator layout, lane
 // (r, q) holds D[q + 4v][r] = D[r][q + 4v], so accumulator slot B of lane (r, q) IS the panel entry (row r, panel column q).
 //   1. the 4x4 diagonal block is factored as wave-uniform scalars (its ten entries by readlane): the pivot chain -- four
@@ -96,56 +109,67 @@ __device__ __forceinline__ double sqrt_from(double d, double y) {
 //   3. the factored panel is both operands of ONE rank-4 MFMA update of the rest of the tile.
 // (Versions before: 16 columns swept with 15 - J broadcast-and-FMA updates behind each pivot, 7.4k cycles per tile; the panel
 // rows solved per lane group with three dependent cross-lane broadcasts, 4.6k.)
+// per-lane constants of PanelBlock: dq[k] = (q == k), mr[k] = (r == k) as doubles (selects by multiplication: one of four terms survives)
+struct PanelLane { double dq[4], mr[4]; };
+__device__ __forceinline__ PanelLane panel_lane(const int r, const int q) {
+    PanelLane c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c.dq[k] = q == k ? 1.0 : 0.0; c.mr[k] = r == k ? 1.0 : 0.0; }
+    return c;
+}
+
 template <int B>
 struct PanelBlock {
-    static __device__ __forceinline__ void step(double4_t &acc, double *sT, double &ykeep, int r, int q, int lane, int &bad) {
+    static __device__ __forceinline__ void step(double4_t &acc, double *sT, double *srdt, const PanelLane &pc, int r, int q, int lane,
+                                                double (&wops)[4], double (&lcs)[4]) {
         constexpr int R0 = 4 * B;
+        FVGP_FINE();
         const bool above = r < R0 + q;                        // finished rows, and the 4x4 block above its diagonal
         const double x = above ? 0.0 : acc[B];
         const double d00 = bcast<R0>(x), d10 = bcast<R0 + 1>(x), d20 = bcast<R0 + 2>(x), d30 = bcast<R0 + 3>(x);
         const double d11 = bcast<16 + R0 + 1>(x), d21 = bcast<16 + R0 + 2>(x), d31 = bcast<16 + R0 + 3>(x);
         const double d22 = bcast<32 + R0 + 2>(x), d32 = bcast<32 + R0 + 3>(x);
         const double d33 = bcast<48 + R0 + 3>(x);
-        if (!(d00 > 0.0) && bad < 0) bad = R0;
+        FVGP_FINE();
+        // (no test of the pivots here: a pivot <= 0 or NaN makes its reciprocal square root, and everything after it, inf or NaN;
+        // diag_factor_acc looks at the sixteen 1 / L_rr once per tile and finds the first that is not a positive finite number)
         const double y0 = rsqrt_nr(d00);
         const double l10 = d10 * y0, l20 = d20 * y0, l30 = d30 * y0;
         const double e11 = fma(-l10, l10, d11);
-        if (!(e11 > 0.0) && bad < 0) bad = R0 + 1;
         const double y1 = rsqrt_nr(e11);
         const double l21 = fma(-l20, l10, d21) * y1, l31 = fma(-l30, l10, d31) * y1;
         const double e22 = fma(-l21, l21, fma(-l20, l20, d22));
-        if (!(e22 > 0.0) && bad < 0) bad = R0 + 2;
         const double y2 = rsqrt_nr(e22);
         const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * y2;
         const double e33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
-        if (!(e33 > 0.0) && bad < 0) bad = R0 + 3;
         const double y3 = rsqrt_nr(e33);
+        FVGP_FINE();
         // column q of W = inv(L_bb) by forward substitution on the unit vector e_q, in lane group q
-        const bool g0 = q == 0, g1 = q == 1, g2 = q == 2;
-        const double w0 = g0 ? y0 : 0.0;
-        const double w1 = ((g1 ? 1.0 : 0.0) - l10 * w0) * y1;
-        const double w2 = fma(-l21, w1, fma(-l20, w0, g2 ? 1.0 : 0.0)) * y2;
-        const double w3 = fma(-l32, w2, fma(-l31, w1, fma(-l30, w0, (q == 3) ? 1.0 : 0.0))) * y3;
-#ifdef EXP_B
-        const double wop = w3;
-#else
-        const double wop = r == 0 ? w0 : (r == 1 ? w1 : (r == 2 ? w2 : (r == 3 ? w3 : 0.0)));      // W[r][q], rows >= 4 of the operand: 0
-#endif
+        const double w0 = pc.dq[0] * y0;
+        const double w1 = fma(-l10, w0, pc.dq[1]) * y1;
+        const double w2 = fma(-l21, w1, fma(-l20, w0, pc.dq[2])) * y2;
+        const double w3 = fma(-l32, w2, fma(-l31, w1, fma(-l30, w0, pc.dq[3]))) * y3;
+        const double wop = fma(pc.mr[3], w3, fma(pc.mr[2], w2, fma(pc.mr[1], w1, pc.mr[0] * w0)));      // W[r][q], rows >= 4 of the operand: 0
         if (r < 4 && q < r) sT[el(R0 + q, R0 + r)] = wop;
+        if (lane == 0) { srdt[R0] = y0; srdt[R0 + 1] = y1; srdt[R0 + 2] = y2; srdt[R0 + 3] = y3; }      // 1 / L_rr
+        FVGP_FINE();
         // every row of the panel: X[r][R0 + q] = sum_k W[q][k] R[r][R0 + k], one MFMA, result in slot 0
         double4_t xs = {0.0, 0.0, 0.0, 0.0};
         xs = mfma(wop, x, xs);
         double xf = xs[0];
+        FVGP_FINE();
         // the diagonal entries with one correction step (on this lane group's pivot), zeros above them
-        const double eq = g0 ? d00 : (g1 ? e11 : (g2 ? e22 : e33));
-        const double yq = g0 ? y0 : (g1 ? y1 : (g2 ? y2 : y3));
+        const double eq = fma(pc.dq[3], e33, fma(pc.dq[2], e22, fma(pc.dq[1], e11, pc.dq[0] * d00)));
+        const double yq = fma(pc.dq[3], y3, fma(pc.dq[2], y2, fma(pc.dq[1], y1, pc.dq[0] * y0)));
         const double pd = sqrt_from(eq, yq);
-        if (r == R0 + q) { xf = pd; ykeep = yq; }            // lane (r, q = r mod 4) keeps 1 / L_rr
+        if (r == R0 + q) xf = pd;
         if (above) xf = 0.0;
         if (r >= R0 + q) sT[el(r, R0 + q)] = xf;
+        wops[B] = wop; lcs[B] = xf;                              // what tile_trsm reads back from LDS, for the wave that has them anyway
+        FVGP_FINE();
         if constexpr (B < 3) {
             acc = mfma(-xf, xf, acc);
-            PanelBlock<B + 1>::step(acc, sT, ykeep, r, q, lane, bad);
+            PanelBlock<B + 1>::step(acc, sT, srdt, pc, r, q, lane, wops, lcs);
         }
     }
 };
@@ -159,24 +183,24 @@ __device__ __forceinline__ double4_t load_sym_tile(const double *sT, int r, int 
 }
 
 // one wave: Cholesky of the symmetric 16x16 tile in `acc` into sT (lower part; the inverses of its 4x4 diagonal blocks into their
-// strict upper halves); 1/diag -> srd[0..15].  Returns the first bad pivot column or -1
-__device__ __forceinline__ int diag_factor_acc(double4_t acc, double *sT, double *srd, int lane) {
+// strict upper halves); 1/diag -> srd[0..15].  Returns the first bad pivot column (not positive, or NaN: dpotrf's info) or -1
+__device__ __forceinline__ int diag_factor_acc(double4_t acc, double *sT, double *srd, const PanelLane &pc, int lane, double (&wops)[4], double (&lcs)[4]) {
     const int r = lane & 15, q = lane >> 4;
-    int bad = -1;
-    double ykeep = 0.0;
-    PanelBlock<0>::step(acc, sT, ykeep, r, q, lane, bad);
-    if (q == (r & 3)) srd[r] = ykeep;
-    return bad;
+    PanelBlock<0>::step(acc, sT, srd, pc, r, q, lane, wops, lcs);
+    // a pivot that is not positive leaves inf or NaN in its 1 / L_rr and NaN in every later one: the first such column, if any
+    // (the four uniform values of the last block are in registers; the twelve before them are read back: off the critical path)
+    const double yr = srd[r];
+    const unsigned long long m = __ballot(!(yr > 0.0 && yr < 1.0e300)) & 0xffffull;
+    return m ? __builtin_ctzll(m) : -1;
 }
 
-// the W operand of block b of the factored diagonal tile Lp (PanelBlock, step 2) as lane (r, q) supplies it: W[r][q] for r < 4
+// the W operand of block b of the factored diagonal tile Lp (PanelBlock, step 2) as lane (r, q) supplies it: W[r][q] for r < 4.
+// Two unconditional LDS reads (a lane with nothing to fetch reads the block's first entries) and two selects: no divergent branch.
 __device__ __forceinline__ double w_operand(const double *Lp, const double *srdp, const int b, const int r, const int q) {
-    double w = 0.0;
-    if (r < 4) {
-        if (q < r) w = Lp[el(4 * b + q, 4 * b + r)];
-        else if (q == r) w = srdp[4 * b + r];
-    }
-    return w;
+    const bool lower = r < 4 && q < r, diag = r < 4 && q == r;
+    const double v = Lp[lower ? el(4 * b + q, 4 * b + r) : el(4 * b, 4 * b)];
+    const double d = srdp[4 * b + (r & 3)];
+    return lower ? v : (diag ? d : 0.0);
 }
 
 // one wave: the 16 x 16 tile of the rows below the diagonal tile L_pp <- tile inv(L_pp)^T, four columns at a time: the MFMA of
@@ -190,6 +214,16 @@ __device__ __forceinline__ void tile_trsm_acc(double4_t acc, const double *Lp, c
     for (int b = 0; b < 4; ++b) wop[b] = w_operand(Lp, srdp, b, r, q);
 #pragma unroll
     for (int b = 0; b < 3; ++b) lc[b] = Lp[el(r, 4 * b + q)];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        double4_t xs = {0.0, 0.0, 0.0, 0.0};
+        xs = mfma(wop[b], acc[b], xs);
+        xres[b] = xs[0];
+        if (b < 3) acc = mfma(-lc[b], xres[b], acc);
+    }
+}
+// the same with the operands in registers (wave 0: PanelBlock has just produced them)
+__device__ __forceinline__ void tile_trsm_regs(double4_t acc, const double (&wop)[4], const double (&lc)[4], double (&xres)[4]) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         double4_t xs = {0.0, 0.0, 0.0, 0.0};
@@ -316,6 +350,27 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
         }
     };
 
+    // one wave: inv(L_tt)^T = I inv(L_tt)^T is the tile solve of the factor loop applied to the identity; the strictly lower part of the
+    // inverse goes, transposed, into the tile's strict upper half (Dinv[i][c] at [c][i]; the diagonal is srd), and -- `tiles_only`, what the
+    // panel chain asks for -- the inverse itself to linv (8 x 256 doubles, zeros above the diagonals)
+    [[maybe_unused]] unsigned long long vs_inv = 0ull;      // VERIFY: bit patterns of the inverse entries this thread stored
+    auto tile_inverse = [&](const int t) {
+        double4_t id;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) id[v] = (r == q + 4 * v) ? 1.0 : 0.0;
+        double xinv[4];
+        double *Tt = &sT[tix(t, t)];
+        tile_trsm_acc(id, Tt, &srd[16 * t], r, q, xinv);            // xinv[b] = inv(L_tt)[4b + q][r]: exact zeros above the diagonal, srd on it
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int a = 4 * b + q;
+            if (a > r) Tt[el(r, a)] = xinv[b];
+            if (g.tiles_only) {
+                st_linv<CHAIN>(&linv[t * 256 + a * 16 + r], xinv[b]);
+                if constexpr (VERIFY) vs_inv += (unsigned long long)__double_as_longlong(xinv[b]);
+            }
+        }
+    };
     double4_t xb0;          // inv(L_ww)[4s + q][r] of this wave's diagonal tile (the seed of the block-column inverse below)
     if (g.do_factor) {
         // Schedule of the eight 16-column steps.  Wave 0 owns the chain of diagonal tiles and never waits inside a step: behind the
@@ -326,8 +381,10 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
         // fp64 MFMA and the vector ALU share a pipe -- and takes no work during the steps.  ONE workgroup barrier per step.
         int *const s_cnt = reinterpret_cast<int *>(srd + 128);         // (zeroed before the barrier behind the load phase)
         const int slot = (wave == 0 || wave == 4) ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+        double wops[4], lcs[4];                                        // wave 0: the solve's operands of the diagonal tile it has just factored
+        const PanelLane pc = panel_lane(r, q);
         if (wave == 0) {
-            const int bad = diag_factor_acc(load_sym_tile(&sT[tix(0, 0)], r, q), &sT[tix(0, 0)], &srd[0], lane);
+            const int bad = diag_factor_acc(load_sym_tile(&sT[tix(0, 0)], r, q), &sT[tix(0, 0)], &srd[0], pc, lane, wops, lcs);
             if (bad >= 0 && lane == 0 && bad < g.nvalid) atomicCAS(g.info, 0, info_base + bad + 1);
         }
         FVGP_STAMP();
@@ -337,51 +394,83 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
         for (int p = 0; p < 7; ++p) {
             const double *Lp = &sT[tix(p, p)];
             const double *srdp = &srd[16 * p];
+            FVGP_WFINE(p, 0);
             if (wave == 0) {
-                double *Td = &sT[tix(p + 1, p + 1)];
+                double *Td = &sT[tix(p + 1, p + 1)], *T1 = &sT[tix(p + 1, p)];
+                double4_t xacc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) xacc[v] = T1[el(r, q + 4 * v)];
                 double4_t dacc = load_sym_tile(Td, r, q);             // (issued before the solve: its latency hides under it)
                 double xres[4];
-                tile_trsm(&sT[tix(p + 1, p)], Lp, srdp, r, q, xres);
+                tile_trsm_regs(xacc, wops, lcs, xres);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) T1[el(r, q + 4 * b)] = xres[b];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_fetch_add(s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 FVGP_STAMP();
-#pragma unroll
-                for (int b = 0; b < 4; ++b) dacc = mfma(-xres[b], xres[b], dacc);
+                FVGP_WFINE(p, 1);
+                // the solved rows are both operands of X X^T: two accumulators, so that consecutive MFMAs do not wait for each other
+                double4_t dac2 = {0.0, 0.0, 0.0, 0.0};
+                dacc = mfma(-xres[0], xres[0], dacc);
+                dac2 = mfma(-xres[1], xres[1], dac2);
+                dacc = mfma(-xres[2], xres[2], dacc);
+                dac2 = mfma(-xres[3], xres[3], dac2);
+                dacc += dac2;
                 FVGP_STAMP();
-                const int bad = diag_factor_acc(dacc, Td, &srd[16 * (p + 1)], lane);
+                const int bad = diag_factor_acc(dacc, Td, &srd[16 * (p + 1)], pc, lane, wops, lcs);
                 if (bad >= 0 && lane == 0 && 16 * (p + 1) + bad < g.nvalid)
                     atomicCAS(g.info, 0, info_base + 16 * (p + 1) + bad + 1);
                 FVGP_STAMP();
+                FVGP_WFINE(p, 5);
             } else if (slot >= 0) {
                 const int it = p + 2 + slot;
                 if (it < 8) { double xr[4]; tile_trsm(&sT[tix(it, p)], Lp, srdp, r, q, xr); }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_fetch_add(s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                FVGP_WFINE(p, 1);
                 // every solved tile of column p is in LDS once the seven solvers of this step have added to the counter
                 while (__hip_atomic_load(s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 7 * (p + 1)) __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                // ---- trailing update C_ij -= X_i X_j^T, p < j <= i <= 7, without (p+1, p+1) (wave 0 has it in registers) ----
-                const int T = 7 - p;
-                const int ntile = T * (T + 1) / 2;
-                for (int idx = 1 + slot; idx < ntile; idx += 6) {
-                    int ii = 0;
-                    while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
-                    const int jj = idx - ii * (ii + 1) / 2;
-                    const int i = p + 1 + ii, j = p + 1 + jj;
+                FVGP_WFINE(p, 2);
+                // ---- LEFT-looking update of what the next step needs: the tiles (i, p+1), i >= p+2, and the diagonal tile (p+2, p+2)
+                //      receive ALL their terms C -= sum_{k <= p} X_ik X_jk^T now (the diagonal tile its last one, k = p+1, from wave 0's
+                //      registers in the next step).  A right-looking update does the same flops as 27, 20, 14, .. tiles in the first
+                //      steps, where these six waves are what wave 0 then waits for; this way a step has at most 16 tile products. ----
+                const int ntarget = p <= 5 ? 7 - p : 0;                    // (p = 6: column 7 is the diagonal tile alone, wave 0's)
+                for (int t = slot; t < ntarget; t += 6) {
+                    const int i = t < 6 - p ? p + 2 + t : p + 2, j = t < 6 - p ? p + 1 : p + 2;
                     double *C = &sT[tix(i, j)];
-                    const double *Xi = &sT[tix(i, p)], *Xj = &sT[tix(j, p)];
-                    double4_t acc;
+                    const double *Xi = &sT[tix(i, 0)], *Xj = &sT[tix(j, 0)];      // tile (i, k) = Xi + k TSZ
+                    const int o0 = el(r, q), o1 = el(r, 4 + q), o2 = el(r, 8 + q), o3 = el(r, 12 + q);
+                    double4_t acc, ac2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int v = 0; v < 4; ++v) acc[v] = C[el(q + 4 * v, r)];
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) acc = mfma(-Xi[el(r, 4 * s4 + q)], Xj[el(r, 4 * s4 + q)], acc);
+                    double a0 = Xi[o0], a1 = Xi[o1], a2 = Xi[o2], a3 = Xi[o3], b0 = Xj[o0], b1 = Xj[o1], b2 = Xj[o2], b3 = Xj[o3];
+                    for (int k = 0; k <= p; ++k) {
+                        const int kn = k < p ? (k + 1) * TSZ : k * TSZ;
+                        const double n0 = Xi[kn + o0], n1 = Xi[kn + o1], n2 = Xi[kn + o2], n3 = Xi[kn + o3];
+                        const double m0 = Xj[kn + o0], m1 = Xj[kn + o1], m2 = Xj[kn + o2], m3 = Xj[kn + o3];
+                        acc = mfma(-a0, b0, acc);
+                        ac2 = mfma(-a1, b1, ac2);
+                        acc = mfma(-a2, b2, acc);
+                        ac2 = mfma(-a3, b3, ac2);
+                        a0 = n0; a1 = n1; a2 = n2; a3 = n3; b0 = m0; b1 = m1; b2 = m2; b3 = m3;
+                    }
+                    acc += ac2;
 #pragma unroll
                     for (int v = 0; v < 4; ++v) if (i != j || r <= q + 4 * v) C[el(q + 4 * v, r)] = acc[v];
                 }
+                FVGP_WFINE(p, 3);
                 // ---- column p is final: its 8 - p tiles go to global memory while wave 0 factors the next diagonal tile ----
                 for (int i = p + slot; i < 8; i += 6) store_tile(i, p);
+                FVGP_WFINE(p, 4);
+                // ---- and so is the diagonal tile (p, p): its inverse (transposed into its strict upper half, over the 4x4 block
+                //      inverses nobody reads any more; the diagonal is srd) by the wave with the least to do in a step ----
+                if (slot == 5) tile_inverse(p);
+                FVGP_WFINE(p, 5);
             }
             __syncthreads();
+            FVGP_WFINE(p, 6);
             FVGP_STAMP();
         }
         if (wave == 1) store_tile(7, 7);
@@ -389,20 +478,14 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
         //      (neg_log_sum_kernel), not 128 at a time behind a barrier on the chain's critical path (1.4 thousand cycles) ------
         if (logdet_part != nullptr && tid < 128) logdet_part[tid] = tid < g.nvalid ? srd[tid] : 1.0;
         FVGP_STAMP();
-        // ---- inverse of the 8 diagonal tiles, wave w its tile (w, w): inv(L_ww)^T = I inv(L_ww)^T is the tile solve of the factor loop
-        //      applied to the identity; its strictly lower part goes, transposed, into the tile's strict upper half (over the 4x4
-        //      block inverses, which every lane has read by then), the diagonal is srd ----
-        {
-            double4_t id;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) id[v] = (r == q + 4 * v) ? 1.0 : 0.0;
-            double xinv[4];
-            double *Tw = &sT[tix(wave, wave)];
-            tile_trsm_acc(id, Tw, &srd[16 * wave], r, q, xinv);     // xinv[b] = inv(L_ww)[4b + q][r]
-#pragma unroll
-            for (int b = 0; b < 4; ++b) { xb0[b] = xinv[b]; if (4 * b + q > r) Tw[el(r, 4 * b + q)] = xinv[b]; }
-        }
+        if (wave == 7) tile_inverse(7);
         __syncthreads();
+        // the seed of the block-column inverse below (not needed when only the tile inverses go out)
+        if (!g.tiles_only) {
+            const double *Tw = &sT[tix(wave, wave)];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { const int a = 4 * b + q; xb0[b] = a > r ? Tw[el(r, a)] : (a == r ? srd[16 * wave + a] : 0.0); }
+        }
         FVGP_STAMP();
     } else {
         if (tid < 128) srd[tid] = 1.0 / sT[tix(tid >> 4, tid >> 4) + el(tid & 15, tid & 15)];
@@ -437,20 +520,21 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
     }
 
     if (g.tiles_only) {
-        // the chain's TRSM substitutes tile column by tile column (trsm_tiles_kernel) and needs these only; the full
-        // 128 x 128 inverses come from one batched launch after the factorisation (launch_leaf_inverse_batched)
-        const double *Tw = &sT[tix(wave, wave)];
-        [[maybe_unused]] unsigned long long vs = 0ull;
+        // the chain's TRSM substitutes tile column by tile column (trsm_tiles_kernel / trsm_sub) and needs the tile inverses only; the
+        // full 128 x 128 inverses come from one batched launch after the factorisation (launch_leaf_inverse_batched)
+        if (!g.do_factor) {           // (tile inverses of a given factor: as left above, transposed in the strict upper halves)
+            const double *Tw = &sT[tix(wave, wave)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int a = 4 * u + q;
-            double d = 0.0;
-            if (a > r) d = Tw[el(r, a)];
-            else if (a == r) d = srd[16 * wave + a];
-            st_linv<CHAIN>(&linv[wave * 256 + a * 16 + r], d);
-            if constexpr (VERIFY) vs += (unsigned long long)__double_as_longlong(d);
+            for (int u = 0; u < 4; ++u) {
+                const int a = 4 * u + q;
+                double d = 0.0;
+                if (a > r) d = Tw[el(r, a)];
+                else if (a == r) d = srd[16 * wave + a];
+                st_linv<CHAIN>(&linv[wave * 256 + a * 16 + r], d);
+            }
         }
-        if constexpr (VERIFY) {           // the 28 strictly lower tiles: 7168 doubles, fourteen per thread
+        if constexpr (VERIFY) {           // + the 28 strictly lower tiles: 7168 doubles, fourteen per thread
+            unsigned long long vs = vs_inv;
             for (int e = tid; e < 28 * TSZ; e += 512) {
                 const int p = e / TSZ;
                 int ti = 1;

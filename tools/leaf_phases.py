@@ -20,7 +20,7 @@ s = stamps.cpu().numpy()
 names = ["load (LDS-DMA) + zero upper + sync", "diag tile 0 (wave 0)", "sync"]
 for p in range(7):
     names += [f"p={p} wave 0: solve tile ({p + 1},{p})", f"p={p} wave 0: update tile ({p + 1},{p + 1})", f"p={p} wave 0: factor tile {p + 1}", f"p={p} sync"]
-names += ["last tile store + logdet", "diag-tile inverses + sync", "tile inverses / block-column inverse store"]
+names += ["last tile store + logdet", "tile 7 inverse + sync", "tail (block-column inverse + store, or nothing)"]
 d = np.diff(s[:len(names) + 1])
 for nme, c in zip(names, d):
     print(f"{nme:36s} {c:8d} cycles")
