@@ -22,7 +22,7 @@ MAX_RHS_VEC = 8
 
 # every symbol include/fvgp_hip.h declares (tests check the library exports each of them)
 SYMBOLS = [
-    "fvgp_hip_version", "fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_workspace_bytes", "fvgp_hip_create",
+    "fvgp_hip_version", "fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_loglik_dim", "fvgp_hip_workspace_bytes", "fvgp_hip_create",
     "fvgp_hip_destroy", "fvgp_hip_sync", "fvgp_hip_stream_create", "fvgp_hip_stream_destroy", "fvgp_hip_set_option", "fvgp_hip_get_profile", "fvgp_hip_chain_verify_counts", "fvgp_hip_kmat",
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_grad_trace", "fvgp_hip_posterior", "fvgp_hip_gemm",
@@ -132,6 +132,13 @@ def pad128(n):
     return (int(n) + TILE - 1) // TILE * TILE
 
 
+def loglik_dim(n, ncol=1):
+    """rows and columns of the square scratch the fused evaluation wants (fvgp_hip_loglik_dim): padded_dim(n), or 128 more when n
+    leaves fewer than ncol padding rows for the appended (y-m)^T"""
+    n, ncol = int(n), int(ncol)
+    return pad128(n) if pad128(n) - n >= ncol else pad128(n + ncol)
+
+
 def lib():
     """Load (once) and return the ctypes library with argtypes set."""
     global _lib
@@ -158,6 +165,8 @@ def lib():
     L.fvgp_hip_last_error_string.restype = ctypes.c_char_p
     L.fvgp_hip_padded_dim.restype = c_l
     L.fvgp_hip_padded_dim.argtypes = [c_l]
+    L.fvgp_hip_loglik_dim.argtypes = [c_l, c_i]
+    L.fvgp_hip_loglik_dim.restype = c_l
     L.fvgp_hip_workspace_bytes.argtypes = [c_l, c_l]
     L.fvgp_hip_workspace_bytes.restype = c_l
     L.fvgp_hip_create.argtypes = [ctypes.POINTER(c_p), c_i, c_p]

@@ -40,6 +40,10 @@ int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred) {
 }
 
 int64_t fvgp_hip_padded_dim(int64_t n) { return pad128(n); }
+int64_t fvgp_hip_loglik_dim(int64_t n, int ncol) {
+    if (n <= 0 || ncol < 1) return -1;
+    return (pad128(n) - n) >= ncol ? pad128(n) : pad128(n + ncol);
+}
 
 int fvgp_hip_create(fvgp_handle **out, int device, void *stream) {
     if (!out) return -1;
@@ -447,8 +451,10 @@ static double lower_flops(int64_t M, int64_t N, int64_t K) {     // algorithmic 
 // look-ahead (option "lookahead"): the trailing update of panel J is split into the block columns of
 // panel J+1 (done first) and the rest; panel J+1 is then factored on a second, high-priority stream
 // while the rest of the update runs on the main stream.
-static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host, int *info_dev = nullptr, bool enqueue_only = false) {
-    const int64_t np = pad128(n), nblk = np / TILE;
+// np_force != 0: the padded matrix has np_force rows (fvgp_hip_loglik appends (y-m)^T in a block row of its own when n leaves no padding rows)
+static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host, int *info_dev = nullptr, bool enqueue_only = false,
+                        int64_t np_force = 0) {
+    const int64_t np = np_force ? np_force : pad128(n), nblk = np / TILE;
     int rc = ensure_blocks(h, nblk);
     if (rc) return rc;
     h->winv_ok = false; h->linv_L = nullptr;
@@ -1091,22 +1097,30 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     if (h->profile) HIPCHK(hipEventRecord(h->ev_stage[1], h->stream));
     // forward solve fused into the factorisation: (y-m)^T is appended as rows n..n+ncol-1 of the padded
     // matrix (diagonal entry large enough to keep the block PD); the panel TRSM / trailing updates then
-    // leave z^T = (L^-1 (y-m))^T in those rows and quad = |z|^2.  Needs ncol free padding rows.
-    const bool fused = (np - n) >= ncol;
-    if (fused) { rc = launch_rhs_rows(h, KV, n, ld, ymean, ncol, vdiag); if (rc) return rc; }
+    // leave z^T = (L^-1 (y-m))^T in those rows and quad = |z|^2.  Needs ncol free padding rows: where padded_dim(n) leaves
+    // fewer (n a multiple of 128), the rows go into one more block row -- if the caller's square scratch has it
+    // (ld >= fvgp_hip_loglik_dim(n, ncol)); else the forward solve is a sweep of its own after the factorisation.
+    const bool room = (np - n) >= ncol;
+    const int64_t npf = room ? np : pad128(n + ncol);
+    const bool fused = room || ld >= npf;
+    if (fused) {
+        if (npf > np) { rc = launch_pad_identity(h, KV, np, npf, ld); if (rc) return rc; }
+        rc = launch_rhs_rows(h, KV, n, ld, ymean, ncol, vdiag); if (rc) return rc;
+    }
     // ONE host round trip per evaluation: the factorisation is only enqueued, its info word comes back with the scalars at the end
     // (what follows a failed factorisation computes on garbage and is thrown away; the profile option times the factorisation with
     // events and keeps the round trip in the middle)
     int info = 0;
     const bool defer = !h->profile;
-    if (defer) { rc = potrf_driver(h, KV, n, ld, nullptr, nullptr, true); if (rc) return rc; }
+    const int64_t npd = fused ? npf : 0;
+    if (defer) { rc = potrf_driver(h, KV, n, ld, nullptr, nullptr, true, npd); if (rc) return rc; }
     else {
-        rc = potrf_driver(h, KV, n, ld, &info); if (rc) return rc;
+        rc = potrf_driver(h, KV, n, ld, &info, nullptr, false, npd); if (rc) return rc;
         if (info_host) *info_host = info;
         if (info != 0) { out_host[0] = out_host[1] = out_host[2] = NAN; return 0; }
     }
     if (h->profile) HIPCHK(hipEventRecord(h->ev_stage[2], h->stream));
-    rc = launch_neg_log_sum(h, h->logdet_parts, np, h->red); if (rc) return rc;       // sum log L_ii from the leaves' 1 / L_ii
+    rc = launch_neg_log_sum(h, h->logdet_parts, fused ? npf : np, h->red); if (rc) return rc;       // sum log L_ii from the leaves' 1 / L_ii (1 on padding rows)
     if (fused) {
         rc = launch_rowsumsq(h, KV, ld, n, ncol, n, h->red + 1); if (rc) return rc;
         const int C = ncol <= 1 ? 1 : ncol <= 2 ? 2 : ncol <= 4 ? 4 : 8;
@@ -1117,9 +1131,11 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
         }
         // hand back the clean factor of blockdiag(K+V, I): identity padding rows again, and the inverse of
         // the last diagonal block recomputed without the appended rows
-        rc = launch_pad_identity(h, KV, n, np, ld); if (rc) return rc;
-        rc = launch_leaf(h, KV + (np - TILE) * ld + (np - TILE), ld, h->linv + (np / TILE - 1) * LEAF_DOUBLES, nullptr, 0, 0, TILE);
-        if (rc) return rc;
+        rc = launch_pad_identity(h, KV, n, npf, ld); if (rc) return rc;
+        if (room) {           // (a block row of their own: the last diagonal block of the factor never saw the appended rows)
+            rc = launch_leaf(h, KV + (np - TILE) * ld + (np - TILE), ld, h->linv + (np / TILE - 1) * LEAF_DOUBLES, nullptr, 0, 0, TILE);
+            if (rc) return rc;
+        }
         if (alpha) {
             rc = launch_copy_cols(h, alpha, ncol, alpha, ncol, 0, 0, np, ncol); if (rc) return rc;
             if (h->bwd_sweep && ncol == 1) { rc = launch_bwd_sweep(h, KV, ld, np, h->linv, h->vec, alpha, ncol, ncol); if (rc) return rc; }

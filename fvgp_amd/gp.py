@@ -161,8 +161,12 @@ class GP(ValidationMixin):
             return
         H = self._H
         self._np = _lib.pad128(n)
+        # the square buffers an evaluation factors in: one more block row where padded_dim(n) leaves no room for the appended (y-m)^T
+        # (n a multiple of 128): the forward solve then rides in the factorisation for every n (fvgp_hip_loglik_dim)
+        ncol = self.y_data.shape[1]
+        self._ld = _lib.loglik_dim(n, ncol) if ncol <= _lib.MAX_RHS_VEC else self._np
         self._x_dev = H.to_device(self.x_data)
-        self._L = H.empty(self._np, self._np)                     # state: factor of K+V at self.hyperparameters
+        self._L = H.empty(self._ld, self._ld)                     # state: factor of K+V at self.hyperparameters
         self._alpha = H.empty(self._np, self.y_data.shape[1])     # state: KVinvY
         self._work = self._work2 = self._alpha_work = None
 
@@ -249,7 +253,7 @@ class GP(ValidationMixin):
         if self._linalg_callables is not None and use_callables:
             return self._evaluate_callables(hps, KV, alpha, m, V, V2, ymean)
         if V2 is None and self._native is not None and ncol <= _lib.MAX_RHS_VEC and float(np.min(V)) > 0.0:
-            skip = (not need_alpha) and (self._np - n) >= ncol
+            skip = (not need_alpha) and (KV.shape[0] - n) >= ncol
             ll, logdet, quad, info = H.loglik(self._native.kernel_id, self._x_dev, hps, H.to_device(V), ym_dev, KV,
                                               None if skip else alpha)
         else:
@@ -313,7 +317,7 @@ class GP(ValidationMixin):
 
     def _scratch(self):
         if self._work is None:
-            self._work = self._H.empty(self._np, self._np)
+            self._work = self._H.empty(self._ld, self._ld)
             self._alpha_work = self._H.empty(self._np, self.y_data.shape[1])
         return self._work, self._alpha_work
 
@@ -344,7 +348,7 @@ class GP(ValidationMixin):
         work = H.empty(self._np, self._np)
         H.potri(inv, n, work)
         H.symmetrize(inv, n)
-        if self._np > n:
+        if inv.shape[0] > n:
             inv[n:, :] = 0.0
             inv[:, n:] = 0.0
         self._KVinv = inv
@@ -421,15 +425,16 @@ class GP(ValidationMixin):
                 f"(leading minor {info}). This usually indicates the new data rows are linearly dependent on old rows "
                 "or the kernel is not PD on the augmented set.")
         # assemble the bordered factor [[L, 0], [v^T, L22]] in a buffer of the new padded size
-        Lnew = H.zeros(np_new, np_new)
+        ld_new = _lib.loglik_dim(n, self.y_data.shape[1]) if self.y_data.shape[1] <= _lib.MAX_RHS_VEC else np_new
+        Lnew = H.zeros(ld_new, ld_new)
         Lnew[:n_old, :n_old] = L_old[:n_old, :n_old]
         Lnew[n_old:n, :n_old] = B[:n_old, :m].T
         Lnew[n_old:n, n_old:n] = S[:m, :m]
-        if np_new > n:
+        if ld_new > n:
             Lnew[n:, n:].fill_diagonal_(1.0)
         del B, S
         H.invalidate_factor()                                     # Lnew was filled by copies, not by potrf
-        self._np, self._L = np_new, Lnew
+        self._np, self._ld, self._L = np_new, ld_new, Lnew
         self._x_dev = H.to_device(self.x_data)
         ncol = self.y_data.shape[1]
         ymean = self.y_data - mean[:, None]
@@ -1085,10 +1090,11 @@ class GP(ValidationMixin):
             return
         H, n = self._H, self.point_number
         self._x_dev = H.to_device(self.x_data)
-        self._L = H.zeros(self._np, self._np)
+        self._ld = self.__dict__.get("_ld", self._np)                # (objects pickled before the buffers had their extra block row)
+        self._L = H.zeros(self._ld, self._ld)
         self._L[:n, :n] = H.to_device(L_host)
-        if self._np > n:
-            self._L[n:, n:] = H.to_device(np.eye(self._np - n))
+        if self._ld > n:
+            self._L[n:, n:] = H.to_device(np.eye(self._ld - n))
         self._alpha = H.zeros(self._np, self.y_data.shape[1])
         self._alpha[:n] = H.to_device(a_host)
         H.invalidate_factor()                                     # uploaded factor: no cached block inverses belong to it

@@ -57,6 +57,10 @@ enum fvgp_uplo { FVGP_FULL = 0, FVGP_LOWER = 1 };
 int fvgp_hip_version(void);
 const char *fvgp_hip_last_error_string(void);
 int64_t fvgp_hip_padded_dim(int64_t n);
+/* rows AND columns of the square scratch fvgp_hip_loglik wants for n points and ncol columns of y: padded_dim(n) while that leaves
+ * ncol padding rows for the appended (y-m)^T, else 128 more (n a multiple of 128: gp_kv.py:589-593's forward solve then rides in
+ * the factorisation for every n).  A scratch of only padded_dim(n) is accepted: the forward solve is then a sweep of its own. */
+int64_t fvgp_hip_loglik_dim(int64_t n, int ncol);
 /* device bytes a handle allocates by itself for problems of n points (npred prediction points, 0 = none);
  * every N x N buffer is the caller's (gp_kv.py keeps Chol_factor / KVinvY as attributes the same way) */
 int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred);
@@ -245,7 +249,8 @@ int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, cons
  * loglik: GPMarginalLikelihood.log_likelihood(theta)  gp_marginal_likelihood.py:137-179
  *         = kernel -> addKV -> potrf -> potrs -> logdet -> scalar, nothing leaves HBM.
  *   ymean  (n, ncol) row-major = y - m   (default mean: gp_prior.py:449-458, done by caller)
- *   KV     scratch, padded_dim(n) x ld; holds the factor L on return
+ *   KV     SQUARE scratch of ld rows and ld columns, ld >= padded_dim(n) (fvgp_hip_loglik_dim(n, ncol) to fuse the forward solve
+ *          for every n); holds the factor L of the n x n matrix (identity on the padding) at leading dimension ld on return
  *   alpha  (padded_dim(n), ncol) receives KVinvY
  *   out_host[0] = log marginal likelihood, [1] = log|KV|, [2] = sum((y-m)*KVinvY)/ncol
  *   vdiag is REQUIRED here (n positive noise variances, gp_likelihood.py:89-110): returns -8 when NULL;

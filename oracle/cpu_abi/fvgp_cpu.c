@@ -35,6 +35,7 @@ static int64_t pad128(int64_t n) { return (n + FVGP_TILE - 1) / FVGP_TILE * FVGP
 int fvgp_hip_version(void) { return 100; }
 const char *fvgp_hip_last_error_string(void) { return g_err; }
 int64_t fvgp_hip_padded_dim(int64_t n) { return pad128(n); }
+int64_t fvgp_hip_loglik_dim(int64_t n, int ncol) { if (n <= 0 || ncol < 1) return -1; return pad128(n) - n >= ncol ? pad128(n) : pad128(n + ncol); }
 int64_t fvgp_hip_workspace_bytes(int64_t n, int64_t npred) { return (n <= 0 || npred < 0) ? -1 : 0; }
 int fvgp_hip_create(fvgp_handle **out, int device, void *stream) {
     (void)stream;

@@ -591,3 +591,39 @@ def test_append_matches_a_fresh_gp_on_a_long_factor(n, m):
     np.testing.assert_allclose(a.log_likelihood(), b.log_likelihood(), rtol=1e-10)
     assert np.max(np.abs(a.posterior_covariance(xp)["S"] - b.posterior_covariance(xp)["S"])) < 1e-10 * th[0]
     np.testing.assert_allclose(a.posterior_mean(xp)["m(x)"], b.posterior_mean(xp)["m(x)"], rtol=1e-8, atol=1e-10)
+
+
+def test_facade_at_a_size_without_padding_rows():
+    """N = 1024 (a multiple of 128: padded_dim(N) leaves no row for the appended (y-m)^T): the facade's square buffers get one more
+    block row (fvgp_hip_loglik_dim) and the whole method surface -- likelihood at the state's and at another theta, gradient,
+    posterior, CholInv variance, append, pickle -- answers as the oracle does."""
+    import pickle
+    import fvgp_amd
+    from oracle import fvgp_oracle as orc
+    n = 1024
+    rng = np.random.default_rng(77)
+    x = rng.random((n + 3, 3)); y = np.sin(3 * x.sum(1)) + 0.1 * rng.standard_normal(n + 3)
+    th = np.array([1.2, 0.3, 0.35, 0.4]); nv = np.full(n + 3, 0.01)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = fvgp_amd.GP(x[:n], y[:n], init_hyperparameters=th, noise_variances=nv[:n], kernel_function="rbf_ard")
+    assert gp._L.shape == (n + 128, n + 128)
+    ref = orc.OracleGP(x[:n], y[:n], th, nv[:n], kernel="rbf_ard")
+    np.testing.assert_allclose(gp.log_likelihood(), ref.log_likelihood(), rtol=1e-10)
+    t2 = th * np.array([1.3, 0.8, 1.1, 0.9])
+    np.testing.assert_allclose(gp.log_likelihood(t2), ref.log_likelihood(t2), rtol=1e-10)
+    assert np.max(np.abs(gp.KVinvY - ref.KVinvY)) <= 1e-8 * np.max(np.abs(ref.KVinvY))
+    g, g_ref = gp.neg_log_likelihood_gradient(th), ref.neg_log_likelihood_gradient(th)
+    np.testing.assert_allclose(g, g_ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(g_ref)))
+    xp = rng.random((9, 3))
+    pc, rc = gp.posterior_covariance(xp), ref.posterior_covariance(xp)
+    assert np.max(np.abs(pc["S"] - rc["S"])) <= 1e-10 * th[0]
+    np.testing.assert_allclose(gp.posterior_mean(xp)["m(x)"], ref.posterior_mean(xp)["m(x)"], rtol=1e-8, atol=1e-10)
+    gp2 = pickle.loads(pickle.dumps(gp))
+    np.testing.assert_allclose(gp2.log_likelihood(), ref.log_likelihood(), rtol=1e-10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp.update_gp_data(x[n:], y[n:], noise_variances_new=nv[n:], append=True)
+    ref2 = orc.OracleGP(x, y, th, nv, kernel="rbf_ard")
+    np.testing.assert_allclose(gp.log_likelihood(), ref2.log_likelihood(), rtol=1e-10)
+    np.testing.assert_allclose(gp.log_likelihood(t2), ref2.log_likelihood(t2), rtol=1e-10)

@@ -606,6 +606,52 @@ def test_fused_loglik_grad_against_reference_vectors(H, name):
         np.testing.assert_allclose(g, fx["grad_c1"], rtol=1e-8, atol=1e-9 * np.max(np.abs(fx["grad_c1"])))
 
 
+@pytest.mark.parametrize("n,ncol", [(1024, 1), (2048, 2), (4089, 8), (640, 1), (4096, 1)])
+def test_fused_forward_solve_for_sizes_without_padding_rows(H, n, ncol):
+    """n a multiple of 128 (or leaving fewer padding rows than y has columns): with a square scratch of fvgp_hip_loglik_dim(n, ncol)
+    the appended (y-m)^T rows take a block row of their own and the forward solve rides in the factorisation as for every other n
+    (gp_kv.py:589-593); with a scratch of only padded_dim(n) the forward solve is a sweep of its own.  Both against the oracle, the
+    factor handed back clean (identity on every padding row), the backward solve and a posterior on it."""
+    from fvgp_amd import _lib
+    rng = np.random.default_rng(n + ncol)
+    x = rng.random((n, 3))
+    y = np.stack([np.sin((3.0 + c) * x.sum(axis=1)) for c in range(ncol)], axis=1) + 0.1 * rng.standard_normal((n, ncol))
+    nv = np.full(n, 0.01)
+    theta = np.array([1.0, 0.3, 0.35, 0.25])
+    ref = orc.OracleGP(x, y, theta, nv, kernel="rbf_ard")
+    ym = y - np.mean(y)
+    npad, nfull = _lib.pad128(n), _lib.loglik_dim(n, ncol)
+    assert nfull == npad + 128 and _lib.lib().fvgp_hip_loglik_dim(n, ncol) == nfull
+    xd, vd, ymd = H.to_device(x), H.to_device(nv), H.to_device(ym)
+    outs = []
+    for dim in (nfull, npad):
+        KV = H.to_device(np.full((dim, dim), np.nan)); alpha = H.empty(npad, ncol)
+        ll, logdet, quad, info = H.loglik(0, xd, theta, vd, ymd, KV, alpha)
+        H.sync()
+        assert info == 0
+        np.testing.assert_allclose(ll, ref.log_likelihood(), rtol=1e-10)
+        np.testing.assert_allclose(logdet, ref.logdet_KV, rtol=1e-10)
+        a = alpha.cpu().numpy()[:n]
+        assert np.max(np.abs(a - ref.KVinvY)) <= 1e-8 * np.max(np.abs(ref.KVinvY))
+        Lg = KV.cpu().numpy()
+        np.testing.assert_allclose(np.diag(Lg)[:n], np.diag(ref.Chol_factor), rtol=1e-10)
+        if dim > n:                                                  # identity on the padding: lower part of every padding row
+            assert np.array_equal(np.tril(Lg[n:, :])[:, :n], np.zeros((dim - n, n)))
+            assert np.array_equal(np.tril(Lg[n:, n:]), np.eye(dim - n))
+        # likelihood only (no alpha): allowed where the forward solve is fused
+        if dim == nfull:
+            ll2 = H.loglik(0, xd, theta, vd, ymd, KV, None)[0]
+            assert ll2 == ll
+        # the factor serves a solve and a posterior afterwards
+        xp = rng.random((5, 3)); Pp = _lib.pad128(5)
+        kx = H.empty(npad, Pp); mean = H.empty(5, ncol); var = H.empty(5)
+        H.posterior(0, xd, theta, KV, alpha, ncol, H.to_device(xp), kx, mean_out=mean, var_out=var)
+        H.sync()
+        np.testing.assert_allclose(mean.cpu().numpy() + np.mean(y), np.asarray(ref.posterior_mean(xp)["m(x)"]).reshape(5, ncol), rtol=1e-8, atol=1e-10)
+        outs.append((ll, logdet))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-12 * abs(outs[0][0])
+
+
 @pytest.mark.parametrize("name", GOLD[:4])
 def test_posterior_against_reference_vectors(H, name):
     from fvgp_amd import _lib
