@@ -424,19 +424,29 @@ class GP(ValidationMixin):
                 "Cholesky rank-n update failed: the Schur complement of the appended block is not positive definite "
                 f"(leading minor {info}). This usually indicates the new data rows are linearly dependent on old rows "
                 "or the kernel is not PD on the augmented set.")
-        # assemble the bordered factor [[L, 0], [v^T, L22]] in a buffer of the new padded size
-        ld_new = _lib.loglik_dim(n, self.y_data.shape[1]) if self.y_data.shape[1] <= _lib.MAX_RHS_VEC else np_new
-        Lnew = H.zeros(ld_new, ld_new)
-        Lnew[:n_old, :n_old] = L_old[:n_old, :n_old]
+        # the bordered factor [[L, 0], [v^T, L22]]: IN PLACE while the new rows fit into the padding rows of the buffer the factor
+        # lives in (the appended rows only ever touch rows n_old .. n: autonomous-experiment loops append a few points per step,
+        # gp_kv.py:462-476, and copying an N x N factor per step was a quarter of an append at N = 20k), else in a buffer of the
+        # new size
+        ncol = self.y_data.shape[1]
+        ld_new = _lib.loglik_dim(n, ncol) if ncol <= _lib.MAX_RHS_VEC else np_new
+        in_place = ld_new <= L_old.shape[0]
+        if in_place:
+            Lnew, ld_new = L_old, L_old.shape[0]
+            Lnew[n_old:n, n_old:] = 0.0                               # (the identity rows of the padding these rows were)
+        else:
+            # a factor that has outgrown its buffer once will be appended to again: room for max(256, n / 32) more rows
+            ld_new = _lib.pad128(ld_new + max(256, n // 32))
+            Lnew = H.zeros(ld_new, ld_new)
+            Lnew[:n_old, :n_old] = L_old[:n_old, :n_old]
+            if ld_new > n:
+                Lnew[n:, n:].fill_diagonal_(1.0)
         Lnew[n_old:n, :n_old] = B[:n_old, :m].T
         Lnew[n_old:n, n_old:n] = S[:m, :m]
-        if ld_new > n:
-            Lnew[n:, n:].fill_diagonal_(1.0)
         del B, S
         H.invalidate_factor()                                     # Lnew was filled by copies, not by potrf
         self._np, self._ld, self._L = np_new, ld_new, Lnew
         self._x_dev = H.to_device(self.x_data)
-        ncol = self.y_data.shape[1]
         ymean = self.y_data - mean[:, None]
         self._alpha = H.zeros(np_new, ncol)
         self._alpha[:n] = H.to_device(ymean)
@@ -452,7 +462,8 @@ class GP(ValidationMixin):
         self._loglik = -0.5 * (quad + self._logdet + n * np.log(2.0 * np.pi))
         self.m, self.V = mean, V
         self._K_host = None
-        self._work = self._work2 = self._alpha_work = None
+        if not (in_place and self._work is not None and self._work.shape[0] == ld_new and self._alpha_work.shape[0] == np_new):
+            self._work = self._work2 = self._alpha_work = None    # (kept when the sizes did not change: no reallocation per append)
         self._refresh_inverse()
 
     @property

@@ -627,3 +627,35 @@ def test_facade_at_a_size_without_padding_rows():
     ref2 = orc.OracleGP(x, y, th, nv, kernel="rbf_ard")
     np.testing.assert_allclose(gp.log_likelihood(), ref2.log_likelihood(), rtol=1e-10)
     np.testing.assert_allclose(gp.log_likelihood(t2), ref2.log_likelihood(t2), rtol=1e-10)
+
+
+def test_repeated_appends_stay_in_the_factor_buffer_until_it_is_full():
+    """update_gp_data(append=True) step after step, as an autonomous experiment does (gp_kv.py:462-476): while the new rows fit into
+    the padding rows of the factor's buffer the bordered factor is written in place (same buffer object, no N x N copy), across a
+    128-row block boundary too; the step that no longer fits moves to a larger buffer.  After every step: a fresh GP's answers."""
+    import fvgp_amd
+    rng = np.random.default_rng(123)
+    n0, steps = 2400, [30, 70, 50, 10, 40]              # 2400 (buffer of 2432 rows) -> 2430 -> 2500 (new buffer, with headroom) -> 2550 -> 2560 -> 2600
+    ntot = n0 + sum(steps)
+    x = rng.random((ntot, 3)); y = np.sin(3 * x.sum(1)) + 0.1 * rng.standard_normal(ntot)
+    th = np.array([1.1, 0.3, 0.35, 0.4]); nv = np.full(ntot, 0.01)
+    xp = rng.random((6, 3))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = fvgp_amd.GP(x[:n0], y[:n0], init_hyperparameters=th, noise_variances=nv[:n0], kernel_function="rbf_ard")
+        a.log_likelihood(th * 1.01)                      # (allocates the scratch pair an append in place keeps)
+        n = n0
+        same_buffer = []
+        for m in steps:
+            buf = a._L.data_ptr()
+            a.update_gp_data(x[n:n + m], y[n:n + m], noise_variances_new=nv[n:n + m], append=True)
+            n += m
+            same_buffer.append(a._L.data_ptr() == buf)
+            b = fvgp_amd.GP(x[:n], y[:n], init_hyperparameters=th, noise_variances=nv[:n], kernel_function="rbf_ard")
+            np.testing.assert_allclose(a.log_likelihood(), b.log_likelihood(), rtol=1e-10)
+            np.testing.assert_allclose(a.log_likelihood(th * 1.02), b.log_likelihood(th * 1.02), rtol=1e-10)
+            assert np.max(np.abs(a.posterior_covariance(xp)["S"] - b.posterior_covariance(xp)["S"])) < 1e-10 * th[0]
+            np.testing.assert_allclose(a.posterior_mean(xp)["m(x)"], b.posterior_mean(xp)["m(x)"], rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(a.neg_log_likelihood_gradient(th), b.neg_log_likelihood_gradient(th), rtol=1e-7, atol=1e-8)
+            del b
+    assert same_buffer == [True, False, True, True, True]
