@@ -28,7 +28,7 @@ SYMBOLS = [
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_grad_trace", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower", "fvgp_hip_trace_dot", "fvgp_hip_colsumsq", "fvgp_hip_add_matrix", "fvgp_hip_dot", "fvgp_hip_coldot",
     "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
-    "fvgp_hip_grad_trace_cols", "fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy", "fvgp_hip_all_reduce",
+    "fvgp_hip_grad_trace_cols", "fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy", "fvgp_hip_ipc_window", "fvgp_hip_comm_init_ipc", "fvgp_hip_all_reduce",
     "fvgp_hip_all_gather", "fvgp_hip_comm_profile", "fvgp_hip_dist_workspace", "fvgp_hip_loglik_dist", "fvgp_hip_dist_scratch", "fvgp_hip_solve_dist",
     "fvgp_hip_posterior_dist", "fvgp_hip_grad_dist",
 ]
@@ -63,6 +63,9 @@ def bind_dist(L):
         L.fvgp_hip_comm_init.argtypes = [c_p, c_p, c_i, c_i]
         L.fvgp_hip_comm_profile.argtypes = [c_p, P_d]
     L.fvgp_hip_comm_init_callbacks.argtypes = [c_p, ctypes.POINTER(Collectives), c_i, c_i]
+    if hasattr(L, "fvgp_hip_ipc_window"):
+        L.fvgp_hip_ipc_window.argtypes = [c_p, c_l, c_p]
+        L.fvgp_hip_comm_init_ipc.argtypes = [c_p, c_p, ctypes.c_char_p, c_i, c_i]
     L.fvgp_hip_comm_destroy.argtypes = [c_p]
     L.fvgp_hip_all_reduce.argtypes = [c_p, c_p, c_l]
     L.fvgp_hip_all_gather.argtypes = [c_p, c_p, c_p, c_l]
@@ -431,6 +434,17 @@ class Handle(DistCalls):
     def comm_init_callbacks(self, coll, rank, nranks):
         self._coll = coll                                          # the callbacks must outlive the handle's use of them
         _check(lib().fvgp_hip_comm_init_callbacks(self._h, ctypes.byref(coll), int(rank), int(nranks)), "fvgp_hip_comm_init_callbacks")
+
+    def ipc_window(self, window_bytes):
+        """allocate this rank's window of the direct (IPC) collectives; returns its 64-byte handle"""
+        buf = ctypes.create_string_buffer(64)
+        _check(lib().fvgp_hip_ipc_window(self._h, int(window_bytes), buf), "fvgp_hip_ipc_window")
+        return buf.raw
+
+    def comm_init_ipc(self, all_handles, shm_name, rank, nranks):
+        """bind the direct collectives: all_handles = the ranks' 64-byte window handles in rank order"""
+        blob = ctypes.create_string_buffer(b"".join(bytes(hd) for hd in all_handles), 64 * int(nranks))
+        _check(lib().fvgp_hip_comm_init_ipc(self._h, blob, shm_name.encode(), int(rank), int(nranks)), "fvgp_hip_comm_init_ipc")
 
     def comm_destroy(self):
         _check(lib().fvgp_hip_comm_destroy(self._h), "fvgp_hip_comm_destroy")

@@ -127,6 +127,7 @@ struct fvgp_handle {
     fvgp_collectives coll{nullptr, nullptr, nullptr};
     int coll_rank = 0, coll_nranks = 1;
     void *rccl_lib = nullptr, *rccl_comm = nullptr;
+    void *ipc_comm = nullptr;          // direct collectives over peer mappings (ipc.hip), or nullptr
     struct CollRec { int kind; double bytes; hipEvent_t e0, e1; };
     std::vector<CollRec> coll_rec;
     std::vector<hipEvent_t> coll_ev_pool;
@@ -254,4 +255,5 @@ int launch_trace_dot(fvgp_handle *h, const double *W, int64_t ldw, const double 
 int ensure_linv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl);
 int ensure_scratch(fvgp_handle *h, int64_t np);
 int fvgp_ensure_side(fvgp_handle *h);
+void fvgp_ipc_destroy(fvgp_handle *h);
 int fvgp_read_back(fvgp_handle *h, const double *dev, double *host, int count);

@@ -187,6 +187,7 @@ int fvgp_hip_comm_destroy(fvgp_handle *h) {
     if (h->side) (void)hipStreamSynchronize(h->side);         // the chain stream issues the collectives: it must be done with the communicator
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->rccl_comm) { (void)g_rccl.CommDestroy((ncclComm_t)h->rccl_comm); h->rccl_comm = nullptr; }
+    fvgp_ipc_destroy(h);
     h->coll = fvgp_collectives{nullptr, nullptr, nullptr};
     h->coll_rank = 0; h->coll_nranks = 1;
     for (auto &r : h->coll_rec) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

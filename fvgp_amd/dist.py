@@ -110,6 +110,12 @@ class HipOps:
     def comm_init_callbacks(self, coll, rank, nranks):
         self.H.comm_init_callbacks(coll, rank, nranks)
 
+    def ipc_window(self, window_bytes):
+        return self.H.ipc_window(window_bytes)
+
+    def comm_init_ipc(self, all_handles, shm_name, rank, nranks):
+        self.H.comm_init_ipc(all_handles, shm_name, rank, nranks)
+
     def comm_profile(self):
         return self.H.comm_profile()
 
@@ -176,7 +182,7 @@ class ShardedGP:
     `collectives` is "rccl"): the whole multi-rank code path on one GPU."""
 
     def __init__(self, x, y, noise_variances, kernel="rbf_ard", group=None, ops=None, panel=1024,
-                 rank=None, world=None, collectives="auto", force_collectives=False):
+                 rank=None, world=None, collectives="auto", force_collectives=False, ipc_window_bytes=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -225,6 +231,28 @@ class ShardedGP:
                 if self.P > 1:
                     dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
                 o.comm_init(uid[0], self.p, self.P)
+            elif collectives == "ipc":
+                # direct collectives over peer mappings (csrc/ipc.hip): every rank's window handle to every rank, the flag file's name
+                # from rank 0; the bootstrap is the process group's own object collectives (any backend)
+                import os
+                import uuid
+                window = int(ipc_window_bytes) if ipc_window_bytes else self._ipc_window_bytes()
+                handle = o.ipc_window(window)
+                if self.P > 1:
+                    handles = [None] * self.P
+                    dist.all_gather_object(handles, handle, group=group)
+                    name = [f"/fvgp_ipc_{os.getpid()}_{uuid.uuid4().hex[:12]}" if self.p == 0 else None]
+                    dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                else:
+                    handles, name = [handle], [f"/fvgp_ipc_{os.getpid()}_{uuid.uuid4().hex[:12]}"]
+                o.comm_init_ipc(handles, name[0], self.p, self.P)
+                if self.P > 1:
+                    dist.barrier(group=group)                       # every rank has mapped the flag file: its name can go
+                if self.p == 0:
+                    try:
+                        os.unlink("/dev/shm" + name[0])
+                    except OSError:
+                        pass
             elif user_coll is not None:
                 o.comm_init_callbacks(user_coll, self.p, self.P)
             elif self.P > 1:
@@ -269,6 +297,12 @@ class ShardedGP:
         self.keep_factor = True            # False: a likelihood-only evaluation leaves the factored panels out of A (no copy back)
         self.theta = None
         self.alpha = None                  # KVinvY, replicated, (np_, 128) with the first ncol columns in use
+
+    def _ipc_window_bytes(self):
+        """two halves, each large enough for the biggest all-gather piece of an evaluation (a rank's rows of a panel factor), capped at
+        2 x 256 MB: larger calls (the gradient's all-reduces) are cut into pieces by the library"""
+        piece = max(self.nloc * TILE * self.NB * 8, self.NB * self.NB * 8, 1 << 20)
+        return 2 * min(piece, 256 << 20)
 
     # -- collectives of the parts sequenced here (through the handle: RCCL or the bound callbacks; nothing on one rank) ----
     def _all_reduce(self, t):

@@ -183,6 +183,16 @@ int fvgp_hip_comm_unique_id(void *out128_host);
 int fvgp_hip_comm_init(fvgp_handle *h, const void *unique_id128_host, int rank, int nranks);
 int fvgp_hip_comm_init_callbacks(fvgp_handle *h, const fvgp_collectives *cb, int rank, int nranks);
 int fvgp_hip_comm_destroy(fvgp_handle *h);
+/* Direct collectives over peer mappings instead of a collective library (csrc/ipc.hip): the reference's workers hand covariance
+ * blocks to each other directly (gp_prior.py:301-322, gp2Scale_covariance.py:419-420).  The payload moves by hipMemcpyAsync
+ * between IPC mappings (copy engines, every peer at once); the only kernels are one-wave flag writers / pollers.
+ *   ipc_window   : allocates this rank's window (window_bytes, two halves: a call moves at most window_bytes / 2 per piece) and
+ *                  returns its 64-byte IPC handle (host); every rank hands its handle to every other by any means;
+ *   comm_init_ipc: all_handles64_host = nranks x 64 bytes in rank order; shm_name = a POSIX shared-memory name ("/fvgp_...") that is
+ *                  NEW for this communicator and the same on every rank (the flag words live there; unlink it once every rank has
+ *                  returned).  Binds the handle's collectives like fvgp_hip_comm_init.  nranks <= 16. */
+int fvgp_hip_ipc_window(fvgp_handle *h, int64_t window_bytes, void *out_handle64_host);
+int fvgp_hip_comm_init_ipc(fvgp_handle *h, const void *all_handles64_host, const char *shm_name, int rank, int nranks);
 /* the handle's collectives on its stream (the parts of the sharded path that are sequenced by the caller: backward solve,
  * posterior, gradient -- gp_kv.py:574-593, gp_posterior.py:139-288 on the distributed factor) */
 int fvgp_hip_all_reduce(fvgp_handle *h, double *buf, int64_t count);

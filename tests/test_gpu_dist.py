@@ -331,3 +331,63 @@ def test_default_panel_shapes_over_gloo_against_the_oracle(tmp_path, world, n, p
     assert np.max(np.abs(r["S"] - ref.posterior_covariance(xp)["S"])) <= 1e-10
     g_ref = ref.neg_log_likelihood_gradient_potri(theta) if n > 4000 else ref.neg_log_likelihood_gradient(theta)
     np.testing.assert_allclose(r["g"], g_ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(g_ref)))
+
+
+WORKER_IPC = r'''
+import os, sys, json
+os.environ["FVGP_DEVICE"] = "0"          # every rank on the one GPU of the test box
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from conftest import synth
+from fvgp_amd.dist import ShardedGP
+torch.cuda.set_device(0)
+if {world} > 1:
+    dist.init_process_group(backend="gloo")          # the bootstrap only: window handles and the flag file's name
+n, d = {n}, 3
+x, y = synth(n, d)
+theta = np.array([1.0, 0.3, 0.3, 0.3])
+gp = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel={panel}, collectives="ipc", force_collectives=True,
+               ipc_window_bytes={window}, **({{}} if {world} > 1 else dict(rank=0, world=1)))
+assert gp.collectives == "ipc" and gp.general
+gp.ops.set_option("profile", 1)
+lls = [gp.log_likelihood(theta * (1 + 0.02 * t))[0] for t in range(3)]
+prof = gp.collective_summary()
+ev = gp.evaluate(theta, want_alpha=True)
+xp = np.random.default_rng(3).random((150, d))
+mean, S = gp.posterior(xp)
+g = gp.gradient(slab=512)
+rank = dist.get_rank() if {world} > 1 else 0
+if rank == 0:
+    np.savez({out!r}, lls=np.array(lls), ev=np.array(ev), alpha=gp.alpha[:n, 0].cpu().numpy(), mean=mean, S=S, g=g,
+             calls=np.array([prof["all_gather"][0], prof["all_reduce"][0]]), ms=np.array([prof["all_gather"][2], prof["all_reduce"][2]]))
+    print("RESULT " + json.dumps(dict(ok=True)))
+gp.ops.close()
+if {world} > 1:
+    dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,n,panel,window", [(1, 2500, 512, 0), (2, 6000, 1024, 0), (4, 3000, 512, 0), (3, 2500, 256, 64 * 1024)])
+def test_direct_ipc_collectives_against_the_oracle(tmp_path, world, n, panel, window):
+    """The row-sharded path with the direct collectives of csrc/ipc.hip (collectives="ipc": payload by hipMemcpyAsync between IPC
+    mappings of the ranks' windows, flags in a shared-memory file, one-wave poll / flag kernels) instead of a collective library:
+    1 - 4 ranks sharing the box's GPU, gloo only as the bootstrap.  Likelihood, KVinvY, posterior and gradient against the oracle;
+    the last case has a window so small that every large call is cut into many pieces."""
+    out = str(tmp_path / "ipc.npz")
+    _spawn(tmp_path, WORKER_IPC.format(root=ROOT, n=n, panel=panel, world=world, window=window or None, out=out), world)
+    r = np.load(out)
+    x, y = synth(n, 3)
+    nv = np.full(n, 0.01)
+    theta = np.array([1.0, 0.3, 0.3, 0.3])
+    for t, ll in enumerate(r["lls"]):
+        ref, _ = orc.log_likelihood_once(x, y, nv, theta * (1 + 0.02 * t), "rbf_ard")
+        np.testing.assert_allclose(ll, ref, rtol=1e-10)
+    assert r["calls"][0] > 0 and r["ms"][0] > 0.0
+    ref = orc.OracleGP(x, y, theta, nv, kernel="rbf_ard")
+    np.testing.assert_allclose(r["ev"][0], ref.log_likelihood(), rtol=1e-10)
+    assert np.max(np.abs(r["alpha"] - ref.KVinvY[:, 0])) <= 1e-8 * np.max(np.abs(ref.KVinvY))
+    xp = np.random.default_rng(3).random((150, 3))
+    np.testing.assert_allclose(r["mean"][:, 0] + np.mean(y), ref.posterior_mean(xp)["m(x)"], rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(r["S"] - ref.posterior_covariance(xp)["S"])) <= 1e-10
+    g_ref = ref.neg_log_likelihood_gradient_potri(theta) if n > 4000 else ref.neg_log_likelihood_gradient(theta)
+    np.testing.assert_allclose(r["g"], g_ref, rtol=1e-8, atol=1e-9 * np.max(np.abs(g_ref)))

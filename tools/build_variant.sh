@@ -6,7 +6,7 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/fvgp_amd/csrc/variants/$name
 mkdir -p "$out"
-for f in gemm kmat leaf chain solve api dist; do
+for f in gemm kmat leaf chain solve api dist ipc; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function "$@" -c "$root/fvgp_amd/csrc/$f.hip" -o "$out/$f.o" &
 done
 wait

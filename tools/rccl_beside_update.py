@@ -2,7 +2,7 @@
 chain stream BESIDE the rank's saturated trailing update, against the same calls replayed ALONE on the idle chip
 (fvgp_hip_comm_profile: calls, ms on their stream).  At one rank an all-gather moves no bytes between GPUs -- RCCL runs its copy
 kernel -- so this times exactly the part a multi-rank run cannot avoid either: a collective's kernel queueing for compute units.
-  python tools/rccl_beside_update.py [N] [panel]"""
+  python tools/rccl_beside_update.py [N] [panel] [update CUs] [rccl|ipc]"""
 import os
 import sys
 
@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def measure(n, panel=1024, keep_cus=256):
+def measure(n, panel=1024, keep_cus=256, collectives="rccl"):
     import torch
     from fvgp_amd import _lib
     from fvgp_amd.dist import ShardedGP, TILE, HipOps
@@ -25,7 +25,7 @@ def measure(n, panel=1024, keep_cus=256):
     rng = np.random.default_rng(20240501)
     x = rng.random((n, 3)); y = np.sin(3 * x.sum(1)) + 0.1 * rng.standard_normal(n)
     ops = HipOps(_lib.Handle(0)) if keep_cus < 256 else None
-    sh = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=panel, rank=0, world=1, force_collectives=True, collectives="rccl", ops=ops)
+    sh = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=panel, rank=0, world=1, force_collectives=True, collectives=collectives, ops=ops)
     th = np.array([1.0, 0.3, 0.3, 0.3])
     o = sh.ops
     sh.log_likelihood(th)
@@ -60,7 +60,7 @@ def measure(n, panel=1024, keep_cus=256):
     o.set_option("profile", 0)
     if ctx is not None:
         ctx.__exit__(None, None, None)
-    return {"n": n, "panel": panel, "update_cus": keep_cus, "evaluation_ms": 1e3 * wall, "calls": beside[0], "doubles_moved": float(sum(sizes)),
+    return {"collectives": collectives, "n": n, "panel": panel, "update_cus": keep_cus, "evaluation_ms": 1e3 * wall, "calls": beside[0], "doubles_moved": float(sum(sizes)),
             "all_gather_ms_beside_update": beside[2], "all_gather_ms_alone": alone[2], "calls_alone": alone[0],
             "slowdown": beside[2] / max(alone[2], 1e-9)}
 
@@ -68,5 +68,6 @@ def measure(n, panel=1024, keep_cus=256):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
     panel = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    coll = sys.argv[4] if len(sys.argv) > 4 else "rccl"          # "rccl" | "ipc" (csrc/ipc.hip: copies between window mappings + one-wave flag kernels)
     for keep in ([int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [256]):
-        print(measure(n, panel, keep), flush=True)
+        print(measure(n, panel, keep, coll), flush=True)
