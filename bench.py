@@ -255,6 +255,19 @@ def config_records():
             "collectives": {k: {"calls": v[0], "bytes_from_peers": v[1], "ms_on_chain_stream_beside_update": v[2]} for k, v in cs.items()}}
         del sh
         torch.cuda.empty_cache()
+        # what ONE rank of the configured 8-rank run has to do, on this GPU: rank 0's kernel / stream schedule of an 8-rank
+        # evaluation at N = 100k with the collectives replaced by local copies of the same size (tools/shard_emulate.py): the
+        # compute-side floor of C4 before any byte crosses xGMI, against the rank's share of the flops at the fp64 MFMA peak
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from shard_emulate import emulate
+            ms8, _, enq8 = emulate(n, world=8, rank=0, panel=1024, steps=2)
+            out["C4_size_one_gpu"]["p8_rank0_schedule_emulated_ms"] = ms8
+            out["C4_size_one_gpu"]["p8_rank_flop_bound_ms"] = 1e3 * flops / 8 / peak
+            out["C4_size_one_gpu"]["p8_frac_of_flop_bound"] = (1e3 * flops / 8 / peak) / ms8
+            out["C4_size_one_gpu"]["p8_host_enqueue_ms"] = enq8
+        except Exception as e:                  # noqa: BLE001
+            out["C4_size_one_gpu"]["p8_emulation_error"] = f"{type(e).__name__}: {e}"[:200]
     except Exception as e:                      # noqa: BLE001 -- a side record must not take the headline down
         out["C4_size_one_gpu"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
