@@ -137,6 +137,25 @@ def headline_parity(cb, n, d, hip_at_n, device):
 # ------------------------------------------------------------------------------------------------
 # the other BASELINE.json configurations that fit one GPU (outside the timed region)
 # ------------------------------------------------------------------------------------------------
+class _stdout_to_stderr:
+    """fd-level: what native libraries print while a communicator is built (RCCL's version banner goes to stdout) lands on stderr, so
+    that the JSON line stays the only line on stdout"""
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
+def _progress(msg):
+    """a line on stderr now and then: a run that is silent for minutes looks hung to a watchdog (the one JSON line stays alone on stdout)"""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def config_records():
     """C2 (N=20k RBF + posterior at P=1000), C3 (N=50k Matern-5/2 value + gradient), C5 (fvGP 4 x 10k, d=2) through
     the GP facade; wall time of the public call, best of two, against the fp64 MFMA bound of its flops."""
@@ -181,6 +200,7 @@ def config_records():
                  "posterior_cov_bound_ms": 1e3 * (n * n * 1000.0 + 2.0 * n * 1000.0 ** 2) / peak}
     del gp
     torch.cuda.empty_cache()
+    _progress("C2 done")
     # the training loop's sizes (gp_mcmc.py:96-224 calls log_likelihood(theta) 10 000 times; C1 is N=500, d=1): wall time of the
     # public call, best of five
     small = {}
@@ -193,6 +213,7 @@ def config_records():
         del gp
     out["small_N"] = {"workload": "RBF log_likelihood(theta) at the training loop's sizes (C1: N=500 d=1)", **small}
     torch.cuda.empty_cache()
+    _progress("small sizes done")
     # C3
     n = 50000
     x, y = synth(n, 3)
@@ -203,6 +224,7 @@ def config_records():
                  "loglik_ms": best(lambda: gp.log_likelihood(th * 1.01), reps=1)}
     del gp
     torch.cuda.empty_cache()
+    _progress("C3 done")
     # C5
     rng = np.random.default_rng(20240501)
     xm = rng.random((10000, 2))
@@ -217,6 +239,7 @@ def config_records():
                  "loglik_ms": ll, "bound_ms": 1e3 * float(n) ** 3 / 3 / peak, "frac": (1e3 * float(n) ** 3 / 3 / peak) / ll}
     del gp
     torch.cuda.empty_cache()
+    _progress("C5 done")
     # C4's size on ONE GPU (the 8-GPU run is the driver's): the fused single-GPU evaluation against the row-sharded driver at one
     # rank, its whole multi-rank code path taken with the collectives issued through RCCL (one-rank communicator)
     try:
@@ -234,7 +257,8 @@ def config_records():
         fused = best(lambda: vals.append(H.loglik(0, xd, th * 1.01, vd, ymd, KV, None)[0]), reps=1)
         del KV
         torch.cuda.empty_cache()
-        sh = ShardedGP(x, y, nv, kernel="rbf_ard", panel=1024, rank=0, world=1, force_collectives=True, collectives="rccl")
+        with _stdout_to_stderr():
+            sh = ShardedGP(x, y, nv, kernel="rbf_ard", panel=1024, rank=0, world=1, force_collectives=True, collectives="rccl")
         svals = []
         sharded = best(lambda: svals.append(sh.log_likelihood(th * 1.01)[0]), reps=1)
         # the collectives of ONE more evaluation, timed with events on the chain stream, i.e. beside the rank's trailing update
@@ -255,6 +279,7 @@ def config_records():
             "collectives": {k: {"calls": v[0], "bytes_from_peers": v[1], "ms_on_chain_stream_beside_update": v[2]} for k, v in cs.items()}}
         del sh
         torch.cuda.empty_cache()
+        _progress("C4 size on one GPU done")
         # what ONE rank of the configured 8-rank run has to do, on this GPU: rank 0's kernel / stream schedule of an 8-rank
         # evaluation at N = 100k with the collectives replaced by local copies of the same size (tools/shard_emulate.py): the
         # compute-side floor of C4 before any byte crosses xGMI, against the rank's share of the flops at the fp64 MFMA peak
@@ -362,9 +387,10 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d, 
     # world == 1 (`--gpus 1 --mode sharded`): the multi-rank code path on one GPU, its collectives issued through RCCL
     # (a one-rank communicator) unless --backend says otherwise
     force = dist is None
-    gp = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=args.outer_block or 1024,
-                   rank=None if dist is not None else 0, world=None if dist is not None else 1,
-                   force_collectives=force, collectives=("rccl" if args.backend == "nccl" else "torch") if force else "auto")
+    with _stdout_to_stderr():
+        gp = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=args.outer_block or 1024,
+                       rank=None if dist is not None else 0, world=None if dist is not None else 1,
+                       force_collectives=force, collectives=("rccl" if args.backend == "nccl" else "torch") if force else "auto")
     for t in range(args.warmup):
         gp.log_likelihood(theta0 * (1.0 + 0.02 * t))
     H = gp.ops
@@ -468,7 +494,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+            with _stdout_to_stderr():
+                dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(backend=args.backend)
 
@@ -533,6 +560,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     H.set_option("profile", 0)
+    _progress(f"timed region done: {1e3 * elapsed / args.steps:.1f} ms per step")
     # outside the timed region: one evaluation at the theta the CPU leg's oracle runs, on the same resident buffers (headline_parity)
     hip_theta0 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -590,7 +618,9 @@ def main():
             except Exception as e:                                  # noqa: BLE001 -- reported in the line, the headline stands
                 out["configs"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline:                                # the CPU leg is timed on rank 0 at N=1 only
+            _progress("configs done; the CPU leg (the oracle on this host, about a minute and a half at N = 50000) starts")
             out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_sample_n)
+            _progress("CPU leg done")
             out["headline_parity"] = headline_parity(out["cpu_baseline"], n, d, hip_theta0, local)
     if rank == 0:
         if sharded_error is not None:
