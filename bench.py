@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X dense fp64 matrix peak: 256 CU x 2.4 GHz x 128 flop/clk/CU
 PEAK_HBM_GBS = 8000.0
 XGMI_GBPS_PER_GPU = 7 * 153.0    # 7 links x ~153 GB/s (point-to-point)
-TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01f_pmc_traffic.json")
+TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01f_pmc_traffic.json")
 
 
 def synth(n, d, seed=20240501):

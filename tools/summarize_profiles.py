@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", f"{tag}_profiles")
 dst = os.path.join(ROOT, "profiles")
 KERNEL = "gemm_f64_kernel<0, 0, 1>"
@@ -43,5 +43,12 @@ rec = {"kernel": KERNEL,
                "stores. Fabric-side counters: Infinity-Cache hits are included, so this is an upper bound on HBM bytes.",
        "bytes_per_launch": (fetch_b + write_b) / max(nf, 1), "bytes_per_evaluation": (fetch_b + write_b) / evals}
 assert nf == nw, (nf, nw)
+l2 = os.path.join(src, "pmc_l2", "l2_counter_collection.csv")
+if os.path.exists(l2):
+    hit, _ = counter_sum(l2, "TCC_HIT_sum")
+    miss, _ = counter_sum(l2, "TCC_MISS_sum")
+    if hit + miss > 0:
+        rec["l2_hit_rate"] = hit / (hit + miss)
+        rec["l2_note"] = "TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) over the same launches, a third --pmc pass"
 json.dump(rec, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(rec, indent=1))
