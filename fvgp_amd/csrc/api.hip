@@ -157,6 +157,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "lookahead_min")) { h->lookahead_min = value; return 0; }
     if (!strcmp(key, "panel_chain")) { if (value < 0 || value > 2) return -3; h->panel_chain = (int)value; return 0; }
     if (!strcmp(key, "panel_chain_min")) { h->panel_chain_min = value; return 0; }
+    if (!strcmp(key, "chain_wide")) { h->chain_wide = (int)value; return 0; }
     if (!strcmp(key, "cols_split")) { h->cols_split = value ? 1 : 0; return 0; }
     if (!strcmp(key, "chain_verify")) { h->chain_verify = value ? 1 : 0; return 0; }
     if (!strcmp(key, "cols_split_rows")) { h->cols_split_rows = value; return 0; }
@@ -430,7 +431,8 @@ static int panel_factor_nested(fvgp_handle *h, double *A, int64_t n, int64_t np,
 // trailing update to run beside it, else the three launches per 128 columns
 static int panel_factor_any(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
     // (the resident kernel has flag words for 32 block columns: a wider panel -- `outer_block` above 4096 -- takes the nested chain)
-    if (h->panel_chain && np - J0 >= h->panel_chain_min && (Jend - J0) / TILE <= FVGP_CHAIN_MAX_BLOCKS) return launch_panel_chain(h, A, n, np, lda, J0, Jend);
+    if (h->panel_chain && (np - J0 >= h->panel_chain_min || (h->chain_alone && h->chain_wide)) && (Jend - J0) / TILE <= FVGP_CHAIN_MAX_BLOCKS)
+        return launch_panel_chain(h, A, n, np, lda, J0, Jend);
     return panel_factor_nested(h, A, n, np, lda, J0, Jend);
 }
 
@@ -487,9 +489,13 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     // panel boundaries: width NB, or the wider `outer_block_big` while more than `big_threshold` rows remain
     // (a wider panel halves the C read-modify-write passes of the trailing update; its longer factorisation
     // chain only stays hidden behind the update while the trailing matrix is large)
+    // matrices too short for look-ahead (no trailing update to hide a panel behind): ONE resident kernel per 4096 columns, a workgroup per
+    // 128 x 128 block (chain.hip) -- 36 us per 128 columns instead of the ~50 us of three launches, and no update launches in between
+    const bool wide = h->panel_chain && h->chain_wide && np < h->lookahead_min;
     std::vector<int64_t> bnd;
     for (int64_t J0 = 0; J0 < np;) {
         bnd.push_back(J0);
+        if (wide) { J0 = (J0 + FVGP_CHAIN_MAX_BLOCKS * TILE < np) ? J0 + FVGP_CHAIN_MAX_BLOCKS * TILE : np; continue; }
         // three widths: `outer_block_big` (2048) while the trailing update hides any chain, NB (1024), and `outer_block_small`
         // (512) for the last `small_threshold` rows, where the chain is what the factorisation waits for: a 512-wide panel's
         // update tiles retire twice as often (K = 512), so the chain's many-workgroup kernels find slots sooner (N=8k -4 %,
@@ -503,6 +509,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     // a switch between the two streams costs ~12 us (event wait): below ~6k rows the panels are too short to pay for it
     // (measured: N=4000 2.78 ms with, 2.68 without; N=8000 7.48 / 7.58; N=12000 16.4 / 16.9)
     const bool la = h->lookahead && npan > 2 && np >= h->lookahead_min;
+    h->chain_alone = la ? 0 : 1;            // (chain.hip: no trailing update runs beside the panel kernels of this factorisation)
     const bool can_split = la && h->cols_split && h->panel_chain && np - bnd[1] >= h->panel_chain_min && chain_streams_concurrent(h) == 1;
     if (!la) {
         for (size_t J = 0; J < npan; ++J) {
@@ -897,7 +904,7 @@ int fvgp_hip_panel_potrf_dev(fvgp_handle *h, double *T, int64_t w, int64_t rows,
     if (rc) return rc;
     h->winv_ok = false; h->linv_L = nullptr;
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
-    if (h->panel_chain >= 2) rc = launch_panel_chain(h, T, n_valid, rows, ldt, 0, w);   // (the row-sharded driver's stacked panel: measured 3 % slower in the 8-rank emulation, off unless panel_chain = 2)
+    if (h->panel_chain >= 2) { h->chain_alone = 0; rc = launch_panel_chain(h, T, n_valid, rows, ldt, 0, w); }   // (the row-sharded driver's stacked panel: measured 3 % slower in the 8-rank emulation, off unless panel_chain = 2)
     else rc = panel_factor_nested(h, T, n_valid, rows, ldt, 0, w);   // leaf / TRSM of every row below / in-panel update per 128 columns, in sub-panels of `inner_block`
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));

@@ -38,6 +38,7 @@ struct ChainArgs {
     double *A; long lda;              // element (J0, J0): origin of the panel
     int n;                            // 128-column blocks of the panel
     int rows;                         // 128-row blocks from J0 to the end of the padded matrix (>= n)
+    int n2;                           // n <= n2 <= rows: the first n2 block rows have one workgroup per BLOCK (the square always), the rest one per block row
     int nvalid;                       // rows of the matrix proper from J0 on (the rest is identity padding)
     double *linv;                     // inverses of the panel's diagonal blocks (n x 128 x 128)
     double *logdet;                   // 1 / L_ii, 128 per block
@@ -58,11 +59,13 @@ struct ChainArgs {
 // handed over, taken by the producer from the registers / LDS it stores from, published (sc1) before the flag; every consumer sums
 // the bytes as they ARRIVED (the LDS images its LDS-DMA loads filled, the registers its buffer loads returned) and compares.  A
 // stale or torn line changes a sum: VH_BAD counts mismatches, VH_CHECKS comparisons.  The words of a launch: row_done payloads
-// [row][step] (32 x 32), leaf payloads [block] (32), the two counters; zeroed by the host per launch.
-constexpr int VH_ROW = 0, VH_LEAF = 32 * 32, VH_BAD = VH_LEAF + 32, VH_CHECKS = VH_BAD + 1, VH_WORDS = VH_CHECKS + 1;
+// [row][step] (1024 x 32), leaf payloads [block] (32), the two counters; zeroed by the host per launch.
+constexpr int VH_ROWS = 1024;           // block rows that may have a workgroup per block
+constexpr int VH_ROW = 0, VH_LEAF = VH_ROWS * 32, VH_BAD = VH_LEAF + 32, VH_CHECKS = VH_BAD + 1, VH_WORDS = VH_CHECKS + 1;
 
 constexpr int FL = 16;                // 64-bit words between two flags
-constexpr int F_TICKET = 0, F_LEAF = 1, F_ABORT = 2, F_ROW = 3, F_COLS = 40;
+constexpr int F_TICKET = 0, F_LEAF = 1, F_ABORT = 2, F_COLS = 40, F_LCOL = 41, F_XCOL = 42, F_DUMMY = 75, F_ROW = 96;      // F_XCOL: one per block row of the square (32), F_ROW: one per block row with a workgroup per block (VH_ROWS)
+constexpr int FLAG_LINES = F_ROW + VH_ROWS;
 constexpr int IMGD = 128 * 16;        // doubles of one operand image (128 rows x 16 k)
 
 __device__ __forceinline__ unsigned long long flag_load(const unsigned long long *p) {
@@ -84,13 +87,14 @@ __device__ __forceinline__ void chain_stamp(const ChainArgs &g, const int code, 
 }
 
 // lane 0 polls until *flag has reached `need`; false when the launch is being abandoned
-__device__ __forceinline__ bool chain_wait(const ChainArgs &g, const int flag, const unsigned long long need, int *s_ok) {
+// (`relaxed`: the waiter is not what the next leaf waits for -- it polls four times less often: hundreds of workgroups of a wide panel wait at a time)
+__device__ __forceinline__ bool chain_wait(const ChainArgs &g, const int flag, const unsigned long long need, int *s_ok, const bool relaxed = false) {
     if (threadIdx.x == 0) {
         int ok = 1, it = 0;
         unsigned long long t0 = 0;
         const unsigned long long *p = g.flags + (long)flag * FL;
         while ((long long)(flag_load(p) - need) < 0) {
-            __builtin_amdgcn_s_sleep(8);
+            if (relaxed) __builtin_amdgcn_s_sleep(40); else __builtin_amdgcn_s_sleep(8);
             if ((++it & 127) == 0) {
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();      // 100 MHz
                 if (t0 == 0) t0 = now;
@@ -144,11 +148,12 @@ __device__ __forceinline__ void verify_compare(const ChainArgs &g, const unsigne
 // row-major; the K loop of the trailing update (gemm.hip): unpadded [128][16] images with XOR-swizzled 16-byte chunks filled
 // by LDS-DMA, lane group q owns k = 4q .. 4q+3 of a step, every address loop-invariant.  All loads sc1.
 // With C given the sum starts at -C (entries above the diagonal of a `lower` block at 0, never read): the caller stores -acc = C - sum.
-// VERIFY: *bsum receives the sum of the bit patterns of every double of the B operand as it landed in LDS (per thread; the caller adds them up)
-template <bool VERIFY = false>
+// VERIFY: *bsum (*asum, if given) receives the sum of the bit patterns of every double of the B (A) operand as it landed in LDS (per thread; the caller adds them up)
+// KEEP: acc goes on from where the last product left it (nothing zeroed, C not read)
+template <bool VERIFY = false, bool KEEP = false>
 __device__ __forceinline__ void product(double4_t (&acc)[4][2], const double *Aop, const long lda, const double *Bop, const long ldb,
                                         const int nk, double *smem, const double *C = nullptr, const long ldc = 0, const bool lower = false,
-                                        unsigned long long *bsum = nullptr) {
+                                        unsigned long long *bsum = nullptr, unsigned long long *asum = nullptr, const int *ybase = nullptr) {
     typedef __attribute__((address_space(3))) void lds_void;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));                  // opaque: the addressing of one product is not kept alive across the others
@@ -170,11 +175,13 @@ __device__ __forceinline__ void product(double4_t (&acc)[4][2], const double *Ao
     const int c0 = (2 * q) ^ swz(r);
     const int fa0 = (wm * 64 + r) * 16 + 2 * c0, fa1 = (wm * 64 + r) * 16 + 2 * (c0 ^ 1);
     const int fb0 = IMGD + (wn * 32 + r) * 16 + 2 * c0, fb1 = IMGD + (wn * 32 + r) * 16 + 2 * (c0 ^ 1);
+    if constexpr (!KEEP) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    if (C) {
+    }
+    if (!KEEP && C) {
         const double *cb = C + (long)(wm * 64 + q) * ldc + wn * 32 + r;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -200,13 +207,21 @@ __device__ __forceinline__ void product(double4_t (&acc)[4][2], const double *Ao
         }
     };
     int soff = 0;
+    // ybase: this product is not what the panel's next leaf waits for -- like the trailing update (gemm.hip, YIELD) every wave reads its
+    // compute unit's yield counter once per K step with a scalar load and sleeps while a leaf, or the solve the next leaf waits for, runs
+    // on this compute unit (two workgroups of this kernel share one; beside sixteen MFMA waves a leaf takes 45 us instead of 24)
+    const int *yp = ybase ? cu_yield_slot(const_cast<int *>(ybase)) : nullptr;
+    int ybudget = 64;
     auto kstep = [&](auto curc, const bool more) {
         constexpr int CUR = decltype(curc)::value;
         if (more) { soff += 128; dma(std::integral_constant<int, CUR ^ 1>{}, soff); }
         const double *ps = &smem[CUR * 2 * IMGD];
+        int yv = 0;
+        if (yp) asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(yv) : "s"(yp));
         if constexpr (VERIFY) {           // this step's B image, 2048 doubles: four per thread (a sum does not mind the swizzle)
             const unsigned long long *pb = reinterpret_cast<const unsigned long long *>(ps + IMGD) + 4 * tid;
             *bsum += (pb[0] + pb[1]) + (pb[2] + pb[3]);
+            if (asum) { const unsigned long long *pa = reinterpret_cast<const unsigned long long *>(ps) + 4 * tid; *asum += (pa[0] + pa[1]) + (pa[2] + pa[3]); }
         }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -222,6 +237,14 @@ __device__ __forceinline__ void product(double4_t (&acc)[4][2], const double *Ao
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i][s], b2[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (yp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(yv) :: "memory");
+            while (yv != 0 && ybudget > 0) {
+                --ybudget;
+                __builtin_amdgcn_s_sleep(127);
+                asm volatile("s_load_dword %0, %1, 0x0 glc\n s_waitcnt lgkmcnt(0)" : "=s"(yv) : "s"(yp) : "memory");
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next step's image has landed
         __syncthreads();
@@ -381,13 +404,8 @@ __device__ __forceinline__ void trsm_sub(double4_t (&xt)[8], double *Ablk, const
     }
 }
 
-// D -= X X^T for the 128 x 128 diagonal block D (lower triangle) with X still in the registers trsm_sub left it in, the result
-// written straight into the leaf's packed LDS tiles: the last update of a diagonal block and its factorisation share a
-// workgroup, so the block never goes back to memory in between.  The waves exchange X through LDS in two halves of the k
-// range (a lane's 32 bytes per 16-column tile as it holds them: the accumulator layout of X^T is both MFMA operands of
-// X X^T); the 36 lower 16 x 16 tiles are dealt round-robin to the eight waves.
-// the diagonal block's 16 x 16 tiles this wave will update (diag_fused): 20 eight-byte sc1 loads per lane, all in flight at once and
-// issued before the solved row is published, so that their round trip hides under the publication
+// the 36 lower 16 x 16 tiles of a 128 x 128 diagonal block, dealt round-robin to the eight waves, NEGATED, in the MFMA accumulator
+// layout (syrk_follow adds X X^T to them): 20 eight-byte sc1 loads per lane, all in flight at once
 __device__ __forceinline__ void diag_load(double4_t (&res)[5], const double *D, const long ldd) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     int tid = threadIdx.x;
@@ -412,12 +430,162 @@ __device__ __forceinline__ void diag_load(double4_t (&res)[5], const double *D, 
     }
 }
 
-__device__ __forceinline__ void diag_fused(const ChainArgs &g, const double4_t (&xt)[8], double4_t (&res)[5], double *smem) {
+// A block row of the panel's SQUARE solves its block against L_jj BEHIND the leaf that is still factoring it: the leaf's idle wave
+// sends every finished 16-column tile column of L_jj (and the inverse of its diagonal tile) to memory and raises F_LCOL (leaf_body.h,
+// publish_column); tile column t of the solve, X_t^T = inv(L_tt) (A_t^T - sum_{s<t} L_ts X_s^T) -- trsm_sub's step t -- needs row t of
+// L's tiles and inv(L_tt) only, which are there once column t is flagged.  So the solve runs two tile columns behind the
+// factorisation and is done a few microseconds after the leaf instead of a whole substitution (16 us) after it.  The solved tile
+// columns are flagged one by one in turn (xcol: column t - 1 once the wait for column t's loads has also covered its stores) for
+// the workgroup that keeps this row's diagonal block up to date (syrk_follow).
+// LDS: two buffers of eight tiles for row t of L (+ the tile inverse).  False: the launch is being abandoned.
+// The arithmetic, operation by operation, is trsm_sub's: same bits.
+template <bool VERIFY>
+__device__ __forceinline__ bool follow(const ChainArgs &g, double4_t (&xt)[8], double *Ablk, const long lda, const double *L, const long ldl,
+                                       const double *dinv, const unsigned long long col_need0, unsigned long long *xcol, double *smem, int *s_ok,
+                                       unsigned long long *lsum) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void lds_void;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // tile coordinates live in scalar registers
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(Ablk + (long)wave_u * 16 * lda)), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t l_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(L)), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(dinv)), 0, 0xffffffff, 0x00020000);
+    const int vo = (int)(((long)r * lda + 4 * q) * 8);
+    const int pr = 4 * (r & 3) + (r >> 2);           // the row of a 16 x 16 tile this lane supplies as MFMA row r
+    unsigned long long seen = 0ull;                  // thread 0: the column flag as last read
+    [[maybe_unused]] unsigned long long vs = 0ull;
+    // row t of L's tiles, (t, 0) .. (t, t-1), and inv(L_tt) -> buffer t & 1, tiles 0 .. t: 2 t + 2 half-tiles of 1 KB, one LDS-DMA instruction each
+    auto fetch = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        double *buf = smem + (t & 1) * 8 * TSZ;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int hx = wave_u + 8 * it;
+            if (hx < 2 * t + 2) {
+                const int sx = hx >> 1, u = hx & 1;
+                const int a = 8 * u + (lane >> 3);
+                const int piece = (lane & 7) ^ ((a >> 1) & 7);
+                lds_void *dst = (lds_void *)&buf[sx * TSZ + 8 * u * 16];
+                if (sx < t) __builtin_amdgcn_raw_ptr_buffer_load_lds(l_src, dst, 16, (int)(((long)(16 * t + a) * ldl + 16 * sx + 2 * piece) * 8), 0, 0, 16);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(d_src, dst, 16, (t * 256 + a * 16 + 2 * piece) * 8, 0, 0, 16);
+            }
+        }
+    };
+    // navail: tile columns of L known to be flagged (thread 0's last poll); ahead: this column's tiles were requested a column ago (the
+    // solver is catching up with a leaf that is ahead of it: the round trip of the loads hides under the column before)
+    int navail = 0;
+    bool ahead = false;
+    auto column = [&](auto tc) -> bool {
+        constexpr int t = decltype(tc)::value;
+        double *buf = smem + (t & 1) * 8 * TSZ;
+        if (!ahead) {
+            if (tid == 0) {
+                int ok = 1;
+                const unsigned long long need = col_need0 + t + 1;
+                if ((long long)(seen - need) < 0) {
+                    const unsigned long long *p = g.flags + (long)F_LCOL * FL;
+                    int it = 0;
+                    unsigned long long t0 = 0;
+                    while ((long long)((seen = flag_load(p)) - need) < 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if ((++it & 255) == 0) {
+                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+                            if (t0 == 0) t0 = now;
+                            if (now - t0 > 300000000ull || flag_load(g.flags + F_ABORT * FL) == g.tag0) {
+                                flag_store(g.flags + F_ABORT * FL, g.tag0);
+                                atomicCAS(g.info, 0, 0x7fffffff);
+                                ok = 0;
+                                break;
+                            }
+                        }
+                    }
+                }
+                const unsigned long long have = seen - col_need0;
+                s_ok[0] = ok ? (have > 8ull ? 8 : (int)have) : -1;
+            }
+            __syncthreads();                     // (also: nobody reads buffer t & 1 of two columns ago any more)
+            navail = s_ok[0];
+            if (navail < 0) return false;
+            fetch(tc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this column's tiles have landed -- and the last column's solved tile has left
+            __syncthreads();
+            if (t > 0 && tid == 0) flag_store(xcol, col_need0 + t);
+        } else {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the tiles asked for a column ago have landed (behind them: the two stores of the last solved tile)
+            __syncthreads();
+            if (t > 1 && tid == 0) flag_store(xcol, col_need0 + t - 1);
+        }
+        ahead = false;
+        if constexpr (t < 7) {
+            if (navail >= t + 2) { fetch(std::integral_constant<int, t + 1>{}); ahead = true; }
+        }
+        if constexpr (VERIFY) {
+            const unsigned long long *pt = reinterpret_cast<const unsigned long long *>(buf);
+            for (int e = tid; e < (t + 1) * TSZ; e += 512) vs += pt[e];
+        }
+        {
+            double4_t a0 = xt[t], a1 = {0.0, 0.0, 0.0, 0.0}, a2 = {0.0, 0.0, 0.0, 0.0}, a3 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < t; ++s) {
+                const double *T = &buf[s * TSZ];
+                const double2_t l01 = *reinterpret_cast<const double2_t *>(&T[el(pr, 4 * q)]);
+                const double2_t l23 = *reinterpret_cast<const double2_t *>(&T[el(pr, 4 * q + 2)]);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l01[0], xt[s][0], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l01[1], xt[s][1], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l23[0], xt[s][2], a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(-l23[1], xt[s][3], a3, 0, 0, 0);
+            }
+            const double4_t rr = (a0 + a1) + (a2 + a3);
+            const double *D = &buf[t * TSZ];
+            const double2_t d01 = *reinterpret_cast<const double2_t *>(&D[el(pr, 4 * q)]);
+            const double2_t d23 = *reinterpret_cast<const double2_t *>(&D[el(pr, 4 * q + 2)]);
+            double4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(d01[0], rr[0], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(d01[1], rr[1], x1, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(d23[0], rr[2], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(d23[1], rr[3], x1, 0, 0, 0);
+            xt[t] = x0 + x1;
+        }
+        {   // (no scalar offset on a 16-byte store: see trsm_sub)
+            u32x4 lo, hi;
+            const double2_t d0 = {xt[t][0], xt[t][1]}, d1 = {xt[t][2], xt[t][3]};
+            __builtin_memcpy(&lo, &d0, 16); __builtin_memcpy(&hi, &d1, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(lo, a_src, vo + t * 128, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(hi, a_src, vo + t * 128 + 16, 0, 16);
+        }
+        return true;
+    };
+    if (!column(std::integral_constant<int, 0>{})) return false;
+    if (!column(std::integral_constant<int, 1>{})) return false;
+    if (!column(std::integral_constant<int, 2>{})) return false;
+    if (!column(std::integral_constant<int, 3>{})) return false;
+    if (!column(std::integral_constant<int, 4>{})) return false;
+    if (!column(std::integral_constant<int, 5>{})) return false;
+    if (!column(std::integral_constant<int, 6>{})) return false;
+    if (!column(std::integral_constant<int, 7>{})) return false;
+    if constexpr (VERIFY) *lsum = vs;
+    return true;
+}
+
+// The workgroup that will factor diagonal block `row` keeps that block in registers for the whole launch (`res`: its 36 lower
+// 16 x 16 tiles dealt round-robin to the eight waves, negated, as diag_load leaves them) and subtracts X X^T for every solved block
+// X = L[row, j] of its block row as the solver produces it, one tile column (K = 16) at a time behind the solver's column flags:
+// the 128 x 16 tile column comes in by LDS-DMA as eight packed tiles (two buffers), each wave reads both operands of its tiles from
+// there -- the accumulator layout of X^T is both MFMA operands of X X^T.  False: the launch is being abandoned.
+// VERIFY: *xsum receives this thread's share of the sum of the bit patterns of the block as it arrived.
+template <bool VERIFY>
+__device__ __forceinline__ bool syrk_follow(const ChainArgs &g, double4_t (&res)[5], const double *X, const long ldx, const unsigned long long col_need0,
+                                            const unsigned long long *xcol, double *smem, int *s_ok, unsigned long long *xsum) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(uniform_ptr(X)), 0, 0xffffffff, 0x00020000);
     int ta[5], tb[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -426,42 +594,90 @@ __device__ __forceinline__ void diag_fused(const ChainArgs &g, const double4_t (
         while ((a + 1) * (a + 2) / 2 <= p) ++a;
         ta[i] = a; tb[i] = p - a * (a + 1) / 2;
     }
-    double2_t *XS = reinterpret_cast<double2_t *>(smem);          // [wave][t' < 4][half of the lane's 32 bytes][lane]
+    // this lane's share of a tile column: wave w lands tile w (rows 16 w ..), half u: row 8 u + (lane >> 3), its eight 16-byte pieces swizzled as in el()
+    int voff[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();                                          // the L tiles of the solve / the first half are no longer read
+    for (int u = 0; u < 2; ++u) {
+        const int a = 8 * u + (lane >> 3);
+        const int piece = (lane & 7) ^ ((a >> 1) & 7);
+        voff[u] = (int)(((long)(16 * wave_u + a) * ldx + 2 * piece) * 8);
+    }
+    const int o0 = el(r, 4 * q), o1 = el(r, 4 * q + 2);
+    unsigned long long seen = 0ull;
+    [[maybe_unused]] unsigned long long vs = 0ull;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            XS[((wave_u * 4 + t) * 2 + 0) * 64 + lane] = (double2_t){xt[4 * h + t][0], xt[4 * h + t][1]};
-            XS[((wave_u * 4 + t) * 2 + 1) * 64 + lane] = (double2_t){xt[4 * h + t][2], xt[4 * h + t][3]};
+    for (int t = 0; t < 8; ++t) {
+        if (tid == 0) {
+            int ok = 1;
+            const unsigned long long need = col_need0 + t + 1;
+            if ((long long)(seen - need) < 0) {
+                int it = 0;
+                unsigned long long t0 = 0;
+                while ((long long)((seen = flag_load(xcol)) - need) < 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((++it & 255) == 0) {
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+                        if (t0 == 0) t0 = now;
+                        if (now - t0 > 300000000ull || flag_load(g.flags + F_ABORT * FL) == g.tag0) {
+                            flag_store(g.flags + F_ABORT * FL, g.tag0);
+                            atomicCAS(g.info, 0, 0x7fffffff);
+                            ok = 0;
+                            break;
+                        }
+                    }
+                }
+            }
+            *s_ok = ok;
         }
+        __syncthreads();                         // (also: nobody reads buffer t & 1 of two columns ago any more)
+        if (*s_ok == 0) return false;
+        double *buf = smem + (t & 1) * 8 * TSZ;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_src, (lds_void *)&buf[wave_u * TSZ + 8 * u * 16], 16, voff[u], t * 128, 0, 16);      // (the column's byte offset as the scalar offset: an instruction offset would move the LDS address too)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        chain_stamp(g, 10 + h, 0, 0, 0);
+        if constexpr (VERIFY) {
+            const unsigned long long *pt = reinterpret_cast<const unsigned long long *>(buf);
+            vs += (pt[tid] + pt[tid + 512]) + (pt[tid + 1024] + pt[tid + 1536]);
+        }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             if (wave_u + 8 * i < NT) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const double2_t a01 = XS[((ta[i] * 4 + t) * 2 + 0) * 64 + lane], a23 = XS[((ta[i] * 4 + t) * 2 + 1) * 64 + lane];
-                    const double2_t b01 = XS[((tb[i] * 4 + t) * 2 + 0) * 64 + lane], b23 = XS[((tb[i] * 4 + t) * 2 + 1) * 64 + lane];
-                    res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b01[0], res[i], 0, 0, 0);
-                    res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b01[1], res[i], 0, 0, 0);
-                    res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b23[0], res[i], 0, 0, 0);
-                    res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b23[1], res[i], 0, 0, 0);
-                }
+                const double *Ta = &buf[ta[i] * TSZ], *Tb = &buf[tb[i] * TSZ];
+                const double2_t a01 = *reinterpret_cast<const double2_t *>(&Ta[o0]), a23 = *reinterpret_cast<const double2_t *>(&Ta[o1]);
+                const double2_t b01 = *reinterpret_cast<const double2_t *>(&Tb[o0]), b23 = *reinterpret_cast<const double2_t *>(&Tb[o1]);
+                res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b01[0], res[i], 0, 0, 0);
+                res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b01[1], res[i], 0, 0, 0);
+                res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b23[0], res[i], 0, 0, 0);
+                res[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b23[1], res[i], 0, 0, 0);
             }
         }
     }
-    chain_stamp(g, 12, 0, 0, 0);
-    __syncthreads();                                              // everybody has read the exchange buffer: the tiles may land
+    if constexpr (VERIFY) *xsum = vs;
+    return true;
+}
+
+// `res` (syrk_follow) -> the leaf's packed LDS tiles: the last update of a diagonal block and its factorisation share a workgroup,
+// the block never goes back to memory in between
+__device__ __forceinline__ void diag_to_tiles(const double4_t (&res)[5], double *smem) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __syncthreads();                                              // everybody has read the tile columns: D's tiles may land
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        if (wave_u + 8 * i < NT) {
-            double *T = &smem[tix(ta[i], tb[i])];
+        const int p = wave_u + 8 * i;
+        if (p < NT) {
+            int a = 0;
+            while ((a + 1) * (a + 2) / 2 <= p) ++a;
+            const int b = p - a * (a + 1) / 2;
+            double *T = &smem[tix(a, b)];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int ii = q + 4 * v;
-                T[el(ii, r)] = (ta[i] == tb[i] && r > ii) ? 0.0 : -res[i][v];
+                T[el(ii, r)] = (a == b && r > ii) ? 0.0 : -res[i][v];
             }
         }
     }
@@ -482,62 +698,124 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
     chain_stamp(g, 0, t, 0, 0);
     double4_t acc[4][2];
 
-    if (t < n) {
-        // ---- block row t of the panel's square, right-looking, then the leaf of its own diagonal block (no loop around the
-        //      leaf: inside one the compiler keeps so much alive across it that it spills hundreds of registers) ----
-        const int row = t;
+    // tickets of the first n2 block rows, block column after block column: (0,0), (1,0), .. (n2-1,0), (1,1), (2,1), ..  A diagonal block
+    // waits for the blocks left of it in its row, a block (row, k) for blocks of the columns before k and for leaf k: always a lower ticket
+    const int n2 = g.n2;
+    const int nsq = n * n2 - n * (n - 1) / 2;
+    int bk = 0, brow = 0;
+    if (t < nsq) {
+        int off = 0;
+        while (t >= off + (n2 - bk)) { off += n2 - bk; ++bk; }
+        brow = bk + (t - off);
+    }
+    if (t < nsq && brow != bk) {
+        // ---- block (row, k) of the panel below the diagonal: A[row,k] - sum_{j<k} L[row,j] L[k,j]^T, one K = 128 product per
+        //      block column j as soon as both operands are published (the sum stays in registers), then the solve against L_kk
+        //      BEHIND leaf k (follow), then publication as row_done[row] = k + 1 ----
+        const int row = brow, k = bk;
         double *Ar = g.A + (long)row * 128 * g.lda;
-        int *yslot = nullptr;                      // on the critical path: the co-resident trailing-update workgroup sleeps meanwhile
-        if (row > 0 && g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
-        __builtin_amdgcn_s_setprio(2);
-        double4_t xt[8];
-        for (int j = 0; j < row; ++j) {
-            trsm_load(xt, Ar + j * 128, g.lda);
-            if (!chain_wait(g, F_LEAF, tag + j + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
-            chain_stamp(g, 3, t, row, j);
-            if constexpr (!VERIFY) trsm_sub<true>(xt, Ar + j * 128, g.lda, g.A + (long)j * 128 * g.lda + j * 128, g.lda, g.linv + (long)j * LEAF_DOUBLES, smem);
-            else {
-                unsigned long long vs = 0ull;
-                trsm_sub<true, true>(xt, Ar + j * 128, g.lda, g.A + (long)j * 128 * g.lda + j * 128, g.lda, g.linv + (long)j * LEAF_DOUBLES, smem, &vs);
-                // what arrived of leaf j against what leaf j said it stored; then this row's own payload for step j: the solved
-                // block as the registers hold it (exactly the bytes trsm_sub has just stored), published before row_done
-                verify_compare(g, wg_sum(vs, &s_acc), flag_load(g.vhash + VH_LEAF + j));
-                unsigned long long mine = 0ull;
-#pragma unroll
-                for (int tt = 0; tt < 8; ++tt) mine += (bits_of(xt[tt][0]) + bits_of(xt[tt][1])) + (bits_of(xt[tt][2]) + bits_of(xt[tt][3]));
-                mine = wg_sum(mine, &s_acc);
-                if (tid == 0) flag_store(g.vhash + VH_ROW + row * 32 + j, mine);
-            }
-            if (j + 1 == row) {                    // the step the next leaf waits for: its diagonal block straight into the leaf's tiles
-                double4_t res[5];
-                diag_load(res, Ar + row * 128, g.lda);
-                chain_publish(g, F_ROW + row, tag + j + 1);
-                chain_stamp(g, 4, t, row, j);
-                diag_fused(g, xt, res, smem);
-                chain_stamp(g, 5, t, row, j);
-                break;
-            }
-            chain_publish(g, F_ROW + row, tag + j + 1);
-            chain_stamp(g, 4, t, row, j);
-            for (int k = j + 1; k <= row; ++k) {
-                if (k < row && !chain_wait(g, F_ROW + k, tag + j + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
-                if constexpr (!VERIFY) product(acc, Ar + j * 128, g.lda, g.A + (long)k * 128 * g.lda + j * 128, g.lda, 8, smem, Ar + k * 128, g.lda, k == row);
-                else {
-                    unsigned long long bs = 0ull;
-                    product<true>(acc, Ar + j * 128, g.lda, g.A + (long)k * 128 * g.lda + j * 128, g.lda, 8, smem, Ar + k * 128, g.lda, k == row, &bs);
-                    bs = wg_sum(bs, &s_acc);
-                    if (k < row) verify_compare(g, bs, flag_load(g.vhash + VH_ROW + k * 32 + j));
+        const double *Ak = g.A + (long)k * 128 * g.lda;
+        unsigned long long *xcol = g.flags + (long)(row < n ? F_XCOL + row : F_DUMMY) * FL;      // (only a row of the square has a diagonal block behind it)
+        int *yslot = nullptr;
+        // (the block the next leaf waits for goes first wherever it shares a SIMD: two workgroups of this kernel fit a compute unit, and in a
+        // wide panel every compute unit has two)
+        if (row == k + 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
+        // (a row below the square: its part of the trailing update may still be running beside this launch)
+        if (row >= n && g.cols_tag && !chain_wait(g, F_COLS, g.cols_tag, &s_i[1])) return;
+        if (k > 0) {
+            for (int j = 0; j < k; ++j) {
+                if (!chain_wait(g, F_ROW + row, tag + j + 1, &s_i[1], row != k + 1) || !chain_wait(g, F_ROW + k, tag + j + 1, &s_i[1], row != k + 1)) { if (yslot) atomicAdd(yslot, -1); return; }
+                unsigned long long bs = 0ull, as = 0ull;
+                // the LAST product of a block is what its solve behind leaf k waits for (and with it, one way or another, every later
+                // leaf): from here on this workgroup raises its compute unit's yield counter; the earlier products have whole steps to
+                // spare and sleep wherever a workgroup in that state -- or a leaf -- shares their compute unit.  (Every block right of
+                // column j starts its product j the moment column j is published: hundreds at a time, two per compute unit, and
+                // without this the thirty that matter took 29 us instead of 14.)
+                const bool last = j == k - 1;
+                if (last) {
+                    if (g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
+                    __builtin_amdgcn_s_setprio(row == k + 1 ? 3 : 2);
                 }
-                epilogue<true, true>(acc, Ar + k * 128, g.lda, k == row);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                const int *yb = last ? nullptr : g.yield;
+                if (j == 0) product<VERIFY, false>(acc, Ar, g.lda, Ak, g.lda, 8, smem, Ar + k * 128, g.lda, false, &bs, &as, yb);
+                else product<VERIFY, true>(acc, Ar + j * 128, g.lda, Ak + j * 128, g.lda, 8, smem, nullptr, 0, false, &bs, &as, yb);
+                if constexpr (VERIFY) {               // both operands were solved and stored by other workgroups
+                    verify_compare(g, wg_sum(bs, &s_acc), flag_load(g.vhash + VH_ROW + k * 32 + j));
+                    verify_compare(g, wg_sum(as, &s_acc), flag_load(g.vhash + VH_ROW + row * 32 + j));
+                }
             }
+            epilogue<true, true>(acc, Ar + k * 128, g.lda);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
+        chain_stamp(g, 10, t, row, k);
+        if (k == 0) {                              // (no products: the solve behind leaf 0 starts here)
+            if (g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
+            __builtin_amdgcn_s_setprio(row == k + 1 ? 3 : 2);
+        }
+        double4_t xt[8];
+        trsm_load(xt, Ar + k * 128, g.lda);
+        unsigned long long vs = 0ull;
+        if (!follow<VERIFY>(g, xt, Ar + k * 128, g.lda, Ak + k * 128, g.lda, g.linv + (long)k * LEAF_DOUBLES, tag + 8ull * k, xcol, smem, &s_i[1], &vs)) {
+            if (yslot) atomicAdd(yslot, -1);
+            return;
+        }
+        chain_stamp(g, 3, t, row, k);
+        if constexpr (VERIFY) {
+            // what arrived of leaf k against what leaf k said it stored (its sum is published with the whole block); then this block's
+            // own payload: the solved block as the registers hold it (exactly the bytes stored), published before row_done
+            if (!chain_wait(g, F_LEAF, tag + k + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
+            verify_compare(g, wg_sum(vs, &s_acc), flag_load(g.vhash + VH_LEAF + k));
+            unsigned long long mine = 0ull;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) mine += (bits_of(xt[tt][0]) + bits_of(xt[tt][1])) + (bits_of(xt[tt][2]) + bits_of(xt[tt][3]));
+            mine = wg_sum(mine, &s_acc);
+            if (tid == 0) flag_store(g.vhash + VH_ROW + row * 32 + k, mine);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            // (the column flag of this row is written by the workgroup of every block of the row in turn: its last value of this block
+            // has arrived before the flag goes up that lets the next block's workgroup start)
+            flag_store(xcol, tag + 8ull * k + 8);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            flag_store(g.flags + (long)(F_ROW + row) * FL, tag + k + 1);
+        }
+        chain_stamp(g, 4, t, row, k);
         if (yslot) atomicAdd(yslot, -1);
+        return;
+    }
+    if (t < nsq) {
+        // ---- diagonal block `row` of the square: D -= L[row,j] L[row,j]^T behind the solver of its row, block after block, the
+        //      block in registers all along (syrk_follow); then its LEAF straight from LDS (no loop around the leaf: inside one the
+        //      compiler keeps so much alive across it that it spills hundreds of registers) ----
+        const int row = brow;
+        double *Ar = g.A + (long)row * 128 * g.lda;
+        __builtin_amdgcn_s_setprio(3);
+        if (row > 0) {
+            const unsigned long long *xcol = g.flags + (long)(F_XCOL + row) * FL;
+            double4_t res[5];
+            diag_load(res, Ar + row * 128, g.lda);
+            int *yslot = nullptr;
+            for (int j = 0; j < row; ++j) {
+                unsigned long long xs = 0ull;
+                // (the last block of the row is the one the leaf waits for: see the solver)
+                if (j == row - 1 && g.yield && g.cols_tag == ~0ull && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }      // (off: it would hold the counter up for a whole step)
+                if (!syrk_follow<VERIFY>(g, res, Ar + j * 128, g.lda, tag + 8ull * j, xcol, smem, &s_i[1], &xs)) { if (yslot) atomicAdd(yslot, -1); return; }
+                if constexpr (VERIFY) {               // the block as it arrived against what its solver said it stored
+                    if (!chain_wait(g, F_ROW + row, tag + j + 1, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
+                    verify_compare(g, wg_sum(xs, &s_acc), flag_load(g.vhash + VH_ROW + row * 32 + j));
+                }
+            }
+            chain_stamp(g, 5, t, row, row - 1);
+            diag_to_tiles(res, smem);
+            if (yslot) atomicAdd(yslot, -1);       // (the leaf raises the counter for itself)
+        }
         chain_stamp(g, 1, t, row, row);
         LeafArgs la;
         la.A = g.A; la.lda = g.lda; la.linv = g.linv; la.logdet_part = g.logdet; la.info = g.info; la.info_base = g.info_base;
         la.do_factor = g.leaf_factor; la.a_stride = 0; la.linv_stride = 0; la.stamps = g.leaf_stamps; la.tiles_only = g.leaf_tiles; la.yield = g.yield; la.preloaded = row > 0 ? g.leaf_preloaded : 0;
+        la.col_flag = g.flags + (long)F_LCOL * FL; la.col_base = tag + 8ull * row;
         const int nv = g.nvalid - 128 * row;
         la.nvalid = nv >= 128 ? 128 : (nv > 0 ? nv : 0);
         if constexpr (!VERIFY) leaf_body<true>(la, Ar + row * 128, g.linv + (long)row * LEAF_DOUBLES, g.logdet + row * 128, g.info_base + 128 * row,
@@ -549,29 +827,35 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
             ls = wg_sum(ls, &s_acc);
             if (tid == 0) flag_store(g.vhash + VH_LEAF + row, ls);
         }
-        chain_publish(g, F_LEAF, tag + row + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {                            // the last two tile columns went out with the block (the column flag's last value of this block first: the next leaf writes it too)
+            flag_store(g.flags + (long)F_LCOL * FL, tag + 8ull * row + 8);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            flag_store(g.flags + (long)F_LEAF * FL, tag + row + 1);
+        }
         chain_stamp(g, 2, t, row, row);
         return;
     }
 
     __builtin_amdgcn_s_setprio(2);
     int *yslot = nullptr;
-    const int stride = (int)gridDim.x - n;
+    const int stride = (int)gridDim.x - nsq;
     double4_t xt[8];
     // (the yield counter goes up AFTER this wait: the update these rows wait for polls that counter on the same compute units)
     if (g.cols_tag && !chain_wait(g, F_COLS, g.cols_tag, &s_i[1])) return;
     if (g.yield_below && g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
-    for (int row = t; row < g.rows; row += stride) {
+    for (int row = n2 + (t - nsq); row < g.rows; row += stride) {
         // ---- a block row below the square, left-looking ----
         double *Ar = g.A + (long)row * 128 * g.lda;
         for (int k = 0; k < n; ++k) {
             if (k > 0) {
                 if (!chain_wait(g, F_ROW + k, tag + k, &s_i[1])) { if (yslot) atomicAdd(yslot, -1); return; }
                 chain_stamp(g, 6, t, row, k);
-                if constexpr (!VERIFY) product(acc, Ar, g.lda, g.A + (long)k * 128 * g.lda, g.lda, 8 * k, smem, Ar + k * 128, g.lda);
+                if constexpr (!VERIFY) product(acc, Ar, g.lda, g.A + (long)k * 128 * g.lda, g.lda, 8 * k, smem, Ar + k * 128, g.lda, false, nullptr, nullptr, g.yield_below ? nullptr : g.yield);
                 else {                            // the B operand is row k's solved blocks of steps 0 .. k-1
                     unsigned long long bs = 0ull;
-                    product<true>(acc, Ar, g.lda, g.A + (long)k * 128 * g.lda, g.lda, 8 * k, smem, Ar + k * 128, g.lda, false, &bs);
+                    product<true>(acc, Ar, g.lda, g.A + (long)k * 128 * g.lda, g.lda, 8 * k, smem, Ar + k * 128, g.lda, false, &bs, nullptr, g.yield_below ? nullptr : g.yield);
                     unsigned long long want = 0ull;
                     if (tid == 0) for (int jj = 0; jj < k; ++jj) want += flag_load(g.vhash + VH_ROW + k * 32 + jj);
                     verify_compare(g, wg_sum(bs, &s_acc), want);
@@ -628,11 +912,11 @@ int chain_streams_concurrent(fvgp_handle *h) {
     h->streams_concurrent = 0;
     if (fvgp_ensure_side(h)) return 0;
     if (!h->chain_flags) {
-        if (hipMalloc((void **)&h->chain_flags, 80 * 16 * sizeof(unsigned long long)) != hipSuccess) return 0;
-        if (hipMemset(h->chain_flags, 0, 80 * 16 * sizeof(unsigned long long)) != hipSuccess) return 0;
+        if (hipMalloc((void **)&h->chain_flags, (size_t)FLAG_LINES * FL * sizeof(unsigned long long)) != hipSuccess) return 0;
+        if (hipMemset(h->chain_flags, 0, (size_t)FLAG_LINES * FL * sizeof(unsigned long long)) != hipSuccess) return 0;
         h->chain_tag = 0; h->chain_tick = 0;
     }
-    h->chain_tag += 64;
+    h->chain_tag += 512;
     int *seen = h->dinfo + 2;
     unsigned long long *flag = h->chain_flags + F_COLS * FL;
     hipEvent_t e0 = nullptr;
@@ -664,8 +948,8 @@ int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, i
     if (w <= 0 || w % TILE || J0 % TILE || np % TILE || Jend > np || w / TILE > FVGP_CHAIN_MAX_BLOCKS) { fvgp_set_error("panel chain: bad panel"); return -5; }
     if (lda >= (1L << 21) || (lda & 1) || ((uintptr_t)A & 15)) { fvgp_set_error("panel chain: leading dimension / alignment"); return -4; }
     if (!h->chain_flags) {
-        HIPCHK(hipMalloc((void **)&h->chain_flags, 80 * 16 * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(h->chain_flags, 0, 80 * 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void **)&h->chain_flags, (size_t)FLAG_LINES * FL * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(h->chain_flags, 0, (size_t)FLAG_LINES * FL * sizeof(unsigned long long)));
         h->chain_tag = 0; h->chain_tick = 0;
     }
     ChainArgs g;
@@ -674,14 +958,25 @@ int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, i
     g.linv = h->linv + (J0 / TILE) * LEAF_DOUBLES; g.logdet = h->logdet_parts + J0;
     g.info = h->dinfo; g.info_base = (int)J0;
     g.flags = h->chain_flags;
-    h->chain_tag += 64;
+    h->chain_tag += 512;                  // (a launch uses tag + 1 .. tag + 8 n <= tag + 256 for its flags)
     g.tag0 = h->chain_tag; g.tick0 = h->chain_tick;
     g.cols_tag = cols_tag_out ? h->chain_tag : 0;
     if (cols_tag_out) *cols_tag_out = h->chain_tag;
     g.yield = h->leaf_yield ? h->cu_yield : nullptr;
     g.stamps = h->chain_stamps; g.seq = h->chain_seq++; g.leaf_stamps = h->leaf_stamps; g.leaf_factor = 1; g.leaf_tiles = 1; g.leaf_preloaded = 1; g.yield_below = h->chain_yield >= 2;
-    int grid = g.rows < 480 ? g.rows : 480;       // one block row per ticket (the first n: the square), the rows below dealt round-robin beyond 480
-    if (grid < g.n) grid = g.n;
+    // one ticket per block of the first n2 block rows (the square, and as many rows below it as keep that under ~480 workgroups: short
+    // panels have a workgroup per block), then one per block row (dealt round-robin beyond 480 workgroups in all, at least 128 of these)
+    // (beside a trailing update every resident workgroup holds a slot of the update: only the square -- the critical path -- has a
+    // workgroup per block there, most of which wait most of the time; alone on the chip waiting costs nothing)
+    int n2 = h->chain_alone ? g.rows : g.n;
+    if (n2 > g.rows) n2 = g.rows;
+    if (n2 > VH_ROWS) n2 = VH_ROWS;
+    g.n2 = n2;
+    const int nsq = g.n * n2 - g.n * (g.n - 1) / 2;
+    int below = g.rows - n2;
+    const int room = 480 - nsq > 128 ? 480 - nsq : 128;
+    if (below > room) below = room;
+    const int grid = nsq + below;
     h->chain_tick += (unsigned long long)grid;
     g.vhash = nullptr;
     if (h->chain_verify) {

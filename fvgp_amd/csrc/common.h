@@ -99,11 +99,15 @@ struct fvgp_handle {
     // the column ticket; option "bwd_sweep"
     double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1, fwd_sweep = 1;
     // the panel chain as one resident kernel per panel (chain.hip): flag words, the launch tag and ticket bases; option "panel_chain"
-    unsigned long long *chain_flags = nullptr, chain_tag = 0, chain_tick = 0; int panel_chain = 1; int streams_concurrent = -1;   // -1: not probed yet (chain.hip, chain_streams_concurrent)
+    unsigned long long *chain_flags = nullptr, chain_tag = 0, chain_tick = 0; int panel_chain = 1; int chain_alone = 1; int chain_wide = 1; int streams_concurrent = -1;   // -1: not probed yet (chain.hip, chain_streams_concurrent)
     int chain_verify = 0; unsigned long long *chain_vhash = nullptr;   // option "chain_verify": payload checksums on every hand-off of the resident panel kernel (chain.hip, VH_*)
     int cols_split = 1; int64_t cols_split_rows = 8192;   // (potrf_driver: the next panel's square is updated first, the rows below it beside its chain, while at most this many rows remain)
     int64_t panel_chain_min = 4096;   // ... for panels with at least this many rows from their first column down (below that the chain runs alone on the chip and the three launches per step are as fast)
-    int64_t lookahead_min = 4608;     // look-ahead from this many (padded) rows on (a stream switch costs ~12 us: N=4000 +5 % with it, N=4800 -2.5 %, N=6000 -5 %)
+    // look-ahead (the next panel factored on a second stream beside the trailing update) from this many (padded) rows on.  Off by default
+    // since the resident panel kernel has a workgroup per block (chain.hip): 4096-wide panels factored ALONE on the whole chip, each
+    // followed by one K = 4096 update with nothing beside it, beat look-ahead at every size measured (N=2000 0.95 -> 0.75 ms,
+    // 8000 5.7 -> 5.1, 20000 46.9 -> 45.6, 50000 620 -> 595 on the same box); `lookahead_min` = 4608 restores the old schedule
+    int64_t lookahead_min = (int64_t)1 << 40;
     int posterior_halves = 1;         // posterior covariance at >= 512 points: two halves of the points side by side on two streams (api.hip)
     int64_t outer_block_small = 512, small_threshold = 12288;   // panel width for the last `small_threshold` rows (potrf_driver)
     int lookahead = 1;

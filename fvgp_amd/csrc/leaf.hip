@@ -43,7 +43,7 @@ __global__ __launch_bounds__(512, 4) void leaf_kernel(LeafArgs g) {
 int launch_leaf(fvgp_handle *h, double *A, int64_t lda, double *linv, double *logdet_part, int info_base, int do_factor, int nvalid,
                 int tiles_only) {
     LeafArgs g;
-    g.tiles_only = tiles_only; g.preloaded = 0;
+    g.tiles_only = tiles_only; g.preloaded = 0; g.col_flag = nullptr; g.col_base = 0;
     g.A = A; g.lda = lda; g.linv = linv; g.logdet_part = logdet_part; g.info = h->dinfo; g.info_base = info_base;
     g.do_factor = do_factor; g.a_stride = 0; g.linv_stride = 0; g.nvalid = nvalid; g.stamps = h->leaf_stamps;
     g.yield = (h->leaf_yield && do_factor) ? h->cu_yield : nullptr;
@@ -56,7 +56,7 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
     if (nblk <= 0) return 0;
     LeafArgs g;
     g.A = const_cast<double *>(L); g.lda = ldl; g.linv = linv; g.logdet_part = nullptr; g.info = h->dinfo; g.info_base = 0;
-    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr; g.tiles_only = 0; g.yield = nullptr; g.preloaded = 0;
+    g.do_factor = 0; g.a_stride = 128 * ldl + 128; g.linv_stride = LEAF_DOUBLES; g.nvalid = 128; g.stamps = nullptr; g.tiles_only = 0; g.yield = nullptr; g.preloaded = 0; g.col_flag = nullptr; g.col_base = 0;
     hipLaunchKernelGGL(leaf_kernel, dim3((unsigned)nblk), dim3(512), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;

@@ -27,6 +27,8 @@ struct LeafArgs {
     int tiles_only;               // linv <- the inverses of the eight 16x16 diagonal tiles only (8 x 256 doubles, lower, zeros above)
     int preloaded;                // chain.hip: the block already sits in the packed LDS tiles (the load phase is skipped)
     int *yield;                   // per-CU counters the trailing update's waves poll (common.h, cu_yield); nullptr: nobody yields
+    unsigned long long *col_flag; // chain.hip: raised to col_base + c + 1 once the 16-column tile column c of L and the inverse of its diagonal
+    unsigned long long col_base;  //            tile are in memory (the block rows of the panel's square solve BEHIND the running leaf); may be null
 };
 
 __device__ __forceinline__ double4_t mfma(double a, double b, double4_t c) {
@@ -365,9 +367,33 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
         for (int b = 0; b < 4; ++b) {
             const int a = 4 * b + q;
             if (a > r) Tt[el(r, a)] = xinv[b];
-            if (g.tiles_only) {
-                st_linv<CHAIN>(&linv[t * 256 + a * 16 + r], xinv[b]);
-                if constexpr (VERIFY) vs_inv += (unsigned long long)__double_as_longlong(xinv[b]);
+            if constexpr (!CHAIN) { if (g.tiles_only) linv[t * 256 + a * 16 + r] = xinv[b]; }      // (CHAIN: publish_column, below)
+        }
+    };
+    // CHAIN: wave 4 -- idle in the factor loop -- sends a FINISHED tile column c to memory, a step behind the waves that produce it: the
+    // tiles (c, c) .. (7, c) of L and the inverse of the diagonal tile as tile_inverse left it in LDS (below the diagonal transposed in
+    // the tile's strict upper half, the diagonal in srd), all write-through; when they have left it raises the column flag.  One wave:
+    // its own s_waitcnt covers every store, no barrier.  The workgroups that solve against this block (chain.hip, follow) start on
+    // column c while the factorisation is at column c + 2.
+    [[maybe_unused]] auto publish_column = [&](const int c, const bool raise) {
+        if constexpr (CHAIN) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            for (int i = c; i < 8; ++i) store_tile(i, c);
+            const double *Tt = &sT[tix(c, c)];
+            const __amdgpu_buffer_rsrc_t l_src = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr_rw(linv), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int a = 8 * u + (lane >> 3), cc = 2 * (lane & 7);
+                const double up0 = Tt[el(cc, a)], up1 = Tt[el(cc + 1, a)], dg = srd[16 * c + a];
+                const double2_t pr = {a > cc ? up0 : (a == cc ? dg : 0.0), a > cc + 1 ? up1 : (a == cc + 1 ? dg : 0.0)};
+                if constexpr (VERIFY) vs_inv += (unsigned long long)__double_as_longlong(pr[0]) + (unsigned long long)__double_as_longlong(pr[1]);
+                u32x4 raw;
+                __builtin_memcpy(&raw, &pr, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(raw, l_src, (c * 256 + a * 16 + cc) * 8, 0, 16);
+            }
+            if (raise && g.col_flag) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(g.col_flag, g.col_base + (unsigned long long)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
@@ -462,24 +488,28 @@ __device__ __forceinline__ void leaf_body(const LeafArgs &g, double *A, double *
                 }
                 FVGP_WFINE(p, 3);
                 // ---- column p is final: its 8 - p tiles go to global memory while wave 0 factors the next diagonal tile ----
-                for (int i = p + slot; i < 8; i += 6) store_tile(i, p);
+                if constexpr (!CHAIN) for (int i = p + slot; i < 8; i += 6) store_tile(i, p);      // (CHAIN: wave 4, a step later)
                 FVGP_WFINE(p, 4);
                 // ---- and so is the diagonal tile (p, p): its inverse (transposed into its strict upper half, over the 4x4 block
                 //      inverses nobody reads any more; the diagonal is srd) by the wave with the least to do in a step ----
                 if (slot == 5) tile_inverse(p);
                 FVGP_WFINE(p, 5);
+            } else if (CHAIN && p > 0) {
+                publish_column(p - 1, true);
             }
             __syncthreads();
             FVGP_WFINE(p, 6);
             FVGP_STAMP();
         }
-        if (wave == 1) store_tile(7, 7);
+        if constexpr (CHAIN) { if (wave == 4) publish_column(6, true); }
+        else if (wave == 1) store_tile(7, 7);
         // ---- the reciprocal diagonal, for the log-determinant: the logarithms are taken once, by one kernel over all blocks
         //      (neg_log_sum_kernel), not 128 at a time behind a barrier on the chain's critical path (1.4 thousand cycles) ------
         if (logdet_part != nullptr && tid < 128) logdet_part[tid] = tid < g.nvalid ? srd[tid] : 1.0;
         FVGP_STAMP();
         if (wave == 7) tile_inverse(7);
         __syncthreads();
+        if constexpr (CHAIN) { if (wave == 4) publish_column(7, false); }      // (the caller publishes the whole block behind this)
         // the seed of the block-column inverse below (not needed when only the tile inverses go out)
         if (!g.tiles_only) {
             const double *Tw = &sT[tix(wave, wave)];

@@ -24,8 +24,8 @@ s = stamps.cpu().numpy()
 cnt = int(s[0]); e = s[8:8 + 4 * cnt].reshape(cnt, 4)
 seqs = np.unique(e[:, 0])
 print("events", cnt, "launches", len(seqs))
-names = {0: "start", 1: "leaf_begin", 2: "leaf_done", 3: "sq_trsm_begin", 4: "sq_row_pub", 5: "sq_diag_pub", 6: "below_sum_begin", 7: "below_sum_end",
-         8: "below_trsm_begin", 9: "below_trsm_end", 10: "diag_h0_mfma_begin", 11: "diag_h1_mfma_begin", 12: "diag_mfma_end"}
+names = {0: "start", 1: "leaf_begin", 2: "leaf_done", 3: "solver: block solved", 4: "solver: block published", 5: "diagonal block up to date", 6: "below_sum_begin",
+         7: "below_sum_end", 8: "below_trsm_begin", 9: "below_trsm_end", 10: "block: updates done"}
 for q in ([seqs[which]] if which >= 0 else seqs):
     w = e[e[:, 0] == q]
     w = w[np.argsort(w[:, 3])]
@@ -38,5 +38,5 @@ for q in ([seqs[which]] if which >= 0 else seqs):
     for row in w:
         code, packed, t = int(row[1]), int(row[2]), (row[3] - t0) / 100.0
         tk, r, st = packed >> 16, (packed >> 8) & 255, packed & 255
-        if code in (1, 2, 3, 4, 5, 10, 11, 12) or (code in (6, 7, 8, 9) and r == int(w[:, 2].max() >> 8) & 255) or (code == 0 and tk < 12):
+        if code in (1, 2, 3, 4, 5, 10) or (code in (6, 7, 8, 9) and r == int(w[:, 2].max() >> 8) & 255) or (code == 0 and tk < 12):
             print(f"  {t:9.1f} us  ticket {tk:4d} row {r:3d} step {st:2d}  {names[code]}")
