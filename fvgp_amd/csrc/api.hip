@@ -158,6 +158,13 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "panel_chain")) { if (value < 0 || value > 2) return -3; h->panel_chain = (int)value; return 0; }
     if (!strcmp(key, "panel_chain_min")) { h->panel_chain_min = value; return 0; }
     if (!strcmp(key, "chain_wide")) { h->chain_wide = (int)value; return 0; }
+    if (!strcmp(key, "wide_block") || !strcmp(key, "wide_block_big")) {
+        if (value < TILE || value % TILE || value / TILE > FVGP_CHAIN_MAX_BLOCKS) { fvgp_set_error("wide_block: a multiple of 128, at most 4096"); return -2; }
+        (key[10] ? h->wide_block_big : h->wide_block) = value; return 0;
+    }
+    if (!strcmp(key, "wide_threshold")) { h->wide_threshold = value; return 0; }
+    if (!strcmp(key, "wide_inner")) { if (value % TILE) return -2; h->wide_inner = value; return 0; }
+    if (!strcmp(key, "wide_inner_rows")) { h->wide_inner_rows = value; return 0; }
     if (!strcmp(key, "cols_split")) { h->cols_split = value ? 1 : 0; return 0; }
     if (!strcmp(key, "chain_verify")) { h->chain_verify = value ? 1 : 0; return 0; }
     if (!strcmp(key, "cols_split_rows")) { h->cols_split_rows = value; return 0; }
@@ -431,8 +438,21 @@ static int panel_factor_nested(fvgp_handle *h, double *A, int64_t n, int64_t np,
 // trailing update to run beside it, else the three launches per 128 columns
 static int panel_factor_any(fvgp_handle *h, double *A, int64_t n, int64_t np, int64_t lda, int64_t J0, int64_t Jend) {
     // (the resident kernel has flag words for 32 block columns: a wider panel -- `outer_block` above 4096 -- takes the nested chain)
-    if (h->panel_chain && (np - J0 >= h->panel_chain_min || (h->chain_alone && h->chain_wide)) && (Jend - J0) / TILE <= FVGP_CHAIN_MAX_BLOCKS)
+    if (h->panel_chain && (np - J0 >= h->panel_chain_min || (h->chain_alone && h->chain_wide)) && (Jend - J0) / TILE <= FVGP_CHAIN_MAX_BLOCKS) {
+        // a tall panel (alone on the chip): sub-panels of `wide_inner` columns by the resident kernel, the rest of the panel's columns
+        // brought up to date by the trailing update's kernel with K = wide_inner in between -- three quarters of the panel's flops
+        // move from the resident kernel's products (0.7 of the MFMA rate) to that kernel (0.92)
+        const int64_t inner = h->wide_inner;
+        if (h->chain_alone && inner > 0 && Jend - J0 > inner && np - J0 >= h->wide_inner_rows) {
+            for (int64_t s0 = J0; s0 < Jend; s0 += inner) {
+                const int64_t s1 = (s0 + inner < Jend) ? s0 + inner : Jend;
+                int rc = launch_panel_chain(h, A, n, np, lda, s0, s1); if (rc) return rc;
+                if (s1 < Jend) { rc = trailing_update(h, A, np, lda, s0, s1, s1, Jend, 0); if (rc) return rc; }
+            }
+            return 0;
+        }
         return launch_panel_chain(h, A, n, np, lda, J0, Jend);
+    }
     return panel_factor_nested(h, A, n, np, lda, J0, Jend);
 }
 
@@ -495,7 +515,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     std::vector<int64_t> bnd;
     for (int64_t J0 = 0; J0 < np;) {
         bnd.push_back(J0);
-        if (wide) { J0 = (J0 + FVGP_CHAIN_MAX_BLOCKS * TILE < np) ? J0 + FVGP_CHAIN_MAX_BLOCKS * TILE : np; continue; }
+        if (wide) { const int64_t w = np - J0 > h->wide_threshold ? h->wide_block_big : h->wide_block; J0 = (J0 + w < np) ? J0 + w : np; continue; }
         // three widths: `outer_block_big` (2048) while the trailing update hides any chain, NB (1024), and `outer_block_small`
         // (512) for the last `small_threshold` rows, where the chain is what the factorisation waits for: a 512-wide panel's
         // update tiles retire twice as often (K = 512), so the chain's many-workgroup kernels find slots sooner (N=8k -4 %,

@@ -723,26 +723,41 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
         // (a row below the square: its part of the trailing update may still be running beside this launch)
         if (row >= n && g.cols_tag && !chain_wait(g, F_COLS, g.cols_tag, &s_i[1])) return;
         if (k > 0) {
-            for (int j = 0; j < k; ++j) {
+            for (int j = 0; j < k;) {
                 if (!chain_wait(g, F_ROW + row, tag + j + 1, &s_i[1], row != k + 1) || !chain_wait(g, F_ROW + k, tag + j + 1, &s_i[1], row != k + 1)) { if (yslot) atomicAdd(yslot, -1); return; }
-                unsigned long long bs = 0ull, as = 0ull;
+                // every block column already published on both rows goes into ONE product (they are contiguous along K: a workgroup that
+                // starts late -- most do, a tall panel has twenty times more of them than slots -- restarts its K loop once, not per column)
+                if (tid == 0) {
+                    const unsigned long long fa = flag_load(g.flags + (long)(F_ROW + row) * FL) - tag, fb = flag_load(g.flags + (long)(F_ROW + k) * FL) - tag;
+                    unsigned long long m = fa < fb ? fa : fb;
+                    if (m > (unsigned long long)k) m = (unsigned long long)k;
+                    s_i[1] = (int)m;
+                }
+                __syncthreads();
+                int m = s_i[1];
+                __syncthreads();
                 // the LAST product of a block is what its solve behind leaf k waits for (and with it, one way or another, every later
-                // leaf): from here on this workgroup raises its compute unit's yield counter; the earlier products have whole steps to
+                // leaf): from there on this workgroup raises its compute unit's yield counter; the earlier products have whole steps to
                 // spare and sleep wherever a workgroup in that state -- or a leaf -- shares their compute unit.  (Every block right of
                 // column j starts its product j the moment column j is published: hundreds at a time, two per compute unit, and
                 // without this the thirty that matter took 29 us instead of 14.)
-                const bool last = j == k - 1;
+                if (m == k && m - j > 1) m = k - 1;            // (the last block column on its own)
+                const bool last = m == k;
                 if (last) {
                     if (g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
-                    __builtin_amdgcn_s_setprio(row == k + 1 ? 3 : 2);
+                    if (row == k + 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
                 }
                 const int *yb = last ? nullptr : g.yield;
-                if (j == 0) product<VERIFY, false>(acc, Ar, g.lda, Ak, g.lda, 8, smem, Ar + k * 128, g.lda, false, &bs, &as, yb);
-                else product<VERIFY, true>(acc, Ar + j * 128, g.lda, Ak + j * 128, g.lda, 8, smem, nullptr, 0, false, &bs, &as, yb);
+                unsigned long long bs = 0ull, as = 0ull;
+                if (j == 0) product<VERIFY, false>(acc, Ar, g.lda, Ak, g.lda, 8 * m, smem, Ar + k * 128, g.lda, false, &bs, &as, yb);
+                else product<VERIFY, true>(acc, Ar + j * 128, g.lda, Ak + j * 128, g.lda, 8 * (m - j), smem, nullptr, 0, false, &bs, &as, yb);
                 if constexpr (VERIFY) {               // both operands were solved and stored by other workgroups
-                    verify_compare(g, wg_sum(bs, &s_acc), flag_load(g.vhash + VH_ROW + k * 32 + j));
-                    verify_compare(g, wg_sum(as, &s_acc), flag_load(g.vhash + VH_ROW + row * 32 + j));
+                    unsigned long long wb = 0ull, wa = 0ull;
+                    if (tid == 0) for (int jj = j; jj < m; ++jj) { wb += flag_load(g.vhash + VH_ROW + k * 32 + jj); wa += flag_load(g.vhash + VH_ROW + row * 32 + jj); }
+                    verify_compare(g, wg_sum(bs, &s_acc), wb);
+                    verify_compare(g, wg_sum(as, &s_acc), wa);
                 }
+                j = m;
             }
             epilogue<true, true>(acc, Ar + k * 128, g.lda);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -751,7 +766,7 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
         chain_stamp(g, 10, t, row, k);
         if (k == 0) {                              // (no products: the solve behind leaf 0 starts here)
             if (g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
-            __builtin_amdgcn_s_setprio(row == k + 1 ? 3 : 2);
+            if (row == k + 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
         }
         double4_t xt[8];
         trsm_load(xt, Ar + k * 128, g.lda);

@@ -161,7 +161,7 @@ def test_forward_sweep_in_one_launch(H, n):
 def test_launch_shape_options_keep_the_result(H):
     """The options that only pick a launch shape: `tile_tables` (XCD-balanced block -> tile table vs the formula map) and
     the diagnostic stamp buffers change WHERE and WHEN a tile runs, never its arithmetic: same bits.  `lookahead_min` (look-ahead
-    on / off at this size: two streams and a split trailing update vs one stream) and  `small_tile_max(_update)` = 0 sends the chain's small products to the
+    on at this size: two streams and a split trailing update vs wide panels on one stream), `chain_wide` = 0 (narrow panels on one stream) and  `small_tile_max(_update)` = 0 sends the chain's small products to the
     128-tile kernel, which contracts k in another order: LAPACK accuracy either way.  The diagnostic stamp buffers
     (`chain_stamps`, `leaf_stamps`) fill when set and change nothing."""
     import torch
@@ -192,24 +192,27 @@ def test_launch_shape_options_keep_the_result(H):
     stamps = torch.zeros(8 + 4 * 4096, dtype=torch.int64, device="cuda")
     lstamps = torch.zeros(64, dtype=torch.int64, device="cuda")
     try:
-        for name, opts in (("default", {}), ("no_lookahead", {"lookahead_min": 1 << 30}), ("lookahead", {"lookahead_min": 0}),
-                           ("no_small_tiles", {"small_tile_max": 0, "small_tile_max_update": 0}),
-                           ("stamps", {"chain_stamps": stamps.data_ptr(), "leaf_stamps": lstamps.data_ptr()})):
+        defaults = dict(lookahead_min=1 << 40, chain_wide=1, small_tile_max=160, small_tile_max_update=512, chain_stamps=0, leaf_stamps=0)
+        for name, opts in (("default", {}), ("stamps", {"chain_stamps": stamps.data_ptr(), "leaf_stamps": lstamps.data_ptr()}),
+                           ("lookahead", {"lookahead_min": 0}),
+                           ("lookahead_stamps", {"lookahead_min": 0, "chain_stamps": stamps.data_ptr(), "leaf_stamps": lstamps.data_ptr()}),
+                           ("narrow_panels", {"chain_wide": 0}),
+                           ("no_small_tiles", {"small_tile_max": 0, "small_tile_max_update": 0})):
             for k, v in opts.items():
                 H.set_option(k, v)
             A = H.to_device(buf)
             assert H.potrf(A, n) == 0
             got[name] = np.tril(A.cpu().numpy()[:n, :n])
-            for k, v in dict(lookahead_min=4608, small_tile_max=160, small_tile_max_update=512, chain_stamps=0, leaf_stamps=0).items():
+            for k, v in defaults.items():
                 H.set_option(k, v)
     finally:
-        for k, v in dict(lookahead_min=4608, small_tile_max=160, small_tile_max_update=512, chain_stamps=0, leaf_stamps=0).items():
+        for k, v in dict(lookahead_min=1 << 40, chain_wide=1, small_tile_max=160, small_tile_max_update=512, chain_stamps=0, leaf_stamps=0).items():
             H.set_option(k, v)
-    assert np.array_equal(got["default"], got["lookahead"]) and np.array_equal(got["default"], got["stamps"])
+    assert np.array_equal(got["default"], got["stamps"]) and np.array_equal(got["lookahead"], got["lookahead_stamps"])
     assert int(stamps[0]) > 0 and int(lstamps[:8].abs().sum()) > 0
-    # (without look-ahead a panel's update is ONE launch instead of two: the next panel's columns may then run on the other tile
-    # size, i.e. in the other k order)
-    for name in ("default", "no_small_tiles", "no_lookahead"):
+    # (the default -- 4096-wide panels, each factored by one resident kernel alone on the chip -- the look-ahead schedule on two streams
+    # and the narrow panels without look-ahead contract k in different orders)
+    for name in ("default", "lookahead", "narrow_panels", "no_small_tiles"):
         assert np.max(np.abs(got[name] - Lref)) / np.max(np.abs(Lref)) < 1e-13
 
 
@@ -432,27 +435,33 @@ def test_trsm_lower_few_columns_against_a_long_factor(H, n, nrhs):
     assert np.max(np.abs(got[1] - got[0])) / np.max(np.abs(ref)) < 1e-12
 
 
-@pytest.mark.parametrize("sched", [dict(outer_block=512, outer_block_big=1024, big_threshold=0, inner_block=256, lookahead=1),
-                                   dict(outer_block=256, outer_block_big=1024, big_threshold=1500, inner_block=128, lookahead=1),
-                                   dict(outer_block=256, outer_block_big=768, big_threshold=0, inner_block=512, lookahead=1),
-                                   dict(outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0),
-                                   dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1),
-                                   dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=0),
-                                   dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles_rows=1024),
-                                   dict(outer_block=256, outer_block_big=768, big_threshold=0, inner_block=256, lookahead=1, panel_recursive=0),
-                                   dict(outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0, panel_recursive=0),
-                                   dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, panel_chain=0),
-                                   dict(outer_block=512, outer_block_big=2048, big_threshold=1000, inner_block=512, lookahead=1, panel_chain=1, panel_chain_min=0),
-                                   dict(outer_block=256, outer_block_big=1024, big_threshold=24576, inner_block=512, lookahead=0, panel_chain=1, panel_chain_min=0, outer_block_small=128, small_threshold=1024),
-                                   dict(outer_block=256, outer_block_big=768, big_threshold=0, inner_block=512, lookahead=1, lookahead_min=0, panel_chain=1, panel_chain_min=0, cols_split=1, cols_split_rows=100000),
-                                   dict(outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, lookahead_min=0, panel_chain=1, panel_chain_min=0, cols_split=0)])
+@pytest.mark.parametrize("sched", [dict(chain_wide=0, lookahead_min=4608, outer_block=512, outer_block_big=1024, big_threshold=0, inner_block=256, lookahead=1),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=256, outer_block_big=1024, big_threshold=1500, inner_block=128, lookahead=1),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=256, outer_block_big=768, big_threshold=0, inner_block=512, lookahead=1),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=0),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles_rows=1024),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=256, outer_block_big=768, big_threshold=0, inner_block=256, lookahead=1, panel_recursive=0),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=512, outer_block_big=1536, big_threshold=1000, inner_block=512, lookahead=0, panel_recursive=0),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, panel_chain=0),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=512, outer_block_big=2048, big_threshold=1000, inner_block=512, lookahead=1, panel_chain=1, panel_chain_min=0),
+                                   dict(chain_wide=0, lookahead_min=4608, outer_block=256, outer_block_big=1024, big_threshold=24576, inner_block=512, lookahead=0, panel_chain=1, panel_chain_min=0, outer_block_small=128, small_threshold=1024),
+                                   dict(chain_wide=0, outer_block=256, outer_block_big=768, big_threshold=0, inner_block=512, lookahead=1, lookahead_min=0, panel_chain=1, panel_chain_min=0, cols_split=1, cols_split_rows=100000),
+                                   dict(chain_wide=0, outer_block=512, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, lookahead_min=0, panel_chain=1, panel_chain_min=0, cols_split=0),
+                                   dict(),
+                                   dict(wide_block=1024, wide_block_big=1024),
+                                   dict(wide_block=512, wide_block_big=2048, wide_threshold=1500),
+                                   dict(wide_block=2048, wide_block_big=2048, wide_inner=512, wide_inner_rows=0),
+                                   dict(wide_block=4096, wide_block_big=4096, wide_inner=1024, wide_inner_rows=2048)])
 def test_potrf_panel_schedules_agree(H, sched):
     """Every panel schedule (regular / wide panels, sub-panels of a third block size, with and without look-ahead; the
     chain's TRSM by the inverted 128-block, by substitution with the 16 x 16 tile inverses, or switching between the two
     on the way down; panels by recursive halving (the default) or by 128-column steps inside sub-panels; the chain as three launches
     per 128 columns or as ONE resident kernel per panel, chain.hip, for panels of 128 ... 2048 columns, its rows below the square
-    updated before it starts or beside it behind a flag in memory) is the same factorisation:
-    compare with LAPACK on one matrix."""
+    updated before it starts or beside it behind a flag in memory; the default: panels of up to 4096 columns, each ONE resident
+    kernel alone on the chip with a workgroup per block, optionally in sub-panels with the trailing update's kernel in between)
+    is the same factorisation: compare with LAPACK on one matrix."""
     from fvgp_amd._lib import pad128
     n = 3000
     M = _spd(n, 17)
@@ -483,7 +492,8 @@ def _restore_schedule_defaults(H):
     """the library's own defaults (fvgp_amd/csrc/common.h) for every key the schedule tests touch: the handle is shared by the module"""
     for k, v in dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=1,
                      leaf_tiles_rows=4096, panel_recursive=1, panel_chain=1, panel_chain_min=4096, outer_block_small=512,
-                     small_threshold=12288, lookahead_min=4608, cols_split=1, cols_split_rows=8192).items():
+                     small_threshold=12288, lookahead_min=1 << 40, cols_split=1, cols_split_rows=8192, chain_wide=1, wide_block=4096,
+                     wide_block_big=4096, wide_threshold=1 << 30, wide_inner=2048, wide_inner_rows=16384).items():
         H.set_option(k, v)
 
 
@@ -496,7 +506,7 @@ def test_panels_wider_than_the_resident_kernel_takes(H):
     M = _spd(n, 23)
     Lref = np.tril(sla.cho_factor(M, lower=True)[0])
     try:
-        for k, v in dict(outer_block=8192, outer_block_big=0, outer_block_small=0).items():
+        for k, v in dict(chain_wide=0, lookahead_min=4608, outer_block=8192, outer_block_big=0, outer_block_small=0).items():
             H.set_option(k, v)
         npad = pad128(n)
         buf = np.zeros((npad, npad))
@@ -731,8 +741,9 @@ def test_scheduling_mechanisms_do_not_change_a_bit(H):
 
 @pytest.mark.parametrize("n", [8000, 12000])
 def test_resident_panel_kernel_soak(H, n):
-    """30 evaluations of the same theta with look-ahead on (the resident panel kernel of chain.hip beside a full trailing update:
-    uneven load, consumers with warm caches), the matrix buffer poisoned with NaN before each: log-likelihood, log-det, quadratic
+    """30 evaluations of the same theta (the resident panel kernel of chain.hip, a workgroup per block, hundreds of in-launch hand-offs
+    per panel; at n = 12000 under the look-ahead schedule instead: the kernel beside a full trailing update, uneven load, consumers
+    with warm caches), the matrix buffer poisoned with NaN before each: log-likelihood, log-det, quadratic
     form, alpha and every entry of L must come out with the same bits each time -- a stale or torn in-launch hand-off would change
     some of them -- and agree with LAPACK's answer (the oracle) to rounding."""
     import torch
@@ -746,6 +757,8 @@ def test_resident_panel_kernel_soak(H, n):
     KV = H.empty(npad, npad); alpha = H.empty(npad, 1)
     ref = None
     differ = 0
+    if n == 12000:
+        H.set_option("lookahead_min", 4608)
     for _ in range(30):
         KV.fill_(float("nan"))
         out = H.loglik(0, xd, theta, vd, ymd, KV, alpha)
@@ -774,6 +787,7 @@ def test_resident_panel_kernel_soak(H, n):
         bad, checks = H.chain_verify_counts()
     finally:
         H.set_option("chain_verify", 0)
+        H.set_option("lookahead_min", 1 << 40)
     assert bad == 0 and checks > 1000 and not vdiffer, (bad, checks, vdiffer, ref[0])
     want, _ = orc.log_likelihood_once(x, y, np.full(n, 0.01), theta, "rbf_ard")
     np.testing.assert_allclose(ref[0][0], want, rtol=1e-10)
