@@ -155,7 +155,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "leaf_yield")) { h->leaf_yield = (int)value; return 0; }
     if (!strcmp(key, "chain_yield")) { h->chain_yield = (int)value; return 0; }
     if (!strcmp(key, "lookahead_min")) { h->lookahead_min = value; return 0; }
-    if (!strcmp(key, "panel_chain")) { if (value < 0 || value > 2) return -3; h->panel_chain = (int)value; return 0; }
+    if (!strcmp(key, "panel_chain")) { if (value < 0 || value > 3) return -3; h->panel_chain = (int)value; return 0; }
     if (!strcmp(key, "panel_chain_min")) { h->panel_chain_min = value; return 0; }
     if (!strcmp(key, "chain_wide")) { h->chain_wide = (int)value; return 0; }
     if (!strcmp(key, "wide_block") || !strcmp(key, "wide_block_big")) {
@@ -924,7 +924,9 @@ int fvgp_hip_panel_potrf_dev(fvgp_handle *h, double *T, int64_t w, int64_t rows,
     if (rc) return rc;
     h->winv_ok = false; h->linv_L = nullptr;
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
-    if (h->panel_chain >= 2) { h->chain_alone = 0; rc = launch_panel_chain(h, T, n_valid, rows, ldt, 0, w); }   // (the row-sharded driver's stacked panel: measured 3 % slower in the 8-rank emulation, off unless panel_chain = 2)
+    // the row-sharded driver's stacked panel: ONE resident kernel with a workgroup per block (8-rank emulation at N = 50 000: 93.2 ms
+    // against 96.0 with the launch-per-step chain; with a workgroup per block ROW below the square, panel_chain = 2, 100.6)
+    if (h->panel_chain >= 1 && w / TILE <= FVGP_CHAIN_MAX_BLOCKS && rows / TILE <= 1024) { h->chain_alone = h->panel_chain == 2 ? 0 : 1; rc = launch_panel_chain(h, T, n_valid, rows, ldt, 0, w); }
     else rc = panel_factor_nested(h, T, n_valid, rows, ldt, 0, w);   // leaf / TRSM of every row below / in-panel update per 128 columns, in sub-panels of `inner_block`
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
