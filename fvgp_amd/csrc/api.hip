@@ -474,8 +474,9 @@ static double lower_flops(int64_t M, int64_t N, int64_t K) {     // algorithmic 
 // panel J+1 (done first) and the rest; panel J+1 is then factored on a second, high-priority stream
 // while the rest of the update runs on the main stream.
 // np_force != 0: the padded matrix has np_force rows (fvgp_hip_loglik appends (y-m)^T in a block row of its own when n leaves no padding rows)
+// skip_inverses: the caller launches the batched block inverses itself (fvgp_hip_loglik: after it has taken the appended rows out again)
 static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *info_host, int *info_dev = nullptr, bool enqueue_only = false,
-                        int64_t np_force = 0) {
+                        int64_t np_force = 0, bool skip_inverses = false) {
     const int64_t np = np_force ? np_force : pad128(n), nblk = np / TILE;
     int rc = ensure_blocks(h, nblk);
     if (rc) return rc;
@@ -586,11 +587,11 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
         // the chain only needed the inverses of the 16 x 16 diagonal tiles; the 128 x 128 block inverses the sweeps, the
         // posterior and POTRI use come from one launch over all blocks (a few tens of microseconds on the whole chip
         // instead of 8 us per block on the chain's critical path)
-        rc = launch_leaf_inverse_batched(h, A, lda, nblk, h->linv); if (rc) return rc;
+        if (!skip_inverses) { rc = launch_leaf_inverse_batched(h, A, lda, nblk, h->linv); if (rc) return rc; }
     }
     if (enqueue_only) {          // no host round trip: info stays on the device, nothing is timed
         if (info_dev) HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-        h->winv_ok = false; h->linv_L = A; h->linv_n = n; h->linv_ld = lda;
+        h->winv_ok = false; h->linv_L = skip_inverses ? nullptr : A; h->linv_n = n; h->linv_ld = lda;
         return 0;
     }
     if (h->profile) { rc = get_event(&e_end); if (rc) return rc; HIPCHK(hipEventRecord(e_end, h->stream)); }
@@ -601,7 +602,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     if (info == 0x7fffffff) { fvgp_set_error("panel chain: a workgroup waited longer than 3 s for a hand-off and the launch was abandoned"); return 1999; }
     if (info > n) info = 0;   // cannot happen: the padding is an identity block
     if (info_host) *info_host = info;
-    h->winv_ok = false; h->linv_L = A; h->linv_n = n; h->linv_ld = lda;
+    h->winv_ok = false; h->linv_L = skip_inverses ? nullptr : A; h->linv_n = n; h->linv_ld = lda;
     if (h->profile) {
         h->prof_launches = 0; h->prof_ms = 0; h->prof_flops = 0;
         for (size_t i = 0; i < h->ev_flops.size(); ++i) {
@@ -1142,31 +1143,31 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     int info = 0;
     const bool defer = !h->profile;
     const int64_t npd = fused ? npf : 0;
-    if (defer) { rc = potrf_driver(h, KV, n, ld, nullptr, nullptr, true, npd); if (rc) return rc; }
+    const bool own_inverses = fused && (h->leaf_tiles || h->panel_chain);      // (see below: the block inverses wait until the appended rows are out again)
+    if (defer) { rc = potrf_driver(h, KV, n, ld, nullptr, nullptr, true, npd, own_inverses); if (rc) return rc; }
     else {
-        rc = potrf_driver(h, KV, n, ld, &info, nullptr, false, npd); if (rc) return rc;
+        rc = potrf_driver(h, KV, n, ld, &info, nullptr, false, npd, own_inverses); if (rc) return rc;
         if (info_host) *info_host = info;
         if (info != 0) { out_host[0] = out_host[1] = out_host[2] = NAN; return 0; }
     }
     if (h->profile) HIPCHK(hipEventRecord(h->ev_stage[2], h->stream));
-    rc = launch_neg_log_sum(h, h->logdet_parts, fused ? npf : np, h->red); if (rc) return rc;       // sum log L_ii from the leaves' 1 / L_ii (1 on padding rows)
     if (fused) {
-        rc = launch_rowsumsq(h, KV, ld, n, ncol, n, h->red + 1); if (rc) return rc;
+        // ONE launch: sum log L_ii from the leaves' 1 / L_ii (1 on padding rows), |z|^2 of the appended rows, z (rows of L) -> the
+        // (np x C) vector layout of the backward sweep, alpha <- 0
         const int C = ncol <= 1 ? 1 : ncol <= 2 ? 2 : ncol <= 4 ? 4 : 8;
-        if (alpha) {
-            // z (rows of L) -> (np x C) vector layout for the backward sweep
-            rc = ensure_scratch(h, np); if (rc) return rc;
-            rc = launch_rows_to_vec(h, KV, ld, n, ncol, h->vec, C, np); if (rc) return rc;
-        }
-        // hand back the clean factor of blockdiag(K+V, I): identity padding rows again, and the inverse of
-        // the last diagonal block recomputed without the appended rows
+        if (alpha) { rc = ensure_scratch(h, np); if (rc) return rc; }
+        rc = launch_loglik_tail(h, h->logdet_parts, npf, KV, ld, n, ncol, h->red, alpha ? h->vec : nullptr, C, np, alpha); if (rc) return rc;
+        // hand back the clean factor of blockdiag(K+V, I): identity padding rows again; the 128 x 128 block inverses the sweeps, the
+        // posterior and POTRI take are computed from THAT (one batched launch; the last diagonal block without the appended rows)
         rc = launch_pad_identity(h, KV, n, npf, ld); if (rc) return rc;
-        if (room) {           // (a block row of their own: the last diagonal block of the factor never saw the appended rows)
+        if (own_inverses) {
+            rc = launch_leaf_inverse_batched(h, KV, ld, npf / TILE, h->linv); if (rc) return rc;
+            h->linv_L = KV; h->linv_n = n; h->linv_ld = ld;
+        } else if (room) {
             rc = launch_leaf(h, KV + (np - TILE) * ld + (np - TILE), ld, h->linv + (np / TILE - 1) * LEAF_DOUBLES, nullptr, 0, 0, TILE);
             if (rc) return rc;
         }
         if (alpha) {
-            rc = launch_copy_cols(h, alpha, ncol, alpha, ncol, 0, 0, np, ncol); if (rc) return rc;
             if (h->bwd_sweep && ncol == 1) { rc = launch_bwd_sweep(h, KV, ld, np, h->linv, h->vec, alpha, ncol, ncol); if (rc) return rc; }
             else
             for (int64_t k0 = np - TILE; k0 >= 0; k0 -= TILE) {
@@ -1175,6 +1176,7 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
             }
         }
     } else {
+        rc = launch_neg_log_sum(h, h->logdet_parts, np, h->red); if (rc) return rc;
         if (!alpha) { fvgp_set_error("loglik without alpha needs ncol free padding rows (n % 128 <= 128 - ncol)"); return -13; }
         rc = launch_copy_cols(h, ymean, ncol, alpha, ncol, n, ncol, np, ncol); if (rc) return rc;
         rc = potrs_vec(h, KV, n, ld, alpha, ncol, ncol, true); if (rc) return rc;

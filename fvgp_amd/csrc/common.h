@@ -222,6 +222,8 @@ int launch_leaf_inverse_batched(fvgp_handle *h, const double *L, int64_t ldl, in
 int launch_fwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,
                     double *B, int64_t ldb, double *Y, int c);
 int launch_neg_log_sum(fvgp_handle *h, const double *v, int64_t n, double *out_dev);
+int launch_loglik_tail(fvgp_handle *h, const double *v, int64_t nlog, const double *A, int64_t lda, int64_t n, int ncol, double *out2_dev,
+                       double *vec, int C, int64_t np, double *alpha);
 int launch_bwd_sweep(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, const double *linv, const double *Yres, double *X, int64_t ldx, int c);
 int launch_fwd_sweep(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, const double *linv, const double *B, int64_t ldb, double *Y);
 int launch_bwd_step(fvgp_handle *h, const double *L, int64_t ldl, int64_t np, int64_t k0, const double *linv_k,

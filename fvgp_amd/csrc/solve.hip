@@ -736,7 +736,45 @@ __global__ void rows_to_vec_kernel(const double *A, long lda, long row0, int nro
     }
 }
 
+// What follows the fused factorisation of fvgp_hip_loglik in ONE launch (four launches of ~5 us each at the training loop's sizes):
+// block 0: out[0] = -sum log v[i] (neg_log_sum_kernel); block 1: out[1] = the squared norm of the appended rows (rowsumsq_kernel);
+// the other blocks: vec <- the appended rows transposed (rows_to_vec_kernel), alpha <- 0.  The two sums add up in the order of the
+// kernels they replace (1024 threads striding the input, wave shuffle, sixteen partial sums in turn).
+__global__ __launch_bounds__(1024) void loglik_tail_kernel(const double *v, long nlog, const double *A, long lda, long row0, int nrows, double *out,
+                                                         double *vec, int C, long np, double *alpha, int ncol) {
+    __shared__ double sw[16];
+    if (blockIdx.x <= 1) {
+        double s = 0.0;
+        if (blockIdx.x == 0) { for (long i = threadIdx.x; i < nlog; i += blockDim.x) s -= log(v[i]); }
+        else {
+            for (int rr = 0; rr < nrows; ++rr)
+                for (long j = threadIdx.x; j < row0; j += blockDim.x) { const double a = A[(row0 + rr) * lda + j]; s = fma(a, a, s); }
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sw[w]; out[blockIdx.x] = t; }
+        return;
+    }
+    if (!vec) return;
+    const long stride = (long)(gridDim.x - 2) * blockDim.x, first = (long)(blockIdx.x - 2) * blockDim.x + threadIdx.x;
+    for (long e = first; e < np * C; e += stride) {
+        const long i = e / C; const int c = (int)(e % C);
+        vec[e] = (i < row0 && c < nrows) ? A[(row0 + c) * lda + i] : 0.0;
+    }
+    for (long e = first; e < np * ncol; e += stride) alpha[e] = 0.0;
+}
+
 }  // namespace
+
+int launch_loglik_tail(fvgp_handle *h, const double *v, int64_t nlog, const double *A, int64_t lda, int64_t n, int ncol, double *out2_dev,
+                       double *vec, int C, int64_t np, double *alpha) {
+    long blocks = vec ? (np * C + 1023) / 1024 : 0; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(loglik_tail_kernel, dim3((unsigned)(2 + blocks)), dim3(1024), 0, h->stream, v, (long)nlog, A, (long)lda, (long)n, ncol, out2_dev,
+                       vec, C, (long)np, alpha, ncol);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 
 int launch_rhs_rows(fvgp_handle *h, double *A, int64_t n, int64_t lda, const double *ymean, int ncol, const double *vdiag) {
     hipLaunchKernelGGL(rhs_rows_kernel, dim3(1), dim3(1024), 0, h->stream, A, (long)n, (long)lda, ymean, ncol, vdiag);
