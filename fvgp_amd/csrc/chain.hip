@@ -38,6 +38,7 @@ struct ChainArgs {
     double *A; long lda;              // element (J0, J0): origin of the panel
     int n;                            // 128-column blocks of the panel
     int rows;                         // 128-row blocks from J0 to the end of the padded matrix (>= n)
+    int sleep_rows;                   // panels of more block rows than this: no product yields its compute unit (option chain_sleep_rows)
     int n2;                           // n <= n2 <= rows: the first n2 block rows have one workgroup per BLOCK (the square always), the rest one per block row
     int nvalid;                       // rows of the matrix proper from J0 on (the rest is identity padding)
     double *linv;                     // inverses of the panel's diagonal blocks (n x 128 x 128)
@@ -747,7 +748,8 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
                     if (g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
                     if (row == k + 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
                 }
-                const int *yb = last ? nullptr : g.yield;
+                // (a tall panel is bound by the products' throughput, not by the leaf chain: nobody sleeps there)
+                const int *yb = (last || g.rows > g.sleep_rows) ? nullptr : g.yield;
                 unsigned long long bs = 0ull, as = 0ull;
                 if (j == 0) product<VERIFY, false>(acc, Ar, g.lda, Ak, g.lda, 8 * m, smem, Ar + k * 128, g.lda, false, &bs, &as, yb);
                 else product<VERIFY, true>(acc, Ar + j * 128, g.lda, Ak + j * 128, g.lda, 8 * (m - j), smem, nullptr, 0, false, &bs, &as, yb);
@@ -986,7 +988,7 @@ int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, i
     int n2 = h->chain_alone ? g.rows : g.n;
     if (n2 > g.rows) n2 = g.rows;
     if (n2 > VH_ROWS) n2 = VH_ROWS;
-    g.n2 = n2;
+    g.n2 = n2; g.sleep_rows = h->chain_sleep_rows;
     const int nsq = g.n * n2 - g.n * (g.n - 1) / 2;
     int below = g.rows - n2;
     const int room = 480 - nsq > 128 ? 480 - nsq : 128;
