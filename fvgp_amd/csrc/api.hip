@@ -159,6 +159,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "panel_chain_min")) { h->panel_chain_min = value; return 0; }
     if (!strcmp(key, "chain_wide")) { h->chain_wide = (int)value; return 0; }
     if (!strcmp(key, "chain_sleep_rows")) { h->chain_sleep_rows = (int)value; return 0; }
+    if (!strcmp(key, "chain_single_rows")) { h->chain_single_rows = (int)value; return 0; }
     if (!strcmp(key, "wide_block") || !strcmp(key, "wide_block_big")) {
         if (value < TILE || value % TILE || value / TILE > FVGP_CHAIN_MAX_BLOCKS) { fvgp_set_error("wide_block: a multiple of 128, at most 4096"); return -2; }
         (key[10] ? h->wide_block_big : h->wide_block) = value; return 0;

@@ -287,6 +287,52 @@ __device__ __forceinline__ void epilogue(const double4_t (&acc)[4][2], double *C
             }
 }
 
+// acc <- -C (the start of `product` with C given, on its own: a block's workgroup loads C before it waits for its operands)
+__device__ __forceinline__ void load_c_neg(double4_t (&acc)[4][2], const double *C, const long ldc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const double *cb = C + (long)(wm * 64 + q) * ldc + wn * 32 + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[i][j][v] = -ld_sc1(cb + (long)(i * 16 + 4 * v) * ldc + j * 16);
+}
+
+// The block C - sum as `product` leaves it (acc = -(C - sum), eight waves of 64 x 32) -> the solve's layout (xt: wave w owns rows
+// 16 w .., lane (r, q) columns 16 t + 4 q .. + 3 of row r) through LDS, 64 rows at a time (a row of the staging buffer is 144 doubles:
+// the four lane groups of a wave, four rows apart, land on alternating halves of the banks) -- instead of a write-through store of the
+// block, a drain and sixteen loads back (4-5 us on the path of the block the next leaf waits for).  The staging buffer takes all 72 KB.
+constexpr int XSTG = 144;
+__device__ __forceinline__ void acc_to_xt(const double4_t (&acc)[4][2], double4_t (&xt)[8], double *smem) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave_u & 3;
+    auto put = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) smem[(i * 16 + q + 4 * v) * XSTG + wn * 32 + j * 16 + r] = -acc[i][j][v];
+    };
+    auto get = [&]() {
+        const double *row = &smem[((wave_u & 3) * 16 + r) * XSTG + 4 * q];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const double2_t a = *reinterpret_cast<const double2_t *>(row + 16 * t), b = *reinterpret_cast<const double2_t *>(row + 16 * t + 2);
+            xt[t] = (double4_t){a[0], a[1], b[0], b[1]};
+        }
+    };
+    // (the same four barriers on both paths: rows 0 .. 63 go through the buffer first, then rows 64 .. 127)
+    if (wave_u < 4) { put(); __syncthreads(); get(); __syncthreads(); __syncthreads(); __syncthreads(); }
+    else { __syncthreads(); __syncthreads(); put(); __syncthreads(); get(); __syncthreads(); }
+}
+
 // X = A inv(L)^T in place for one 128 x 128 block A, by substitution over the eight 16-column tiles of the lower block L with the
 // inverses of L's diagonal tiles only (what the leaf leaves: `dinv`, 8 x 256 doubles, zeros above the diagonals) -- no
 // 128 x 128 inverse anywhere on the chain.  L's strictly lower tiles and the tile inverses sit in LDS as the leaf's 36 packed
@@ -724,6 +770,7 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
         // (a row below the square: its part of the trailing update may still be running beside this launch)
         if (row >= n && g.cols_tag && !chain_wait(g, F_COLS, g.cols_tag, &s_i[1])) return;
         if (k > 0) {
+            load_c_neg(acc, Ar + k * 128, g.lda);      // (before the first wait: the block itself has been final since the last trailing update)
             for (int j = 0; j < k;) {
                 if (!chain_wait(g, F_ROW + row, tag + j + 1, &s_i[1], row != k + 1) || !chain_wait(g, F_ROW + k, tag + j + 1, &s_i[1], row != k + 1)) { if (yslot) atomicAdd(yslot, -1); return; }
                 // every block column already published on both rows goes into ONE product (they are contiguous along K: a workgroup that
@@ -743,16 +790,17 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
                 // column j starts its product j the moment column j is published: hundreds at a time, two per compute unit, and
                 // without this the thirty that matter took 29 us instead of 14.)
                 if (m == k && m - j > 1) m = k - 1;            // (the last block column on its own)
-                const bool last = m == k;
+                // (only the two blocks under the diagonal: (k+1, k) is what leaf k+1 waits for, (k+2, k) what the block leaf k+2 waits for is
+                // updated with as soon as leaf k is through; the blocks further down have a leaf's time to spare)
+                const bool last = m == k && row <= k + 2;
                 if (last) {
                     if (g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
                     if (row == k + 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
                 }
                 // (a tall panel is bound by the products' throughput, not by the leaf chain: nobody sleeps there)
-                const int *yb = (last || g.rows > g.sleep_rows) ? nullptr : g.yield;
+                const int *yb = (row <= k + 2 || g.rows > g.sleep_rows) ? nullptr : g.yield;      // (the two blocks under the diagonal never sleep: their turn comes within a leaf or two)
                 unsigned long long bs = 0ull, as = 0ull;
-                if (j == 0) product<VERIFY, false>(acc, Ar, g.lda, Ak, g.lda, 8 * m, smem, Ar + k * 128, g.lda, false, &bs, &as, yb);
-                else product<VERIFY, true>(acc, Ar + j * 128, g.lda, Ak + j * 128, g.lda, 8 * (m - j), smem, nullptr, 0, false, &bs, &as, yb);
+                product<VERIFY, true>(acc, Ar + j * 128, g.lda, Ak + j * 128, g.lda, 8 * (m - j), smem, nullptr, 0, false, &bs, &as, yb);
                 if constexpr (VERIFY) {               // both operands were solved and stored by other workgroups
                     unsigned long long wb = 0ull, wa = 0ull;
                     if (tid == 0) for (int jj = j; jj < m; ++jj) { wb += flag_load(g.vhash + VH_ROW + k * 32 + jj); wa += flag_load(g.vhash + VH_ROW + row * 32 + jj); }
@@ -761,17 +809,15 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
                 }
                 j = m;
             }
-            epilogue<true, true>(acc, Ar + k * 128, g.lda);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
         }
         chain_stamp(g, 10, t, row, k);
-        if (k == 0) {                              // (no products: the solve behind leaf 0 starts here)
+        if (k == 0 && row <= 2) {                  // (no products: the solve behind leaf 0 starts here)
             if (g.yield && tid == 0) { yslot = cu_yield_slot(g.yield); atomicAdd(yslot, 1); }
             if (row == k + 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
         }
         double4_t xt[8];
-        trsm_load(xt, Ar + k * 128, g.lda);
+        if (k > 0) acc_to_xt(acc, xt, smem);       // (the updated block never goes to memory: only its solve does)
+        else trsm_load(xt, Ar + k * 128, g.lda);
         unsigned long long vs = 0ull;
         if (!follow<VERIFY>(g, xt, Ar + k * 128, g.lda, Ak + k * 128, g.lda, g.linv + (long)k * LEAF_DOUBLES, tag + 8ull * k, xcol, smem, &s_i[1], &vs)) {
             if (yslot) atomicAdd(yslot, -1);
@@ -1007,7 +1053,10 @@ int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, i
         hipLaunchKernelGGL(chain_verify_begin_kernel, dim3(1), dim3(256), 0, h->stream, h->chain_vhash);
         hipLaunchKernelGGL(chain_kernel<true>, dim3((unsigned)grid), dim3(512), 0, h->stream, g);
     } else {
-        hipLaunchKernelGGL(chain_kernel<false>, dim3((unsigned)grid), dim3(512), 0, h->stream, g);
+        // a short panel alone on the chip is bound by its chain of leaves: with ONE workgroup per compute unit (16 KB of LDS nobody uses
+        // take the second one's room) a leaf, or the solve behind it, never shares its SIMDs with another block's products
+        const unsigned pad_lds = (h->chain_alone && g.rows <= h->chain_single_rows) ? 16384u : 0u;
+        hipLaunchKernelGGL(chain_kernel<false>, dim3((unsigned)grid), dim3(512), pad_lds, h->stream, g);
     }
     HIPCHK(hipGetLastError());
     return 0;
