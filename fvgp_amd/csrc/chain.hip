@@ -2,30 +2,41 @@
 //
 // A panel of the blocked Cholesky (scipy.linalg.cho_factor -> dpotrf, fvgp/gp_lin_alg.py:245) is w = 128 n columns wide and
 // reaches from its diagonal square down to the last row of the matrix.  Per 128 columns the chain is: factor the diagonal
-// block (leaf), solve every block row below against it (TRSM), bring the rest of the panel up to date (K = 128 products).
-// As three launches per step every one of them waited 20-80 us for its first slot beside the trailing update that fills the
-// chip (look-ahead), 3 x n times per panel.  Here the whole panel is one launch whose workgroups take their slots ONCE and
-// hand results to each other through memory:
+// block (leaf), solve every block below against it, bring the rest of the panel up to date.  Here the whole panel is one
+// launch whose workgroups hand results to each other through memory -- a workgroup per 128 x 128 BLOCK of the panel:
 //
-//   tickets 0 .. n-1   the block rows of the panel's SQUARE, right-looking: after leaf j row i solves its block (i, j) against
-//                      L_jj (substitution with the inverses of its 16 x 16 diagonal tiles, trsm_sub), publishes
-//                      row_done[i] = j + 1, and subtracts L[i,j] L[k,j]^T from its blocks (i, k), k = j+1 .. i, the one the next
-//                      step needs first; when its own diagonal block is final it runs that block's LEAF (leaf_body.h) and
-//                      publishes leaf_done = i + 1 -- the critical path never changes workgroup between the update of a
-//                      diagonal block and its factorisation;
-//   further tickets    the block rows BELOW the square, left-looking: column k of row r is A[r,k] - L[r,0:k] L[k,0:k]^T in ONE
-//                      product with K = 128 k (it waits for row_done[k] = k only), then the solve against L_kk.
+//   diagonal block (k, k)   keeps its block in registers from the start (36 lower 16 x 16 tiles over eight waves), subtracts
+//                           X X^T for every solved block X = L[k, j] of its row, one 16-column tile column at a time BEHIND the
+//                           solver's column flags (syrk_follow), then runs the block's LEAF (leaf_body.h) straight from LDS.
+//                           The leaf's idle wave sends every finished tile column of L_kk to memory and raises a column flag;
+//   block (r, k), r > k     A[r,k] - sum_{j<k} L[r,j] L[k,j]^T: products with K = 128 per published block column (as many columns
+//                           as are already there in one K loop), the sum in registers; then through LDS into the solve's layout
+//                           and X = (that) inv(L_kk)^T by substitution over the tile columns BEHIND leaf k's column flags
+//                           (follow): the solve ends a few microseconds after the leaf, not a substitution (16 us) after it.
+//                           X goes to memory tile column by tile column with a flag per column (for the diagonal block of its
+//                           row) and row_done[r] = k + 1 at the end (for the products to its right and below);
+//   beside a trailing update (the look-ahead schedule, option lookahead_min) only the square has a workgroup per block; a block
+//   row below it is one workgroup, left-looking: column k of row r is A[r,k] - L[r,0:k] L[k,0:k]^T in ONE product with K = 128 k
+//   (it waits for row_done[k] = k only), then the solve against L_kk (trsm_sub).  Every resident workgroup holds a slot of the
+//   update there, and a workgroup per block mostly waits.
 //
-// Roles are dealt by a start-order ticket, and a workgroup only ever waits for workgroups with a LOWER ticket -- which have
-// started: nothing
-// depends on dispatch order or on all workgroups being resident together.  Every wait is bounded (about 3 s): a workgroup
-// that gives up raises the abort word, everybody leaves, and the host reports an error instead of hanging the GPU.
+// Tickets are dealt in start order, block column after block column ((0,0), (1,0), .. (1,1), (2,1), ..), and a workgroup only
+// ever waits for workgroups with a LOWER ticket -- which have started: nothing depends on dispatch order or on all workgroups
+// being resident together (a 4096-wide panel over 50 000 rows has twelve thousand).  Every wait is bounded (about 3 s): a
+// workgroup that gives up raises the abort word, everybody leaves, and the host reports an error instead of hanging the GPU.
+//
+// Who gets the compute unit: two workgroups fit one.  The leaf, the block the next leaf waits for, and the block under it raise the
+// unit's yield counter while they are on the critical path; the early products of the other blocks read that counter once per
+// K step and sleep while it is up (as the trailing update does, gemm.hip).  A short panel alone on the chip runs ONE workgroup
+// per compute unit (16 KB of unused LDS take the second one's room): a leaf then never shares its SIMDs.
 //
 // Hand-off form (MI355X_MICROARCH.md, inter-workgroup visibility): payload stored with sc1 (write-through) stores, every
-// storing wave waits vmcnt(0), workgroup barrier, ONE lane stores the flag with sc1; the consumer's lane 0 polls the flag
-// with sc1 loads, workgroup barrier, then every load of handed-off bytes is an sc1 load (buffer loads / LDS-DMA with
-// aux = sc1, which go past the compute unit's L1).  No fences: a release would write back the dirty lines the trailing
-// update keeps producing in the same L2.  Flags are 64-bit tags (launch base + progress), never reset.
+// storing wave waits vmcnt(0), workgroup barrier (or, for the leaf's column flags, ONE wave stores and waits for itself), ONE
+// lane stores the flag with sc1; the consumer's lane 0 polls the flag with sc1 loads, workgroup barrier, then every load of
+// handed-off bytes is an sc1 load (buffer loads / LDS-DMA with aux = sc1, which go past the compute unit's L1).  No fences: a
+// release would write back the dirty lines a trailing update keeps producing in the same L2.  Flags are 64-bit tags (launch
+// base + progress), never reset; a flag written by several workgroups in turn (the column flags) gets its last value of one
+// writer before the flag goes up that lets the next writer start.  Option "chain_verify": every hand-off carries a checksum.
 //
 // Resource shape: 512 threads at <= 128 registers and 73 KB of LDS -- what ONE retiring trailing-update workgroup frees, as
 // the leaf kernel -- so a workgroup starts beside a full update.

@@ -77,19 +77,28 @@ int fvgp_hip_stream_create(void **out_stream, int device, int high_priority, con
 int fvgp_hip_stream_destroy(void *stream);
 /* Every key has a default and a test (tests/test_gpu_primitives.py); none changes a result except where noted "order": another,
  * equally valid order of the same sums (LAPACK accuracy either way).
- *   panel widths ("order"): "outer_block" (1024: panel width = K of the trailing update, multiple of 128; any multiple is accepted,
- *       panels wider than 4096 are factored by the launch-per-step chain whatever "panel_chain" says),
- *       "outer_block_big" / "big_threshold" (2048 while more than 24576 rows remain), "outer_block_small" / "small_threshold"
- *       (512 for the last 12288 rows), "inner_block" / "panel_recursive" (how the three-launch chain splits a panel);
- *   panel chain: "panel_chain" (1: one resident kernel per panel, csrc/chain.hip, for panels with at least "panel_chain_min" = 4096
- *       rows below their first column; 0: three launches per 128 columns; 2: also for the row-sharded driver's stacked panel) ("order"),
- *       "cols_split" (1: while at most "cols_split_rows" = 8192 rows remain only the next panel's square is brought up to date before
- *       its resident kernel starts; the rows below follow on the main stream and the kernel's block rows wait for a flag in memory),
+ *   schedule ("order"): by default a matrix is factored in panels of "wide_block" = 4096 columns ("wide_block_big" while more than
+ *       "wide_threshold" rows remain), each ONE resident kernel (csrc/chain.hip, a workgroup per 128 x 128 block) ALONE on the chip,
+ *       followed by ONE trailing update with K = the panel's width; a panel over at least "wide_inner_rows" = 16384 rows goes in
+ *       sub-panels of "wide_inner" = 2048 columns with the update kernel bringing the rest of the panel up to date in between.
+ *       "chain_wide" = 0 or "lookahead_min" <= the padded size give the schedule of the earlier rounds instead: panels of
+ *       "outer_block" (1024; "outer_block_big" = 2048 while more than "big_threshold" = 24576 rows remain, "outer_block_small" = 512
+ *       for the last "small_threshold" = 12288; any multiple of 128, panels wider than 4096 take the launch-per-step chain),
+ *       with "lookahead" (1) from "lookahead_min" padded rows on: the next panel factored on a high-priority side stream under
+ *       the trailing update ("lookahead_min" defaults to 2^40: off; 4608 was the default until round 5);
+ *   panel chain: "panel_chain" (1: one resident kernel per panel -- in the look-ahead schedule for panels with at least
+ *       "panel_chain_min" = 4096 rows below their first column -- and for the row-sharded driver's stacked panel; 0: three launches
+ *       per 128 columns ("inner_block" / "panel_recursive": how those split a panel); 2: in the row-sharded driver a workgroup per
+ *       block ROW below the square instead of per block) ("order"), "chain_sleep_rows" (96: in panels of at most this many block rows
+ *       a block's early products yield their compute unit to a leaf or to the block the next leaf waits for), "chain_single_rows"
+ *       (96: such panels run one workgroup per compute unit),
+ *       "cols_split" (look-ahead schedule; 1: while at most "cols_split_rows" = 8192 rows remain only the next panel's square is
+ *       brought up to date before its resident kernel starts; the rows below follow on the main stream and the kernel's block rows
+ *       wait for a flag in memory),
  *       "leaf_tiles" / "leaf_tiles_rows" / "k128_kernels" / "small_tile_max" / "small_tile_max_update" (kernels of the three-launch
  *       chain) ("order"), "leaf_yield" / "chain_yield" (1: the trailing update's waves sleep while a workgroup of the chain shares
- *       their compute unit; chain_yield 2: also for the resident kernel's rows below the square), "chain_verify" (see fvgp_hip_chain_verify_counts);
- *   schedule: "lookahead" (0/1) from "lookahead_min" = 4608 padded rows on: the next panel's chain on a high-priority side stream
- *       under the trailing update; "tile_tables" (1: XCD-balanced block -> tile tables instead of the formula map);
+ *       their compute unit; chain_yield 2: also for the resident kernel's rows below the square), "chain_verify" (see
+ *       fvgp_hip_chain_verify_counts); "tile_tables" (1: XCD-balanced block -> tile tables instead of the formula map);
  *   solves / posterior / gradient: "bwd_sweep" / "fwd_sweep" (1: the backward / forward vector sweep with one right-hand side in
  *       one launch), "block_inverses" (1: the posterior
  *       substitutes with inverted diagonal blocks) ("order"), "posterior_block" (2048 / 1024: width of those blocks up to 1024
