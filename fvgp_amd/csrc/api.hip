@@ -399,6 +399,19 @@ static int trailing_update(fvgp_handle *h, double *A, int64_t np, int64_t lda, i
     s.A = A + c0 * lda + J0; s.lda = lda;
     s.B = A + c0 * lda + J0; s.ldb = lda;
     s.C = A + c0 * lda + c0; s.ldc = lda;
+    // the last update behind a wide panel may have a handful of tiles and K = 4096 (N = 4096 with its extra block row: ONE tile, 0.2 ms
+    // on four compute units): split K so that the launch fills the chip once, partial tiles summed in a fixed order
+    const int64_t tm = s.M / TILE, tn = s.N / TILE, tiles = tn * (tn + 1) / 2 + (tm - tn) * tn;
+    if (role == 1 && h->chain_alone && h->chain_wide && tiles > 0 && tiles <= 64 && s.K >= 1024) {
+        int64_t split = 256 / tiles;
+        if (split > s.K / 512) split = s.K / 512;
+        if (split > 1) {
+            int rc = ensure_scratch(h, (split * s.M * s.N + 7) / 8); if (rc) return rc;
+            s.split = (int)split; s.split_ws = h->vec;
+            if (big_kernel) *big_kernel = true;
+            return launch_gemm(h, s);
+        }
+    }
     if (big_kernel) *big_kernel = !gemm_takes_small_tiles(h, s);
     return launch_gemm(h, s);
 }
