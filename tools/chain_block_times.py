@@ -8,6 +8,8 @@ from fvgp_amd import _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 H = _lib.Handle(0)
+for kv in sys.argv[3:]:
+    H.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 rng = np.random.default_rng(20240501)
 x = rng.random((n, 3)); y = np.sin(3 * x.sum(1)) + 0.1 * rng.standard_normal(n)
 xd = H.to_device(x); npad = _lib.pad128(n)
@@ -33,6 +35,8 @@ for code, packed, t in zip(w[:, 1], w[:, 2], w[:, 3]):
         rec.setdefault(int(packed >> 16), {})[int(code)] = ((t - t0) / 100.0, int((packed >> 8) & 255), int(packed & 255))
 span = (w[:, 3].max() - t0) / 100.0
 print(f"launch {which}: {len(start)} workgroups, span {span:.0f} us")
+leaf = sorted((r[3], t) for code, p, t in zip(w[:, 1], w[:, 2], w[:, 3]) if code == 2 for r in [((p >> 16), (p >> 8) & 255, p & 255, (t - t0) / 100.0)])
+print("leaves done at (us):", " ".join(f"{a:.0f}" for a, _ in leaf))
 byk = {}
 for ticket, r in rec.items():
     if 10 in r and 3 in r and 4 in r and ticket in start:
