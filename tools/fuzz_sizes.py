@@ -1,6 +1,7 @@
 """One-off fuzz of the fused evaluation over problem sizes (GPU box): log-likelihood, alpha and the gradient route's inputs
-against numpy / scipy on the same inputs, sizes drawn around every schedule switch (128-multiples +-1, 4096, 4608, 6144, 8192,
-12288 rows; look-ahead on / off; 512 / 1024 panels).   python tools/fuzz_sizes.py [count]"""
+against numpy / scipy on the same inputs, sizes drawn around every schedule switch (128-multiples +-1; one / two / three wide panels:
+4096, 8192; sizes whose appended rows need a block row of their own; a last panel of one or two blocks), once under the default
+schedule and once under look-ahead.   python tools/fuzz_sizes.py [count]"""
 import os
 import sys
 
@@ -13,8 +14,11 @@ from fvgp_amd import _lib  # noqa: E402
 H = _lib.Handle(0)
 rng = np.random.default_rng(7)
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-special = [1, 2, 127, 128, 129, 255, 257, 4095, 4096, 4097, 4607, 4608, 4609, 4700, 6143, 6144, 6145, 8191, 8193, 9000]
+special = [1, 2, 127, 128, 129, 255, 257, 3968, 4095, 4096, 4097, 4223, 4224, 4225, 4352, 4607, 4608, 4609, 4700, 6143, 6144, 6145, 8064, 8191, 8192, 8193, 8320, 9000]
 sizes = special[:max(0, count - 6)] + [int(v) for v in rng.integers(3, 9000, size=6)]
+look = len(sys.argv) > 2 and sys.argv[2] == "lookahead"
+if look:
+    H.set_option("lookahead_min", 4608); H.set_option("chain_wide", 0)
 worst = 0.0
 for n in sizes:
     x = rng.random((n, 3)); y = np.sin(3 * x.sum(1)) + 0.1 * rng.standard_normal(n)
@@ -35,4 +39,4 @@ for n in sizes:
     worst = max(worst, ea, el)
     print(f"n {n:5d}: info {info}  rel err loglik {el:.2e}  alpha {ea:.2e}", flush=True)
     assert info == 0 and el < 1e-10 and ea < 1e-8, (n, el, ea)
-print("sizes", len(sizes), "worst relative error", f"{worst:.2e}")
+print("schedule:", "look-ahead (lookahead_min 4608, chain_wide 0)" if look else "default (wide panels)", "sizes", len(sizes), "worst relative error", f"{worst:.2e}")
