@@ -216,16 +216,16 @@ __global__ __launch_bounds__(256) void bwd_sweep_kernel(BwdSweepArgs g) {      /
         for (int u = 0; u < 32; ++u) l2[u] = __builtin_amdgcn_raw_buffer_load_b128(src, 16 * lane, u * rowb, 0);
     };
     // the inverse of the diagonal block is the last "block" of the column: thread (i, half) takes half of column i of inv(L_cc)
-    // (coalesced across i) into the same registers, while the x right under the diagonal is still on its way
-    auto load_inv = [&]() {
+    // (coalesced across i)
+    // (registers of its own, requested before anything else: behind the last block of the column its round trip -- 128 KB, 2.6 us -- sat on
+    // the path from x_{c+1} to x_c, a third of every hop of the sweep; one workgroup per compute unit has the registers)
+    double2_t li[32];
+    {
         const double *inv = g.linv + (long)c * 128 * 128 + (tid >> 7) * 64 * 128 + (tid & 127);
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const double2_t v = {inv[(2 * u) * 128], inv[(2 * u + 1) * 128]};
-            __builtin_memcpy(&l2[u], &v, 16);
-        }
-    };
-    if (c < nb - 1) load_block(nb - 1); else load_inv();
+        for (int u = 0; u < 32; ++u) li[u] = (double2_t){inv[(2 * u) * 128], inv[(2 * u + 1) * 128]};
+    }
+    if (c < nb - 1) load_block(nb - 1);
     if (tid < 128) sy[tid] = g.Y[(long)c * 128 + tid];
     __syncthreads();
     for (int I = nb - 1; I > c; --I) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void bwd_sweep_kernel(BwdSweepArgs g) {      /
             a0 = fma(lv[0], xv, a0);
             a1 = fma(lv[1], xv, a1);
         }
-        if (I - 1 > c) load_block(I - 1); else load_inv();      // the next block of the column is on its way while the partial sums are combined
+        if (I - 1 > c) load_block(I - 1);      // the next block of the column is on its way while the partial sums are combined
         sp[wave][2 * lane] = a0; sp[wave][2 * lane + 1] = a1;
         __syncthreads();
         if (tid < 128) sy[tid] -= (sp[0][tid] + sp[1][tid]) + (sp[2][tid] + sp[3][tid]);
@@ -276,10 +276,8 @@ __global__ __launch_bounds__(256) void bwd_sweep_kernel(BwdSweepArgs g) {      /
         double acc = 0.0;
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
-            double2_t lv;
-            __builtin_memcpy(&lv, &l2[u], 16);
-            acc = fma(lv[0], sy[half * 64 + 2 * u], acc);
-            acc = fma(lv[1], sy[half * 64 + 2 * u + 1], acc);
+            acc = fma(li[u][0], sy[half * 64 + 2 * u], acc);
+            acc = fma(li[u][1], sy[half * 64 + 2 * u + 1], acc);
         }
         sxv[half][i] = acc;
     }
@@ -357,7 +355,15 @@ __global__ __launch_bounds__(256) void fwd_sweep_kernel(FwdSweepArgs g) {
     };
     const double *Lrow = g.L + (long)r * 128 * g.ldl;
     const double *inv = g.linv + (long)r * 128 * 128;
-    if (r > 0) load_rows(Lrow, g.ldl); else load_rows(inv, 128);
+    // (the inverse of the diagonal block in registers of its own, requested first: see bwd_sweep_kernel)
+    u32x4 li[32];
+    {
+        const double *base = uniform_ptr(inv + (long)wave_u * 32 * 128);
+        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) li[u] = __builtin_amdgcn_raw_buffer_load_b128(src, 16 * lane, u * 1024, 0);
+    }
+    if (r > 0) load_rows(Lrow, g.ldl);
     const double bval = tid < 128 ? g.B[((long)r * 128 + tid) * g.ldb] : 0.0;
     double acc[32][1];
 #pragma unroll
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(256) void fwd_sweep_kernel(FwdSweepArgs g) {
             acc[u][0] = fma(lv[0], y0, acc[u][0]);
             acc[u][0] = fma(lv[1], y1, acc[u][0]);
         }
-        if (c + 1 < r) load_rows(Lrow + (long)(c + 1) * 128, g.ldl); else load_rows(inv, 128);      // on its way while the next y is awaited
+        if (c + 1 < r) load_rows(Lrow + (long)(c + 1) * 128, g.ldl);      // on its way while the next y is awaited
     }
     const int urow = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
     {
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(256) void fwd_sweep_kernel(FwdSweepArgs g) {
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
             double2_t lv;
-            __builtin_memcpy(&lv, &l2[u], 16);
+            __builtin_memcpy(&lv, &li[u], 16);
             acc[u][0] = fma(lv[1], t1, lv[0] * t0);
         }
     }
