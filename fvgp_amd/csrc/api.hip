@@ -942,7 +942,7 @@ int fvgp_hip_panel_potrf_dev(fvgp_handle *h, double *T, int64_t w, int64_t rows,
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
     // the row-sharded driver's stacked panel: ONE resident kernel with a workgroup per block (8-rank emulation at N = 50 000: 93.2 ms
     // against 96.0 with the launch-per-step chain; with a workgroup per block ROW below the square, panel_chain = 2, 100.6)
-    if (h->panel_chain >= 1 && w / TILE <= FVGP_CHAIN_MAX_BLOCKS && rows / TILE <= 1024) { h->chain_alone = h->panel_chain == 2 ? 0 : 1; rc = launch_panel_chain(h, T, n_valid, rows, ldt, 0, w); }
+    if (h->panel_chain >= 1 && w / TILE <= FVGP_CHAIN_MAX_BLOCKS && rows / TILE <= 1024) { h->chain_alone = h->panel_chain == 2 ? 0 : 2; rc = launch_panel_chain(h, T, n_valid, rows, ldt, 0, w); }      // (2: a workgroup per block, but NOT alone: the rank's trailing update runs beside it)
     else rc = panel_factor_nested(h, T, n_valid, rows, ldt, 0, w);   // leaf / TRSM of every row below / in-panel update per 128 columns, in sub-panels of `inner_block`
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(info_dev, h->dinfo, sizeof(int), hipMemcpyDeviceToDevice, h->stream));

@@ -1066,7 +1066,7 @@ int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, i
     } else {
         // a short panel alone on the chip is bound by its chain of leaves: with ONE workgroup per compute unit (16 KB of LDS nobody uses
         // take the second one's room) a leaf, or the solve behind it, never shares its SIMDs with another block's products
-        const unsigned pad_lds = (h->chain_alone && g.rows <= h->chain_single_rows) ? 16384u : 0u;
+        const unsigned pad_lds = (h->chain_alone == 1 && g.rows <= h->chain_single_rows) ? 16384u : 0u;      // (beside an update the padded workgroup would not fit next to an update workgroup)
         hipLaunchKernelGGL(chain_kernel<false>, dim3((unsigned)grid), dim3(512), pad_lds, h->stream, g);
     }
     HIPCHK(hipGetLastError());
