@@ -99,7 +99,14 @@ struct fvgp_handle {
     // the column ticket; option "bwd_sweep"
     double *sweep_gran = nullptr; size_t sweep_gran_cap = 0; unsigned long long sweep_tag = 0; int *sweep_ticket = nullptr; int bwd_sweep = 1, fwd_sweep = 1;
     // the panel chain as one resident kernel per panel (chain.hip): flag words, the launch tag and ticket bases; option "panel_chain"
-    unsigned long long *chain_flags = nullptr, chain_tag = 0, chain_tick = 0; int panel_chain = 1; int chain_alone = 1; int chain_wide = 1; int chain_sleep_rows = 96; int chain_single_rows = 96; int64_t wide_block = 4096, wide_block_big = 4096, wide_threshold = 1 << 30, wide_inner = 2048, wide_inner_rows = 16384; int streams_concurrent = -1;   // -1: not probed yet (chain.hip, chain_streams_concurrent)
+    unsigned long long *chain_flags = nullptr, chain_tag = 0, chain_tick = 0; int panel_chain = 1;
+    int streams_concurrent = -1;      // -1: not probed yet (chain.hip, chain_streams_concurrent)
+    // the default schedule (potrf_driver): panels of `wide_block` columns (`wide_block_big` while more than `wide_threshold` rows remain), each
+    // ONE resident kernel alone on the chip + one trailing update; a panel over >= wide_inner_rows rows in sub-panels of wide_inner columns
+    int chain_wide = 1; int64_t wide_block = 4096, wide_block_big = 4096, wide_threshold = 1 << 30, wide_inner = 2048, wide_inner_rows = 16384;
+    int chain_alone = 1;              // set per factorisation: 1 no update runs beside the panel kernels, 0 look-ahead, 2 the row-sharded driver (a workgroup per block, not alone)
+    int chain_sleep_rows = 96;        // panels of at most this many block rows: early products yield their compute unit to the critical blocks
+    int chain_single_rows = 96;       // ... and run one workgroup per compute unit (alone only)
     int chain_verify = 0; unsigned long long *chain_vhash = nullptr;   // option "chain_verify": payload checksums on every hand-off of the resident panel kernel (chain.hip, VH_*)
     int cols_split = 1; int64_t cols_split_rows = 8192;   // (potrf_driver: the next panel's square is updated first, the rows below it beside its chain, while at most this many rows remain)
     int64_t panel_chain_min = 4096;   // ... for panels with at least this many rows from their first column down (below that the chain runs alone on the chip and the three launches per step are as fast)
