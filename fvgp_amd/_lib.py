@@ -27,7 +27,7 @@ SYMBOLS = [
     "fvgp_hip_potrf", "fvgp_hip_potrf_dev", "fvgp_hip_potrs", "fvgp_hip_logdet", "fvgp_hip_potri", "fvgp_hip_trsm_lower",
     "fvgp_hip_loglik", "fvgp_hip_loglik_grad", "fvgp_hip_grad_trace", "fvgp_hip_posterior", "fvgp_hip_gemm",
     "fvgp_hip_mfma_selftest", "fvgp_hip_mfma_peak", "fvgp_hip_symmetrize", "fvgp_hip_add_lower", "fvgp_hip_trace_dot", "fvgp_hip_colsumsq", "fvgp_hip_add_matrix", "fvgp_hip_dot", "fvgp_hip_coldot",
-    "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
+    "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_debug_chain_ticket", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
     "fvgp_hip_grad_trace_cols", "fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy", "fvgp_hip_ipc_window", "fvgp_hip_comm_init_ipc", "fvgp_hip_all_reduce",
     "fvgp_hip_all_gather", "fvgp_hip_comm_profile", "fvgp_hip_dist_workspace", "fvgp_hip_loglik_dist", "fvgp_hip_dist_scratch", "fvgp_hip_solve_dist",
     "fvgp_hip_posterior_dist", "fvgp_hip_grad_dist",
@@ -209,12 +209,14 @@ def lib():
     L.fvgp_hip_syrk_rowshard.argtypes = [c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i]
     L.fvgp_hip_debug_tile_map.argtypes = [c_i, c_i, c_i, c_i, c_i, P_i, P_i, c_l]
     L.fvgp_hip_debug_tile_map.restype = c_l
+    L.fvgp_hip_debug_chain_ticket.argtypes = [c_i, c_i, c_i, P_i]
+    L.fvgp_hip_debug_chain_ticket.restype = c_i
     L.fvgp_hip_debug_tile_table.argtypes = [c_i, c_i, c_i, c_i, c_i, P_i, c_l]
     L.fvgp_hip_debug_tile_table.restype = c_l
     L.fvgp_hip_grad_trace_cols.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_l, c_l, c_l, c_p, c_l, c_p, P_d]
     bind_dist(L)
     for s in SYMBOLS:
-        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_workspace_bytes", "fvgp_hip_dist_scratch"):
+        if s not in ("fvgp_hip_last_error_string", "fvgp_hip_padded_dim", "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_debug_chain_ticket", "fvgp_hip_workspace_bytes", "fvgp_hip_dist_scratch"):
             getattr(L, s).restype = c_i
     _lib = L
     return L

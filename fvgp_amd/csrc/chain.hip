@@ -75,6 +75,21 @@ struct ChainArgs {
 constexpr int VH_ROWS = 1024;           // block rows that may have a workgroup per block
 constexpr int VH_ROW = 0, VH_LEAF = VH_ROWS * 32, VH_BAD = VH_LEAF + 32, VH_CHECKS = VH_BAD + 1, VH_WORDS = VH_CHECKS + 1;
 
+// ticket -> role of the resident panel kernel (also replayed on the host: fvgp_hip_debug_chain_ticket).  The first
+// nsq = n n2 - n (n - 1) / 2 tickets are the blocks (row, k), k <= row < n2, of the first n2 block rows, block column after block
+// column: kind 0 = diagonal block (row == k), 1 = block below it.  Later tickets: kind 2, a whole block row (row = n2 + ticket - nsq,
+// then every `stride`-th row).  What a role waits for always has a LOWER ticket:
+//   (row, k), row > k : (row, j) and (k, j) for j < k -- block column j < k --, and the leaf of (k, k), the first ticket of column k;
+//   (k, k)            : (k, j), j < k;      a block row: (k, j) for j < k < n and every leaf.
+__host__ __device__ inline void chain_ticket_role(const int n, const int n2, const int t, int *kind, int *row, int *col) {
+    const int nsq = n * n2 - n * (n - 1) / 2;
+    if (t < nsq) {
+        int k = 0, off = 0;
+        while (t >= off + (n2 - k)) { off += n2 - k; ++k; }
+        *row = k + (t - off); *col = k; *kind = *row == k ? 0 : 1;
+    } else { *kind = 2; *row = n2 + (t - nsq); *col = -1; }
+}
+
 constexpr int FL = 16;                // 64-bit words between two flags
 constexpr int F_TICKET = 0, F_LEAF = 1, F_ABORT = 2, F_COLS = 40, F_LCOL = 41, F_XCOL = 42, F_DUMMY = 75, F_ROW = 96;      // F_XCOL: one per block row of the square (32), F_ROW: one per block row with a workgroup per block (VH_ROWS)
 constexpr int FLAG_LINES = F_ROW + VH_ROWS;
@@ -761,11 +776,7 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
     const int n2 = g.n2;
     const int nsq = n * n2 - n * (n - 1) / 2;
     int bk = 0, brow = 0;
-    if (t < nsq) {
-        int off = 0;
-        while (t >= off + (n2 - bk)) { off += n2 - bk; ++bk; }
-        brow = bk + (t - off);
-    }
+    if (t < nsq) { int kind; chain_ticket_role(n, n2, t, &kind, &brow, &bk); }
     if (t < nsq && brow != bk) {
         // ---- block (row, k) of the panel below the diagonal: A[row,k] - sum_{j<k} L[row,j] L[k,j]^T, one K = 128 product per
         //      block column j as soon as both operands are published (the sum stays in registers), then the solve against L_kk
@@ -1083,5 +1094,13 @@ int chain_verify_counts(fvgp_handle *h, unsigned long long *out2) {
     HIPCHK(hipMemcpy(w, h->chain_vhash + VH_BAD, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     out2[0] = w[0] + w[2]; out2[1] = w[1] + w[3];
     HIPCHK(hipMemset(h->chain_vhash + VH_BAD, 0, 4 * sizeof(unsigned long long)));
+    return 0;
+}
+
+// host-only replay of the panel kernel's ticket -> role map for a panel of n block columns whose first n2 block rows have a workgroup per
+// block (chain_ticket_role): out3 = {kind, block row, block column}
+extern "C" int fvgp_hip_debug_chain_ticket(int n, int n2, int ticket, int *out3) {
+    if (n < 1 || n > FVGP_CHAIN_MAX_BLOCKS || n2 < n || ticket < 0 || !out3) return -1;
+    chain_ticket_role(n, n2, ticket, &out3[0], &out3[1], &out3[2]);
     return 0;
 }

@@ -340,6 +340,11 @@ int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int scale, 
  * on XCD b % 8; each XCD gets a contiguous, equally long run of the REAL tiles in super-tile order).  Entries are
  * (tile row << 16) | tile col, or -1; returns the grid size, fills min(grid, cap) entries. */
 int64_t fvgp_hip_debug_tile_table(int tiles_m, int tiles_n, int lower, int scale, int off, int *out, int64_t cap);
+/* host-only: the role a start-order ticket gets in the resident panel kernel (csrc/chain.hip) for a panel of n block columns whose
+ * first n2 >= n block rows have a workgroup per 128 x 128 block: out3 = {kind, block row, block column}, kind 0 = diagonal block
+ * (updates it, then its leaf), 1 = block below the diagonal (products, then the solve behind the leaf), 2 = a whole block row
+ * (column = -1).  tests/test_host_logic.py replays every role's waits on it: a workgroup only ever waits for LOWER tickets. */
+int fvgp_hip_debug_chain_ticket(int n, int n2, int ticket, int *out3);
 /* diagnostic: blocks x 256 threads each issue iters x 16 register-only fp64 MFMAs (2048 flop each per wave);
  * out needs blocks*256 doubles.  Gives the sustained fp64 MFMA ceiling of the device. */
 int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);

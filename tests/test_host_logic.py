@@ -87,6 +87,37 @@ def test_gemm_tile_map_covers_each_tile_once(L, case):
         assert abs(i0 - i1) <= 8 and abs(j0 - j1) <= 8
 
 
+@pytest.mark.parametrize("n,n2", [(1, 1), (1, 9), (4, 4), (4, 32), (8, 8), (8, 57), (16, 16), (16, 235), (32, 32), (32, 63), (32, 391)])
+def test_panel_kernel_roles_only_wait_for_lower_tickets(L, n, n2):
+    """The resident panel kernel (csrc/chain.hip) deals its roles by a start-order ticket and never needs all workgroups resident: a
+    workgroup may only wait for what a LOWER ticket produces.  Host replay of the ticket -> role map (the function the kernel calls):
+    every block of the first n2 block rows has exactly one ticket, and for every role each thing it waits for -- the blocks left of it
+    in its row and in the row of its column's diagonal block, the leaf of that diagonal block; for a whole block row: every block
+    of the square and every leaf -- has a lower ticket."""
+    nsq = n * n2 - n * (n - 1) // 2
+    out = (ctypes.c_int * 3)()
+    ticket = {}
+    for t in range(nsq + 3):
+        assert L.fvgp_hip_debug_chain_ticket(n, n2, t, out) == 0
+        kind, row, col = out[0], out[1], out[2]
+        if t < nsq:
+            assert kind in (0, 1) and 0 <= col < n and col <= row < n2 and (kind == 0) == (row == col)
+            assert (row, col) not in ticket
+            ticket[(row, col)] = t
+        else:
+            assert kind == 2 and row == n2 + (t - nsq) and col == -1
+    assert set(ticket) == {(r, k) for k in range(n) for r in range(k, n2)}
+    for (row, k), t in ticket.items():
+        if row == k:
+            waits = [(k, j) for j in range(k)]                                   # the solved blocks of its row, column by column
+        else:
+            waits = [(row, j) for j in range(k)] + [(k, j) for j in range(k)] + [(k, k)]      # both operands of its products; the leaf
+        for w in waits:
+            assert ticket[w] < t, (n, n2, (row, k), "waits for", w)
+    # a whole block row (tickets >= nsq) waits for blocks of the square and for leaves only
+    assert max(ticket.values()) == nsq - 1
+
+
 @pytest.mark.parametrize("case", [(391, 391, 1), (131, 131, 1), (100, 100, 1), (64, 64, 1), (375, 16, 1), (40, 300, 0),
                                          (47, 359, 2, 8, -8), (19, 135, 2, 8, -8), (9, 55, 2, 8, -8), (50, 391, 2, 8, -5), (3, 5, 2, 4, 0)])
 def test_balanced_tile_table(L, case):
