@@ -6,6 +6,7 @@ covariance assembly (+noise) -> blocked Cholesky -> two triangular solves -> log
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (no launcher: bench.py starts its N ranks itself, see launch_ranks)
 
 N = 1: the fused single-GPU evaluation (fvgp_hip_loglik).  The line also carries, measured outside the timed
 region, the other BASELINE.json configurations that fit one GPU ("configs") and the CPU restatement of the
@@ -109,6 +110,25 @@ def cpu_baseline(n_full, d, sample_n):
             "oracle_theta": theta.tolist()}
 
 
+def cpu_small_sizes(small):
+    """CPU leg, the training loop's sizes: the oracle on this host at the size and theta of every `small_N` record (milliseconds of
+    work; best of three), written beside the GPU number -- at C1's size (N=500) the line then shows GPU and CPU side by side."""
+    from oracle import fvgp_oracle as orc
+    for key, rec in small.items():
+        if not isinstance(rec, dict) or "loglik_ms" not in rec:
+            continue
+        n, d = (int(t.split("=")[1]) for t in key.split())
+        x, y = synth(n, d)
+        ths = np.array([1.0] + [0.2 if d == 1 else 0.3] * d) * 1.01
+        cpu, cpu_ll = 1e9, None
+        for _ in range(3 if n <= 2000 else 1):
+            t0 = time.perf_counter()
+            cpu_ll, _ = orc.log_likelihood_once(x, y, np.full(n, 0.01), ths, "rbf_ard")
+            cpu = min(cpu, time.perf_counter() - t0)
+        rec.update(cpu_ms=1e3 * cpu, cpu_threads=_blas_threads(), cpu_over_gpu=1e3 * cpu / rec["loglik_ms"],
+                   rel_diff_vs_oracle=abs(rec["loglik"] - cpu_ll) / abs(cpu_ll))
+
+
 def headline_parity(cb, n, d, hip_at_n, device):
     """The HIP path against the log-likelihood the CPU leg's oracle run computed -- same synthetic inputs, same theta, outside the
     timed region.  When the oracle ran the full workload the HIP value is the one evaluated on the bench's own resident buffers
@@ -192,24 +212,37 @@ def config_records():
     gp.posterior_covariance(xp)
     torch.cuda.synchronize()
     first_cov = 1e3 * (time.perf_counter() - t0)
+    def cov_bound_ms(p):          # L^-1 k: n^2 p flop; S = kk - V^T V on the lower half: n p^2 flop
+        return 1e3 * (float(n) * n * p + float(n) * p * p) / peak
+
     out["C2"] = {"workload": "N=20000 d=3 RBF: log_likelihood(theta); posterior mean / covariance at P=1000",
                  "loglik_ms": ll, "bound_ms": 1e3 * n ** 3 / 3 / peak, "frac": (1e3 * n ** 3 / 3 / peak) / ll,
                  "posterior_mean_ms": best(lambda: gp.posterior_mean(xp)),
                  "posterior_cov_ms": best(lambda: gp.posterior_covariance(xp)),
                  "posterior_cov_first_call_after_new_factor_ms": first_cov,
                  "posterior_cov_bound_ms": 1e3 * (n * n * 1000.0 + 2.0 * n * 1000.0 ** 2) / peak}
+    out["C2"]["posterior_cov_frac"] = out["C2"]["posterior_cov_bound_ms"] / out["C2"]["posterior_cov_ms"]
+    # variance_only in the default 'Chol' mode still forms S, as the reference does (gp_posterior.py:246); many points go through the
+    # device in chunks of 1024 with S assembled on the host block row by block row (fvgp_amd/gp.py _posterior_chunked)
+    out["C2"]["posterior_cov_variance_only_ms"] = best(lambda: gp.posterior_covariance(xp, variance_only=True))
+    xp4 = np.random.default_rng(3).random((4000, 3))
+    out["C2"]["posterior_cov_p4000_ms"] = best(lambda: gp.posterior_covariance(xp4))
+    out["C2"]["posterior_cov_p4000_bound_ms"] = cov_bound_ms(4000)
+    out["C2"]["posterior_cov_p4000_frac"] = cov_bound_ms(4000) / out["C2"]["posterior_cov_p4000_ms"]
+    out["C2"]["posterior_cov_p4000_chunk_groups"] = gp._posterior_groups
     del gp
     torch.cuda.empty_cache()
     _progress("C2 done")
     # the training loop's sizes (gp_mcmc.py:96-224 calls log_likelihood(theta) 10 000 times; C1 is N=500, d=1): wall time of the
     # public call, best of five
     small = {}
-    for n, d in ((500, 1), (2000, 3), (8000, 3)):
+    for n, d in ((500, 1), (2000, 3), (4000, 3), (8000, 3), (12000, 3)):
         x, y = synth(n, d)
         ths = np.array([1.0] + [0.2 if d == 1 else 0.3] * d)
         gp = fvgp_amd.GP(x, y, init_hyperparameters=ths, noise_variances=np.full(n, 0.01), kernel_function="rbf_ard")
         ms = best(lambda: gp.log_likelihood(ths * 1.01), reps=5)
         small[f"N={n} d={d}"] = {"loglik_ms": ms, "bound_ms": 1e3 * n ** 3 / 3 / peak, "frac": (1e3 * n ** 3 / 3 / peak) / ms}
+        small[f"N={n} d={d}"]["loglik"] = gp.log_likelihood(ths * 1.01)       # (checked against the oracle by the CPU leg)
         del gp
     out["small_N"] = {"workload": "RBF log_likelihood(theta) at the training loop's sizes (C1: N=500 d=1)", **small}
     torch.cuda.empty_cache()
@@ -385,12 +418,101 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d, 
         secs = float(tt.item())
     state["replicas"] = {"value": world * len(thetas) / secs, "evals_per_gpu": len(thetas), "ms_per_step": 1e3 * secs / len(thetas)}
     # world == 1 (`--gpus 1 --mode sharded`): the multi-rank code path on one GPU, its collectives issued through RCCL
-    # (a one-rank communicator) unless --backend says otherwise
+    # (a one-rank communicator) unless --backend / --collectives say otherwise
     force = dist is None
-    with _stdout_to_stderr():
-        gp = ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=args.outer_block or 1024,
-                       rank=None if dist is not None else 0, world=None if dist is not None else 1,
-                       force_collectives=force, collectives=("rccl" if args.backend == "nccl" else "torch") if force else "auto")
+    base = "rccl" if args.backend == "nccl" else "torch"
+    candidates = [base, "ipc"] if args.collectives == "auto" else [args.collectives]
+    if world == 1 and args.collectives == "auto":
+        candidates = [base]                                        # one rank has no peer to pull from: nothing to compare
+
+    def all_ranks_ok(ok):
+        """True when `ok` holds on EVERY rank (a collective of its own: every rank decides the same way)"""
+        if dist is None:
+            return bool(ok)
+        tt = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()) == 0.0
+
+    def max_over_ranks(v):
+        if dist is None:
+            return float(v)
+        tt = torch.tensor([v], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def build(kind):
+        with _stdout_to_stderr():
+            return ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=args.outer_block or 1024,
+                             rank=None if dist is not None else 0, world=None if dist is not None else 1,
+                             force_collectives=force, collectives=kind)
+
+    def coll_record(gp, evals):
+        """the collectives of the last `evals` evaluations (events on the chain stream around every call): per kind the calls, the
+        bytes this rank received, the milliseconds, and the rate per peer link against the 153 GB/s of one xGMI link -- a direct
+        gather pulls from all world - 1 peers at once, a ring moves everything over one link: both are priced per link"""
+        rec = {}
+        peers = max(world - 1, 1)
+        for kind, (calls, nbytes, ms) in gp.collective_summary().items():
+            if calls:
+                gbps = nbytes / (ms * 1e-3) / 1e9 if ms > 0 and nbytes > 0 else None
+                rec[kind] = {"calls_per_eval": calls / evals, "bytes_received_per_rank_per_eval": nbytes / evals,
+                             "ms_on_chain_stream_per_eval": ms / evals, "ms_per_call": ms / calls,
+                             "GBps_per_rank": gbps, "GBps_per_peer_link": gbps / peers if gbps else None,
+                             "frac_of_one_xgmi_link_153": gbps / peers / 153.0 if gbps else None,
+                             "frac_of_xgmi_7x153": gbps / XGMI_GBPS_PER_GPU if gbps else None}
+        return rec
+
+    # --collectives auto: the same two evaluations through each candidate, timed the way the headline is (barrier + synchronise on
+    # both sides, max over ranks); the faster one carries the timed region below
+    trial, done_ok = {}, []
+    for kind in candidates:
+        rec = {}
+        try:
+            g = build(kind)
+            ok = True
+        except Exception as e:                                      # noqa: BLE001 -- recorded; the other candidate still runs
+            g, ok = None, False
+            rec["error"] = f"{type(e).__name__}: {e}"[:300]
+        if not all_ranks_ok(ok):
+            rec.setdefault("error", "communicator construction failed on another rank")
+            trial[kind] = rec
+            if g is not None:
+                g.close()
+            continue
+        try:
+            g.log_likelihood(theta0)                                # first call: scratch growth, tile tables
+            g.ops.set_option("profile", 1)
+            g.collective_summary()
+            sync_all()
+            t0 = time.perf_counter()
+            for t in range(2):
+                lt = g.log_likelihood(theta0 * (1.0 + 0.02 * t))[0]
+            sync_all()
+            rec["ms_per_eval"] = 1e3 * max_over_ranks(time.perf_counter() - t0) / 2
+            rec["collectives"] = coll_record(g, 2)
+            rec["loglik"] = lt
+            g.ops.set_option("profile", 0)
+            ok = True
+        except Exception as e:                                      # noqa: BLE001
+            ok = False
+            rec["error"] = f"{type(e).__name__}: {e}"[:300]
+        if all_ranks_ok(ok):
+            done_ok.append(kind)
+        else:
+            rec.setdefault("error", "the evaluation failed on another rank")
+            rec.pop("ms_per_eval", None)
+        trial[kind] = rec
+        # one communicator at a time on the handle (binding the next one destroys this one): the chosen backend is built again below
+        g.close()
+        del g
+        torch.cuda.empty_cache()
+    if not done_ok:
+        raise RuntimeError("no collective backend completed an evaluation: " + json.dumps(trial))
+    chosen = min(done_ok, key=lambda k: trial[k]["ms_per_eval"])
+    gp = build(chosen)
+    comm = gp.comm_info()
+    if dist is not None:
+        comm["torch_distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
     for t in range(args.warmup):
         gp.log_likelihood(theta0 * (1.0 + 0.02 * t))
     H = gp.ops
@@ -402,22 +524,12 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d, 
     for t in range(args.steps):
         ll, logdet, quad = gp.log_likelihood(theta0 * (1.0 + 0.02 * (args.warmup + t)))
     sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     prof = H.get_profile()
-    # the collectives of the timed evaluations (events on the chain stream around every call)
-    coll = {}
-    for kind, (calls, nbytes, ms) in gp.collective_summary().items():
-        if calls:
-            coll[kind] = {"calls_per_eval": calls / args.steps, "bytes_received_per_rank_per_eval": nbytes / args.steps,
-                          "ms_on_chain_stream_per_eval": ms / args.steps,
-                          "GBps_per_rank": nbytes / (ms * 1e-3) / 1e9 if ms > 0 and nbytes > 0 else None,
-                          "frac_of_xgmi_7x153": nbytes / (ms * 1e-3) / 1e9 / XGMI_GBPS_PER_GPU if ms > 0 and nbytes > 0 else None}
+    coll = coll_record(gp, args.steps)
     H.set_option("profile", 0)
     collectives_via = gp.collectives
+    gp.close()
     del gp
     torch.cuda.empty_cache()
     if rank == 0:
@@ -437,8 +549,16 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d, 
             "rel_diff_vs_single_gpu": abs(ll - vals[0]) / abs(vals[0]),
             "single_gpu_loglik_at_same_theta": vals[0],
             "collectives": coll, "collectives_via": {"rccl": "RCCL called from libfvgp_hip.so on the chain stream (fvgp_hip_comm_init)",
+                                                     "ipc": "direct pulls between IPC-mapped windows on the copy engines (csrc/ipc.hip, fvgp_hip_comm_init_ipc)",
                                                      "torch": "torch.distributed callbacks (gloo test path)"}[collectives_via],
-            "xgmi_peak_GBps_per_gpu": XGMI_GBPS_PER_GPU,
+            "collectives_chosen": collectives_via,
+            # what the communicator says about itself: ncclCommCount / ncclCommUserRank / ncclCommCuDevice for RCCL (not what this
+            # script asked for), the bound rank count for the direct collectives
+            "communicator": comm,
+            "ranks_seen_by_communicator": comm.get("nccl_comm_count", comm.get("nranks_bound")),
+            # --collectives auto: the same two evaluations through each backend before the timed region
+            "collectives_ab": trial,
+            "xgmi_peak_GBps_per_gpu": XGMI_GBPS_PER_GPU, "xgmi_GBps_per_link": 153.0,
             "roofline": {"kernel": "gemm_f64_kernel<0, 0, 1> (row-sharded trailing update, rank 0's launches)", "bound": "mfma",
                          "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
@@ -452,6 +572,53 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d, 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): THIS process -- which has not imported torch and has
+    not touched a GPU -- starts the N ranks as children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torchrun would set them,
+    rendezvous on 127.0.0.1), relays rank 0's single JSON line on stdout (everything else the ranks print goes to stderr) and
+    returns the worst exit code.  A rank that dies takes the others with it after a grace period: no orphan keeps a GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", FVGP_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
+
+    def relay():
+        for line in procs[0].stdout:
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    first_failure = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        failed = [p for p in procs if p.poll() not in (None, 0)]
+        if failed and first_failure is None:
+            first_failure = time.time()
+        if first_failure is not None and time.time() - first_failure > 60.0:
+            for p in procs:                       # exactly the processes started here
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(5.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    t.join(timeout=10.0)
+    codes = [p.returncode for p in procs]
+    worst = next((c for c in codes if c not in (0, None)), 0)
+    if worst:
+        print(f"[bench] rank exit codes {codes}", file=sys.stderr, flush=True)
+    return worst if worst > 0 else (128 - worst if worst < 0 else 0)
 
 
 def main():
@@ -468,6 +635,11 @@ def main():
                          "factors; strong scaling) or independent replicas (one theta stream per GPU; weak scaling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for tests that "
                                                       "put several ranks on one GPU)")
+    ap.add_argument("--collectives", choices=["auto", "rccl", "ipc", "torch"], default="auto",
+                    help="N>1: who moves the panel factors.  rccl = RCCL called from the library on the chain stream; ipc = direct pulls "
+                         "between IPC-mapped windows on the copy engines (csrc/ipc.hip); torch = torch.distributed callbacks (gloo "
+                         "tests); auto = two evaluations through the backend's own (rccl for nccl, torch for gloo) AND two through "
+                         "ipc, both recorded in the line, the faster one timed")
     ap.add_argument("--sharded-timeout", type=float, default=600.0)
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="0 = the full workload if the host can hold it, else N=18000 scaled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -478,16 +650,28 @@ def main():
         ap.error("--steps must be >= 1 and --warmup >= 0")
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        # no launcher around this process.  --gpus 1: run here.  --gpus N > 1: start the N ranks as children of this process,
+        # which has neither imported torch nor touched a GPU (never an exec from a process that has)
+        if args.gpus > 1:
+            raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+        world, rank = 1, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        if args.gpus != world:
+            # a launcher started `world` ranks: the line would say n_gpus = world whatever --gpus asked for
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: the two must agree")
     import torch
     from fvgp_amd import _lib
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("FVGP_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # FVGP_DEVICE: ranks sharing a GPU (tests)
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: device {local} asked for, {torch.cuda.device_count()} visible (--gpus {args.gpus} needs that many GPUs on this node)")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -543,7 +727,7 @@ def main():
     for t in range(args.warmup):
         H.loglik(0, xd, theta_at(t), vd, ymd, KV, alpha)
     H.set_option("profile", 1)
-    prof = {"launches": 0.0, "ms": 0.0, "flops": 0.0, "potrf_ms": 0.0, "kmat_ms": 0.0, "kmat_bytes": 0.0, "tail_ms": 0.0}
+    prof = {"launches": 0.0, "ms": 0.0, "flops": 0.0, "potrf_ms": 0.0, "kmat_ms": 0.0, "kmat_bytes": 0.0, "tail_ms": 0.0, "bytes": 0.0}
     sync_all()
     t0 = time.perf_counter()
     for t in range(args.steps):
@@ -586,7 +770,10 @@ def main():
         out = {
             "metric": "log_marginal_likelihood_evals_per_sec", "value": evals / elapsed, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # one evaluation at a time: at N > 1 the SAME evaluation is row-sharded over the ranks (total work fixed: "strong");
+            # --mode replicas gives every GPU its own theta stream instead (work grows with N: "weak")
+            "higher_is_better": True, "scaling": "weak" if (world > 1 or args.mode == "replicas") else "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N={n} d={d} RBF(ARD) log_likelihood(theta): K-assembly+noise, Cholesky, "
                                    f"2 triangular solves, log-det", "n": n, "d": d, "kernel": "rbf_ard",
                        "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (one theta stream per GPU)"},
@@ -606,8 +793,13 @@ def main():
                 "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                 "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(prof["launches"], 1.0),
                 "algorithmic_flops_per_launch": prof["flops"] / max(prof["launches"], 1.0),
+                # every C tile of the launch read and written once + the panel's rows read once (csrc/api.hip lower_bytes); the
+                # kernel is MFMA-bound: `traffic` above this is operand re-fetch past the L2, at ~1.4 TB/s of an 8 TB/s fabric
+                "algorithmic_bytes_per_launch": prof["bytes"] / max(prof["launches"], 1.0),
+                "traffic_over_algorithmic": (traffic / (prof["bytes"] / max(prof["launches"], 1.0))) if traffic and prof["bytes"] > 0 else None,
             },
         }
+        out["k_assembly"]["frac_of_achievable_6290"] = out["k_assembly"]["achieved"] / 6290.0   # the guide's measured streaming rate
     del KV, alpha
     H.close()
     torch.cuda.empty_cache()
@@ -620,6 +812,8 @@ def main():
         if not args.no_cpu_baseline:                                # the CPU leg is timed on rank 0 at N=1 only
             _progress("configs done; the CPU leg (the oracle on this host, about a minute and a half at N = 50000) starts")
             out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_sample_n)
+            if isinstance(out.get("configs", {}).get("small_N"), dict):
+                cpu_small_sizes(out["configs"]["small_N"])
             _progress("CPU leg done")
             out["headline_parity"] = headline_parity(out["cpu_baseline"], n, d, hip_theta0, local)
     if rank == 0:

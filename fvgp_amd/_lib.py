@@ -30,7 +30,7 @@ SYMBOLS = [
     "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_debug_chain_ticket", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
     "fvgp_hip_grad_trace_cols", "fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy", "fvgp_hip_ipc_window", "fvgp_hip_comm_init_ipc", "fvgp_hip_all_reduce",
     "fvgp_hip_all_gather", "fvgp_hip_comm_profile", "fvgp_hip_dist_workspace", "fvgp_hip_loglik_dist", "fvgp_hip_dist_scratch", "fvgp_hip_solve_dist",
-    "fvgp_hip_posterior_dist", "fvgp_hip_grad_dist",
+    "fvgp_hip_posterior_dist", "fvgp_hip_grad_dist", "fvgp_hip_loglik_rows", "fvgp_hip_get_profile_ex", "fvgp_hip_comm_info", "fvgp_hip_comm_check",
 ]
 
 
@@ -62,6 +62,10 @@ def bind_dist(L):
         L.fvgp_hip_comm_unique_id.argtypes = [c_p]
         L.fvgp_hip_comm_init.argtypes = [c_p, c_p, c_i, c_i]
         L.fvgp_hip_comm_profile.argtypes = [c_p, P_d]
+    if hasattr(L, "fvgp_hip_comm_info"):
+        L.fvgp_hip_comm_info.argtypes = [c_p, ctypes.POINTER(c_l)]
+        L.fvgp_hip_comm_check.argtypes = [c_p]
+        L.fvgp_hip_comm_info.restype = L.fvgp_hip_comm_check.restype = c_i
     L.fvgp_hip_comm_init_callbacks.argtypes = [c_p, ctypes.POINTER(Collectives), c_i, c_i]
     if hasattr(L, "fvgp_hip_ipc_window"):
         L.fvgp_hip_ipc_window.argtypes = [c_p, c_l, c_p]
@@ -189,6 +193,8 @@ def lib():
     L.fvgp_hip_logdet.argtypes = [c_p, c_p, c_l, c_l, P_d]
     L.fvgp_hip_potri.argtypes = [c_p, c_p, c_l, c_l, c_p, c_l]
     L.fvgp_hip_loglik.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_p, c_i, c_p, c_l, c_p, P_d, P_i]
+    L.fvgp_hip_loglik_rows.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_p, c_i, c_p, c_l, c_l, c_p, P_d, P_i]
+    L.fvgp_hip_get_profile_ex.argtypes = [c_p, P_d]
     L.fvgp_hip_loglik_grad.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_i, c_i, c_p, c_l, c_p, c_l, P_d]
     L.fvgp_hip_grad_trace.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_l, c_p, c_l, c_p, P_d]
     L.fvgp_hip_posterior.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_l, c_p, c_i, c_p, c_l,
@@ -328,10 +334,10 @@ class Handle(DistCalls):
         _check(lib().fvgp_hip_invalidate_factor(self._h), "fvgp_hip_invalidate_factor")
 
     def get_profile(self):
-        out = (ctypes.c_double * 8)()
-        _check(lib().fvgp_hip_get_profile(self._h, out), "fvgp_hip_get_profile")
+        out = (ctypes.c_double * 16)()
+        _check(lib().fvgp_hip_get_profile_ex(self._h, out), "fvgp_hip_get_profile_ex")
         return {"launches": out[0], "ms": out[1], "flops": out[2], "potrf_ms": out[3],
-                "kmat_ms": out[4], "kmat_bytes": out[5], "tail_ms": out[6], "host_enqueue_ms": out[7]}
+                "kmat_ms": out[4], "kmat_bytes": out[5], "tail_ms": out[6], "host_enqueue_ms": out[7], "bytes": out[8]}
 
     def chain_verify_counts(self):
         """(mismatches, comparisons) of the resident panel kernel's hand-off checksums since the last call (option "chain_verify")"""
@@ -391,13 +397,19 @@ class Handle(DistCalls):
         _check(lib().fvgp_hip_potri(self._h, _ptr(L), int(n), L.stride(0), _ptr(work), work.stride(0)), "fvgp_hip_potri")
 
     def loglik(self, kernel_id, x, theta, vdiag, ymean, KV, alpha):
+        """fvgp_hip_loglik_rows: the scratch's ROWS are passed as the tensor has them (KV.shape[0]), never inferred from its stride --
+        the forward solve is fused for every n when KV is a square of loglik_dim(n, ncol)"""
         t, tp, nt = _theta(theta)
         out = (ctypes.c_double * 3)()
         info = ctypes.c_int(0)
         n, d = x.shape
-        _check(lib().fvgp_hip_loglik(self._h, int(kernel_id), _ptr(x), n, d, tp, nt, _ptr(vdiag), _ptr(ymean),
-                                     ymean.shape[1], _ptr(KV), KV.stride(0), _ptr(alpha), out, ctypes.byref(info)),
-               "fvgp_hip_loglik")
+        if KV.dim() != 2 or KV.stride(1) != 1 or KV.shape[1] < pad128(n) or KV.shape[0] < pad128(n):
+            raise ValueError(f"loglik: KV must be a row-major 2-d tensor of at least {pad128(n)} x {pad128(n)}, got {tuple(KV.shape)} strides {KV.stride()}")
+        # the extra block row is only claimed when the tensor owns those rows AND columns (a column slice with a wide stride does not)
+        rows = KV.shape[0] if KV.shape[1] >= loglik_dim(n, ymean.shape[1]) else pad128(n)
+        _check(lib().fvgp_hip_loglik_rows(self._h, int(kernel_id), _ptr(x), n, d, tp, nt, _ptr(vdiag), _ptr(ymean),
+                                          ymean.shape[1], _ptr(KV), rows, KV.stride(0), _ptr(alpha), out, ctypes.byref(info)),
+               "fvgp_hip_loglik_rows")
         return out[0], out[1], out[2], info.value
 
     def loglik_grad(self, kernel_id, x, theta, alpha, ncol, component, KV, work):
@@ -463,6 +475,18 @@ class Handle(DistCalls):
     @staticmethod
     def _dist_check(rc, what):
         _check(rc, what)
+
+    def comm_info(self):
+        """the handle's communicator as it reports itself (fvgp_hip_comm_info)"""
+        out = (ctypes.c_int64 * 8)()
+        _check(lib().fvgp_hip_comm_info(self._h, out), "fvgp_hip_comm_info")
+        info = {"kind": {0: "none", 1: "rccl", 2: "ipc", 3: "callbacks"}[int(out[0])], "nranks_bound": int(out[1]), "rank_bound": int(out[2])}
+        if out[0] == 1:
+            info.update(nccl_comm_count=int(out[3]), nccl_comm_user_rank=int(out[4]), nccl_comm_cu_device=int(out[5]), rccl_version=int(out[6]))
+        return info
+
+    def comm_check(self):
+        _check(lib().fvgp_hip_comm_check(self._h), "fvgp_hip_comm_check")
 
     def comm_profile(self):
         out = (ctypes.c_double * 6)()

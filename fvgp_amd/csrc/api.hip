@@ -119,7 +119,7 @@ int fvgp_hip_stream_destroy(void *stream) {
 int fvgp_hip_sync(fvgp_handle *h) {
     if (!h) return -1;
     HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
+    return fvgp_ipc_check(h);
 }
 
 int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
@@ -212,6 +212,13 @@ int fvgp_hip_get_profile(fvgp_handle *h, double *out) {
     }
     out[0] = h->prof_launches; out[1] = h->prof_ms; out[2] = h->prof_flops; out[3] = h->prof_total_ms;
     out[4] = h->prof_kmat_ms; out[5] = h->prof_kmat_bytes; out[6] = h->prof_tail_ms; out[7] = h->prof_host_enqueue_ms;
+    return 0;
+}
+
+int fvgp_hip_get_profile_ex(fvgp_handle *h, double *out16) {
+    int rc = fvgp_hip_get_profile(h, out16); if (rc) return rc;
+    for (int i = 8; i < 16; ++i) out16[i] = 0.0;
+    out16[8] = h->prof_bytes;
     return 0;
 }
 
@@ -471,6 +478,13 @@ static int panel_factor_any(fvgp_handle *h, double *A, int64_t n, int64_t np, in
     return panel_factor_nested(h, A, n, np, lda, J0, Jend);
 }
 
+// algorithmic bytes of a lower-tile update: every C tile read and written once, the panel's rows (the B operand is the top of A) read once
+static double lower_bytes(int64_t M, int64_t N, int64_t K) {
+    const double tm = (double)(M / TILE), tn = (double)(N / TILE);
+    const double tiles = tn * (tn + 1.0) * 0.5 + (tm - tn) * tn;
+    return tiles * 128.0 * 128.0 * 8.0 * 2.0 + (double)M * (double)K * 8.0;
+}
+
 static double lower_flops(int64_t M, int64_t N, int64_t K) {     // algorithmic flops of a lower-tile update
     const double tm = (double)(M / TILE), tn = (double)(N / TILE);
     const double tiles = tn * (tn + 1.0) * 0.5 + (tm - tn) * tn;
@@ -499,7 +513,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     HIPCHK(hipMemsetAsync(h->dinfo, 0, sizeof(int), h->stream));
     const int64_t NB = h->outer_block;
     size_t nev = 0;
-    h->ev_flops.clear();
+    h->ev_flops.clear(); h->ev_bytes.clear();
     hipEvent_t e_begin = nullptr, e_end = nullptr;
     auto get_event = [&](hipEvent_t *e) -> int {
         if (nev >= h->ev.size()) { hipEvent_t x; HIPCHK(hipEventCreate(&x)); h->ev.push_back(x); }
@@ -518,6 +532,7 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
             // only launches of the kernel the roofline names count (sub-round updates run the small-tile kernel): 0 flops = skipped
             r = get_event(&e1); if (r) return r; HIPCHK(hipEventRecord(e1, h->stream));
             h->ev_flops.push_back(big ? lower_flops(np - c0, c1 - c0, Jend - J0) : 0.0);
+            h->ev_bytes.push_back(big ? lower_bytes(np - c0, c1 - c0, Jend - J0) : 0.0);
         }
         return 0;
     };
@@ -619,12 +634,12 @@ static int potrf_driver(fvgp_handle *h, double *A, int64_t n, int64_t lda, int *
     if (info_host) *info_host = info;
     h->winv_ok = false; h->linv_L = skip_inverses ? nullptr : A; h->linv_n = n; h->linv_ld = lda;
     if (h->profile) {
-        h->prof_launches = 0; h->prof_ms = 0; h->prof_flops = 0;
+        h->prof_launches = 0; h->prof_ms = 0; h->prof_flops = 0; h->prof_bytes = 0;
         for (size_t i = 0; i < h->ev_flops.size(); ++i) {
             if (h->ev_flops[i] <= 0.0) continue;
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, h->ev[1 + 2 * i], h->ev[2 + 2 * i]));
-            h->prof_ms += ms; h->prof_flops += h->ev_flops[i]; h->prof_launches += 1.0;
+            h->prof_ms += ms; h->prof_flops += h->ev_flops[i]; h->prof_bytes += h->ev_bytes[i]; h->prof_launches += 1.0;
         }
         float tot = 0.f;
         HIPCHK(hipEventElapsedTime(&tot, e_begin, e_end));
@@ -846,7 +861,7 @@ int fvgp_read_back(fvgp_handle *h, const double *dev, double *host, int count) {
     HIPCHK(hipMemcpyAsync(h->hpin, dev, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int i = 0; i < count; ++i) host[i] = h->hpin[i];
-    return 0;
+    return fvgp_ipc_check(h);       // (direct collectives: a poll that gave up left stale data behind it -- never hand that to the host)
 }
 
 // g_i = 1/2 sum_jk (W_jk - b_j b_k) dK_jk/dtheta_i over the lower triangle of the symmetric W (b may be null):
@@ -1119,6 +1134,14 @@ int fvgp_hip_potri(fvgp_handle *h, double *L, int64_t n, int64_t ldl, double *wo
 int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
                     const double *theta, int ntheta, const double *vdiag, const double *ymean, int ncol,
                     double *KV, int64_t ld, double *alpha, double *out_host, int *info_host) {
+    // the contract of this entry: KV holds padded_dim(n) rows, whatever its leading dimension; nothing below them is touched
+    const int rc = fvgp_hip_loglik_rows(h, kernel_id, x, n, d, theta, ntheta, vdiag, ymean, ncol, KV, pad128(n), ld, alpha, out_host, info_host);
+    return rc <= -13 && rc > -100 ? rc + 1 : rc;        // argument numbers of THIS signature (kv_rows is argument 12 there)
+}
+
+int fvgp_hip_loglik_rows(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                         const double *theta, int ntheta, const double *vdiag, const double *ymean, int ncol,
+                         double *KV, int64_t kv_rows, int64_t ld, double *alpha, double *out_host, int *info_host) {
     if (!h) return -1;
     if (!x) return -3;
     if (n <= 0) return -4;
@@ -1126,9 +1149,10 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     if (!vdiag) { fvgp_set_error("loglik needs the noise variances (vdiag)"); return -8; }
     if (!ymean) return -9;
     if (ncol < 1 || ncol > FVGP_MAX_RHS_VEC) { fvgp_set_error("1 <= ncol <= 8"); return -10; }
-    int rc = check_square(KV, n, ld, 11, 4, 12);
+    int rc = check_square(KV, n, ld, 11, 4, 13);
     if (rc) return rc;
-    if (!out_host) return -14;
+    if (kv_rows < pad128(n)) { fvgp_set_error("loglik: the scratch needs at least padded_dim(n) rows"); return -12; }
+    if (!out_host) return -15;
     HIPCHK(hipSetDevice(h->device));
     const int64_t np = pad128(n);
     KmatDesc k{};
@@ -1143,11 +1167,12 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     // forward solve fused into the factorisation: (y-m)^T is appended as rows n..n+ncol-1 of the padded
     // matrix (diagonal entry large enough to keep the block PD); the panel TRSM / trailing updates then
     // leave z^T = (L^-1 (y-m))^T in those rows and quad = |z|^2.  Needs ncol free padding rows: where padded_dim(n) leaves
-    // fewer (n a multiple of 128), the rows go into one more block row -- if the caller's square scratch has it
-    // (ld >= fvgp_hip_loglik_dim(n, ncol)); else the forward solve is a sweep of its own after the factorisation.
+    // fewer (n a multiple of 128), the rows go into one more block row -- if the caller SAYS its scratch has it
+    // (kv_rows and ld >= fvgp_hip_loglik_dim(n, ncol); never inferred from the leading dimension: a pitched buffer or a row slice
+    // of a larger arena holds padded_dim(n) rows only); else the forward solve is a sweep of its own after the factorisation.
     const bool room = (np - n) >= ncol;
     const int64_t npf = room ? np : pad128(n + ncol);
-    const bool fused = room || ld >= npf;
+    const bool fused = room || (kv_rows >= npf && ld >= npf);
     if (fused) {
         if (npf > np) { rc = launch_pad_identity(h, KV, np, npf, ld); if (rc) return rc; }
         rc = launch_rhs_rows(h, KV, n, ld, ymean, ncol, vdiag); if (rc) return rc;
@@ -1192,7 +1217,7 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
         }
     } else {
         rc = launch_neg_log_sum(h, h->logdet_parts, np, h->red); if (rc) return rc;
-        if (!alpha) { fvgp_set_error("loglik without alpha needs ncol free padding rows (n % 128 <= 128 - ncol)"); return -13; }
+        if (!alpha) { fvgp_set_error("loglik without alpha needs ncol free padding rows (n % 128 <= 128 - ncol) or a scratch of fvgp_hip_loglik_dim(n, ncol) rows"); return -14; }
         rc = launch_copy_cols(h, ymean, ncol, alpha, ncol, n, ncol, np, ncol); if (rc) return rc;
         rc = potrs_vec(h, KV, n, ld, alpha, ncol, ncol, true); if (rc) return rc;
         rc = launch_dot_rows(h, ymean, ncol, alpha, ncol, n, ncol, h->red + 1); if (rc) return rc;

@@ -123,8 +123,8 @@ struct fvgp_handle {
     hipEvent_t ev_panel = nullptr, ev_cols = nullptr;
     // profile of the last potrf
     std::vector<hipEvent_t> ev;
-    std::vector<double> ev_flops;
-    double prof_launches = 0, prof_ms = 0, prof_flops = 0, prof_total_ms = 0;
+    std::vector<double> ev_flops, ev_bytes;
+    double prof_launches = 0, prof_ms = 0, prof_flops = 0, prof_total_ms = 0, prof_bytes = 0;
     double prof_host_enqueue_ms = 0;   // row-sharded evaluation: host time to enqueue one evaluation (no synchronisation inside)
     double prof_kmat_ms = 0, prof_kmat_bytes = 0, prof_tail_ms = 0;   // fused evaluation: assembly, everything after the factorisation
     hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -269,4 +269,5 @@ int ensure_linv(fvgp_handle *h, const double *L, int64_t n, int64_t ldl);
 int ensure_scratch(fvgp_handle *h, int64_t np);
 int fvgp_ensure_side(fvgp_handle *h);
 void fvgp_ipc_destroy(fvgp_handle *h);
+int fvgp_ipc_check(fvgp_handle *h);      // 2200 once a poll of the direct collectives has given up (ask AFTER synchronising), else 0
 int fvgp_read_back(fvgp_handle *h, const double *dev, double *host, int count);

@@ -31,6 +31,10 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     const char *(*GetErrorString)(ncclResult_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *);
+    ncclResult_t (*GetVersion)(int *);
     void *lib = nullptr;
 };
 Rccl g_rccl;
@@ -44,6 +48,7 @@ int rccl_open() {
         if (!g_rccl.field) { fvgp_set_error(std::string("librccl lacks ") + name); dlclose(lib); return 2002; } } while (0)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
     SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+    SYM(CommCount, "ncclCommCount"); SYM(CommUserRank, "ncclCommUserRank"); SYM(CommCuDevice, "ncclCommCuDevice"); SYM(GetVersion, "ncclGetVersion");
 #undef SYM
     g_rccl.lib = lib;
     return 0;
@@ -130,7 +135,7 @@ struct HipBackend {
     int to_host(double *dst_host, const double *src, int64_t count) {
         HIPCHK(hipMemcpyAsync(dst_host, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        return 0;
+        return fvgp_ipc_check(h);
     }
     int copy2d(double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int64_t cols) {
         if (rows <= 0 || cols <= 0) return 0;
@@ -225,6 +230,32 @@ int fvgp_hip_comm_init_callbacks(fvgp_handle *h, const fvgp_collectives *cb, int
     h->coll = *cb;
     h->coll_rank = rank; h->coll_nranks = nranks;
     return 0;
+}
+
+int fvgp_hip_comm_info(fvgp_handle *h, int64_t *out8) {
+    if (!h) return -1;
+    if (!out8) return -2;
+    for (int i = 0; i < 8; ++i) out8[i] = -1;
+    out8[0] = h->rccl_comm ? 1 : h->ipc_comm && h->coll.all_gather ? 2 : h->coll.all_gather ? 3 : 0;
+    out8[1] = h->coll_nranks; out8[2] = h->coll_rank;
+    if (h->rccl_comm) {
+        // what the communicator itself says -- not what this library was told
+        int v = -1;
+        ncclResult_t r = g_rccl.CommCount((ncclComm_t)h->rccl_comm, &v); if (r != ncclSuccess) return rccl_fail(r, "ncclCommCount");
+        out8[3] = v;
+        r = g_rccl.CommUserRank((ncclComm_t)h->rccl_comm, &v); if (r != ncclSuccess) return rccl_fail(r, "ncclCommUserRank");
+        out8[4] = v;
+        r = g_rccl.CommCuDevice((ncclComm_t)h->rccl_comm, &v); if (r != ncclSuccess) return rccl_fail(r, "ncclCommCuDevice");
+        out8[5] = v;
+        r = g_rccl.GetVersion(&v); if (r != ncclSuccess) return rccl_fail(r, "ncclGetVersion");
+        out8[6] = v;
+    }
+    return 0;
+}
+
+int fvgp_hip_comm_check(fvgp_handle *h) {
+    if (!h) return -1;
+    return fvgp_ipc_check(h);
 }
 
 int fvgp_hip_all_reduce(fvgp_handle *h, double *buf, int64_t count) {

@@ -19,12 +19,15 @@
 //   3. per peer q, on copy stream q (which first waits for the caller's stream): poll ready[q] >= s, then
 //      hipMemcpyAsync(recv + q count, peer window q [b]); the caller's stream waits for every copy stream's event
 //   4. flag kernel done[r] = s
-// Every poll is bounded (about 20 s): a rank that gives up raises the error word of the flag file, every later poll of any rank
-// returns at once, and the next host-side check reports status 2200 instead of hanging the GPU.
+// Every poll is bounded (60 s; FVGP_IPC_TIMEOUT_S): a rank that gives up raises the error word of the flag file, every later poll of any rank
+// returns at once, and the host-side check behind the next synchronisation (fvgp_ipc_check: every entry that hands results to the
+// host asks it AFTER waiting for the stream) reports status 2200 instead of hanging the GPU or returning what stale windows held.
 // all_reduce = all_gather into a scratch + a sum in rank order (the same bits on every rank, whatever arrives first).
 // Chunks: a call larger than half a window is cut into pieces, each a gather of its own.
 #include "common.h"
+#include <chrono>
 #include <fcntl.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -44,6 +47,7 @@ struct IpcComm {
     void *flags_host = nullptr; size_t flags_bytes = 0; int shm_fd = -1;
     unsigned long long *flags = nullptr;   // device pointer of the registered flag file
     unsigned long long seq = 0;
+    unsigned long long timeout_ticks = 6000000000ull;     // 100 MHz ticks a poll waits before it gives up (FVGP_IPC_TIMEOUT_S, default 60 s)
     hipStream_t copy[MAXR] = {};
     hipEvent_t ev[MAXR] = {}, ev0 = nullptr;
     double *red = nullptr; size_t red_cap = 0;
@@ -57,7 +61,7 @@ __device__ __forceinline__ void sys_store(unsigned long long *p, unsigned long l
 }
 
 // lane q < nranks waits until flags[(base + q) * FL] >= need (lanes with skip == q do not wait); bounded
-__global__ void ipc_poll_kernel(unsigned long long *flags, int base, int nranks, int only, unsigned long long need) {
+__global__ void ipc_poll_kernel(unsigned long long *flags, int base, int nranks, int only, unsigned long long need, unsigned long long timeout_ticks) {
     const int q = threadIdx.x;
     if (q >= nranks || (only >= 0 && q != only)) return;
     const unsigned long long *p = flags + (size_t)(base + q) * FL;
@@ -65,7 +69,7 @@ __global__ void ipc_poll_kernel(unsigned long long *flags, int base, int nranks,
     while ((long long)(sys_load(p) - need) < 0) {
         __builtin_amdgcn_s_sleep(32);
         if (sys_load(flags + (size_t)F_ERR * FL) != 0ull) return;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) { sys_store(flags + (size_t)F_ERR * FL, 1ull + (unsigned long long)q); return; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { sys_store(flags + (size_t)F_ERR * FL, 1ull + (unsigned long long)q); return; }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
@@ -90,7 +94,7 @@ int ipc_gather_chunk(IpcComm *c, const double *send, double *recv, int64_t cnt, 
     const size_t bytes = (size_t)cnt * sizeof(double);
     double *mine = c->win + (size_t)b * c->half_doubles;
     if (s > 2) {
-        hipLaunchKernelGGL(ipc_poll_kernel, dim3(1), dim3(64), 0, stream, c->flags, F_DONE, c->nranks, -1, s - 2);
+        hipLaunchKernelGGL(ipc_poll_kernel, dim3(1), dim3(64), 0, stream, c->flags, F_DONE, c->nranks, -1, s - 2, c->timeout_ticks);
     }
     HIPCHK(hipMemcpyAsync(mine, send, bytes, hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(ipc_flag_kernel, dim3(1), dim3(1), 0, stream, c->flags, F_READY + c->rank, s);
@@ -99,7 +103,7 @@ int ipc_gather_chunk(IpcComm *c, const double *send, double *recv, int64_t cnt, 
     for (int q = 0; q < c->nranks; ++q) {
         if (q == c->rank) continue;
         HIPCHK(hipStreamWaitEvent(c->copy[q], c->ev0, 0));
-        hipLaunchKernelGGL(ipc_poll_kernel, dim3(1), dim3(64), 0, c->copy[q], c->flags, F_READY, c->nranks, q, s);
+        hipLaunchKernelGGL(ipc_poll_kernel, dim3(1), dim3(64), 0, c->copy[q], c->flags, F_READY, c->nranks, q, s, c->timeout_ticks);
         HIPCHK(hipMemcpyAsync(recv + (size_t)q * recv_stride, c->peer[q] + (size_t)b * c->half_doubles, bytes, hipMemcpyDeviceToDevice, c->copy[q]));
         HIPCHK(hipEventRecord(c->ev[q], c->copy[q]));
     }
@@ -112,7 +116,11 @@ int ipc_gather_chunk(IpcComm *c, const double *send, double *recv, int64_t cnt, 
 
 int ipc_check(IpcComm *c) {
     const volatile unsigned long long *err = reinterpret_cast<const volatile unsigned long long *>(c->flags_host) + (size_t)F_ERR * FL;
-    if (*err != 0ull) { fvgp_set_error("ipc collectives: a rank waited longer than 20 s for a peer's flag (rank index + 1 = " + std::to_string(*err) + ")"); return 2200; }
+    if (*err != 0ull) {
+        fvgp_set_error("ipc collectives: a rank gave up waiting for a peer's flag (rank index + 1 = " + std::to_string(*err) +
+                       "); what the collectives since then delivered is stale and the communicator stays unusable: build a new one");
+        return 2200;
+    }
     return 0;
 }
 
@@ -152,11 +160,32 @@ int ipc_all_reduce(void *ctx, double *buf, int64_t count, void *stream) {
 
 }  // namespace
 
+// The error word after the host has waited for the stream: a poll that gives up lets the copies behind it run on stale window
+// contents, so every entry that hands results to the host (fvgp_read_back, fvgp_hip_sync, the _dist entries) asks here AFTER its
+// synchronisation and fails with 2200 instead of returning those results.
+int fvgp_ipc_check(fvgp_handle *h) {
+    IpcComm *c = static_cast<IpcComm *>(h->ipc_comm);
+    if (!c || !c->flags_host) return 0;
+    return ipc_check(c);
+}
+
 void fvgp_ipc_destroy(fvgp_handle *h) {
     IpcComm *c = static_cast<IpcComm *>(h->ipc_comm);
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    if (c->flags_host && c->seq > 0) {
+        // a slower peer may still be pulling gather number seq (or seq - 1) out of this rank's window: done[q] is only awaited two
+        // calls later.  Wait (bounded, on the host) until every peer has pulled the last gather before the window is freed.
+        const volatile unsigned long long *fl = reinterpret_cast<const volatile unsigned long long *>(c->flags_host);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int q = 0; q < c->nranks; ++q) {
+            if (q == c->rank) continue;
+            while ((long long)(fl[(size_t)(F_DONE + q) * FL] - c->seq) < 0 && fl[(size_t)F_ERR * FL] == 0ull &&
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 10.0)
+                usleep(200);
+        }
+    }
     for (int q = 0; q < c->nranks; ++q) {
         if (c->copy[q]) (void)hipStreamDestroy(c->copy[q]);
         if (c->ev[q]) (void)hipEventDestroy(c->ev[q]);
@@ -182,17 +211,19 @@ int fvgp_hip_ipc_window(fvgp_handle *h, int64_t window_bytes, void *out_handle64
     IpcComm *c = new IpcComm();
     c->device = h->device;
     c->half_doubles = (size_t)window_bytes / 2 / sizeof(double);
-    HIPCHK(hipMalloc((void **)&c->win, (size_t)window_bytes));
-    HIPCHK(hipMemset(c->win, 0, (size_t)window_bytes));
+    if (const char *t = getenv("FVGP_IPC_TIMEOUT_S")) { const double sec = atof(t); if (sec >= 1.0 && sec <= 3600.0) c->timeout_ticks = (unsigned long long)(sec * 1e8); }
+    h->ipc_comm = c;                 // owned by the handle from here on: an error below is cleaned up by fvgp_ipc_destroy
     hipIpcMemHandle_t hd;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
-    HIPCHK(hipIpcGetMemHandle(&hd, c->win));
+    hipError_t e = hipMalloc((void **)&c->win, (size_t)window_bytes);
+    if (e == hipSuccess) e = hipMemset(c->win, 0, (size_t)window_bytes);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&hd, c->win);
+    if (e != hipSuccess) { fvgp_ipc_destroy(h); return fvgp_hip_fail(e, "ipc_window: hipMalloc / hipIpcGetMemHandle", __LINE__); }
     memcpy(out_handle64_host, &hd, sizeof(hd));
-    h->ipc_comm = c;
     return 0;
 }
 
-int fvgp_hip_comm_init_ipc(fvgp_handle *h, const void *all_handles64_host, const char *shm_name, int rank, int nranks) {
+static int comm_init_ipc_body(fvgp_handle *h, const void *all_handles64_host, const char *shm_name, int rank, int nranks) {
     if (!h) return -1;
     if (!all_handles64_host) return -2;
     if (!shm_name) return -3;
@@ -224,6 +255,12 @@ int fvgp_hip_comm_init_ipc(fvgp_handle *h, const void *all_handles64_host, const
     h->coll = fvgp_collectives{c, ipc_all_gather, ipc_all_reduce};
     h->coll_rank = rank; h->coll_nranks = nranks;
     return 0;
+}
+
+int fvgp_hip_comm_init_ipc(fvgp_handle *h, const void *all_handles64_host, const char *shm_name, int rank, int nranks) {
+    const int rc = comm_init_ipc_body(h, all_handles64_host, shm_name, rank, nranks);
+    if (rc != 0 && h && h->ipc_comm) fvgp_ipc_destroy(h);        // the window, the flag file's mapping and descriptor, the peers opened so far
+    return rc;
 }
 
 }  // extern "C"

@@ -119,6 +119,12 @@ class HipOps:
     def comm_profile(self):
         return self.H.comm_profile()
 
+    def comm_info(self):
+        return self.H.comm_info()
+
+    def comm_check(self):
+        self.H.comm_check()
+
     def set_option(self, key, value):
         self.H.set_option(key, value)
 
@@ -239,8 +245,12 @@ class ShardedGP:
                 window = int(ipc_window_bytes) if ipc_window_bytes else self._ipc_window_bytes()
                 handle = o.ipc_window(window)
                 if self.P > 1:
-                    handles = [None] * self.P
-                    dist.all_gather_object(handles, handle, group=group)
+                    both = [None] * self.P
+                    dist.all_gather_object(both, (handle, window), group=group)
+                    handles = [b[0] for b in both]
+                    # a peer's half b sits at b * (its window / 2): every rank must have asked for the same window
+                    if len({b[1] for b in both}) != 1:
+                        raise ValueError(f"ipc collectives: the ranks asked for different window sizes {[b[1] for b in both]}")
                     name = [f"/fvgp_ipc_{os.getpid()}_{uuid.uuid4().hex[:12]}" if self.p == 0 else None]
                     dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
                 else:
@@ -297,6 +307,28 @@ class ShardedGP:
         self.keep_factor = True            # False: a likelihood-only evaluation leaves the factored panels out of A (no copy back)
         self.theta = None
         self.alpha = None                  # KVinvY, replicated, (np_, 128) with the first ncol columns in use
+
+    def close(self):
+        """Give the communicator back.  The ranks meet first (a group barrier after every rank's own work has drained): a rank
+        that freed its IPC window or destroyed its RCCL communicator while a slower peer was still pulling from it would pull
+        the rug from under that peer (the library also waits, bounded, for the peers' last pulls)."""
+        o = self.ops
+        if o is None:
+            return
+        if hasattr(o, "host_sync"):
+            o.host_sync()
+        if self.P > 1 and self.dist.is_initialized():
+            try:
+                self.dist.barrier(group=self.group)
+            except Exception:                                   # noqa: BLE001 -- a dead peer must not keep this rank from cleaning up
+                pass
+        if hasattr(o, "close"):
+            o.close()
+        self.ops = None
+
+    def comm_info(self):
+        """the communicator as it reports itself ({"kind": "rccl", "nccl_comm_count": ...}); {} for ops without the query"""
+        return self.ops.comm_info() if hasattr(self.ops, "comm_info") else {}
 
     def _ipc_window_bytes(self):
         """two halves, each large enough for the biggest all-gather piece of an evaluation (a rank's rows of a panel factor), capped at

@@ -92,6 +92,11 @@ class GP(ValidationMixin):
             raise Exception("Noise function and measurement noise provided. Decide which one to use.")
 
         self.args = {} if args is None else args
+        # posterior covariance at many points (gp_posterior.py:229-288): points per device chunk and the cap on the resident L^-1 k
+        # scratch (None: a third of the free device memory), see _posterior_chunked
+        self._posterior_chunk = int(self.args.get("posterior_chunk", 1024))
+        self._posterior_scratch_bytes = self.args.get("posterior_scratch_bytes")
+        self._posterior_groups = 0
         self.compute_device = "gpu"
         self.ram_economy = ram_economy
         # distribution switch (the reference's gp2Scale= / dask_client= constructor flags, gp.py:419-439):
@@ -315,9 +320,16 @@ class GP(ValidationMixin):
         ll = -0.5 * (np.sum(ymean * a) / ymean.shape[1] + logdet + n * np.log(2.0 * np.pi))
         return ll, logdet, m, (V if V2 is None else V2)
 
+    def _eval_dim(self):
+        """rows = columns of the square scratch an evaluation factors in (fvgp_hip_loglik_dim); the factor's own buffer may be larger
+        (append headroom) -- the scratch never is"""
+        ncol = self.y_data.shape[1]
+        return _lib.loglik_dim(self.point_number, ncol) if ncol <= _lib.MAX_RHS_VEC else self._np
+
     def _scratch(self):
         if self._work is None:
-            self._work = self._H.empty(self._ld, self._ld)
+            d = self._eval_dim()
+            self._work = self._H.empty(d, d)
             self._alpha_work = self._H.empty(self._np, self.y_data.shape[1])
         return self._work, self._alpha_work
 
@@ -343,7 +355,7 @@ class GP(ValidationMixin):
             self._KVinv = None
             return
         H, n = self._H, self.point_number
-        inv = self._L.clone()
+        inv = self._L[:self._np, :self._np].clone()              # (the factor's buffer may carry append headroom: not cloned)
         H.invalidate_factor()                                     # `inv` may sit where a freed factor used to be
         work = H.empty(self._np, self._np)
         H.potri(inv, n, work)
@@ -398,6 +410,22 @@ class GP(ValidationMixin):
         self._append_factor(x, y, nv, n_old)
 
     def _append_factor(self, x, y, nv, n_old):
+        """the bordered factor; all or nothing: a failure anywhere (a Schur complement that is not positive definite, a failed
+        device call) leaves the object exactly as it was -- data, factor (its padding rows included) and cached results"""
+        keep = {k: self.__dict__[k] for k in ("x_data", "y_data", "noise_variances", "point_number", "_np", "_ld", "_L", "_x_dev", "_alpha")}
+        touched = []                      # [L_old] once its padding rows have been written
+        try:
+            self._append_factor_body(x, y, nv, n_old, touched)
+        except BaseException:
+            self.__dict__.update(keep)
+            if touched:
+                L_old, n = touched[0], len(x)
+                L_old[n_old:n, :] = 0.0
+                L_old[n_old:n, n_old:n].fill_diagonal_(1.0)           # identity padding again
+                self._H.invalidate_factor()
+            raise
+
+    def _append_factor_body(self, x, y, nv, n_old, touched):
         H, hps, kid = self._H, self._hps, self._native.kernel_id
         L_old, np_old = self._L, self._np
         n, m = len(x), len(x) - n_old
@@ -433,10 +461,12 @@ class GP(ValidationMixin):
         in_place = ld_new <= L_old.shape[0]
         if in_place:
             Lnew, ld_new = L_old, L_old.shape[0]
+            touched.append(L_old)
             Lnew[n_old:n, n_old:] = 0.0                               # (the identity rows of the padding these rows were)
         else:
-            # a factor that has outgrown its buffer once will be appended to again: room for max(256, n / 32) more rows
-            ld_new = _lib.pad128(ld_new + max(256, n // 32))
+            # a factor that has outgrown its buffer once will be appended to again: room for more rows -- max(256, n / 32), at most
+            # 1024 (+2 % of an N = 50k factor, not +6 %); evaluations at a new theta keep a scratch of their own size (_eval_dim)
+            ld_new = _lib.pad128(ld_new + min(max(256, n // 32), 1024))
             Lnew = H.zeros(ld_new, ld_new)
             Lnew[:n_old, :n_old] = L_old[:n_old, :n_old]
             if ld_new > n:
@@ -462,7 +492,7 @@ class GP(ValidationMixin):
         self._loglik = -0.5 * (quad + self._logdet + n * np.log(2.0 * np.pi))
         self.m, self.V = mean, V
         self._K_host = None
-        if not (in_place and self._work is not None and self._work.shape[0] == ld_new and self._alpha_work.shape[0] == np_new):
+        if not (self._work is not None and self._work.shape[0] == self._eval_dim() and self._alpha_work.shape[0] == np_new):
             self._work = self._work2 = self._alpha_work = None    # (kept when the sizes did not change: no reallocation per append)
         self._refresh_inverse()
 
@@ -700,6 +730,8 @@ class GP(ValidationMixin):
             kk = (np.asarray(self._native(x_pred, x_pred, hps)) if self._native is not None
                   else self._host_kernel(x_pred, x_pred, hps))
             return mean_h, kk - k.T @ np.asarray(self._linalg_callables[1](obj, k), dtype=np.float64).reshape(k.shape)
+        if self._native is not None and want_cov and P > self._posterior_chunk:
+            return self._posterior_chunked(x_pred, hps, L, alpha)
         mean = H.empty(P, ncol)
         kx = H.empty(self._np, Pp)
         if self._native is not None:
@@ -723,6 +755,71 @@ class GP(ValidationMixin):
         H.gemm(1, 1, 0, Pp, Pp, self._np, -1.0, kx, kx, 1.0, S)                            # kk - v^T v, v = L^-1 k
         H.sync()
         return mean_h, S[:P, :P].cpu().numpy()
+
+    def _posterior_chunked(self, x_pred, hps, L, alpha):
+        """Posterior mean and covariance at MANY prediction points with bounded device memory (gp_posterior.py:120-136,229-288 form
+        k (N x P), L^-1 k and the P x P result in one piece each).  The points go through the device in chunks of
+        `posterior_chunk` (1024: the sweep's fastest shape): fvgp_hip_posterior per chunk gives its mean, its diagonal block of S and
+        leaves V_i^T = (L^-1 k_i)^T in the chunk's scratch; the off-diagonal blocks are S_ij = k(x_i, x_j) - V_i^T V_j, one MFMA
+        product each, and S is assembled on the host block row by block row (the device never holds more than a chunk x chunk
+        piece of it).  The V_i stay resident while N x P doubles fit `posterior_scratch_bytes` (default: a third of the free device
+        memory); beyond that the chunks are walked in groups and a group's V is recomputed for every earlier group it meets."""
+        H, n, ncol = self._H, self.point_number, self.y_data.shape[1]
+        torch = H.torch
+        P, C, kid = len(x_pred), int(self._posterior_chunk), self._native.kernel_id
+        spans = [(s0, min(s0 + C, P)) for s0 in range(0, P, C)]
+        Cp = _lib.pad128(C)
+        budget = self._posterior_scratch_bytes
+        if budget is None:
+            budget = torch.cuda.mem_get_info(H.device)[0] // 3
+        fit = max(2, int(budget // (self._np * Cp * 8)))                      # chunk scratches that may be resident at once
+        gsz = len(spans) if len(spans) <= fit else max(1, fit // 2)           # chunks per group (two groups resident when walking pairs)
+        groups = [list(range(g0, min(g0 + gsz, len(spans)))) for g0 in range(0, len(spans), gsz)]
+        self._posterior_groups = len(groups)                                  # (diagnostic: 1 = nothing was recomputed)
+        mean_h, S_h = np.empty((P, ncol)), np.empty((P, P))
+        xp_dev = [H.to_device(x_pred[a:b]) for a, b in spans]
+        Sblk, kk = H.empty(Cp, Cp), H.empty(Cp, Cp)
+        mean_d = H.empty(C, ncol)
+        var_d = H.empty(C)
+
+        def sweep(i, buf, first):
+            """buf <- V_i^T (pad128(P_i) x np, leading dimension np); first: also the chunk's mean and diagonal block"""
+            a, b = spans[i]
+            if first:
+                H.posterior(kid, self._x_dev, hps, L, alpha, ncol, xp_dev[i], buf, mean_d, None, Sblk)
+                mean_h[a:b] = mean_d[:b - a].cpu().numpy()
+                S_h[a:b, a:b] = H.to_host(Sblk[:b - a, :b - a])
+            else:
+                H.posterior(kid, self._x_dev, hps, L, alpha, ncol, xp_dev[i], buf, None, var_d, None)
+
+        def cross(i, bi, j, bj):
+            """S[i-rows, j-cols] = k(x_i, x_j) - V_i^T V_j  (i > j), mirrored on the host"""
+            (a, b), (c, e) = spans[i], spans[j]
+            pi, pj = _lib.pad128(b - a), _lib.pad128(e - c)
+            H.kmat(kid, xp_dev[i], xp_dev[j], hps, kk, pad=_lib.PAD_ZERO)
+            H.gemm(0, 0, 0, pi, pj, self._np, -1.0, bi, bj, 1.0, kk)
+            blk = H.to_host(kk[:b - a, :e - c])
+            S_h[a:b, c:e] = blk
+            S_h[c:e, a:b] = blk.T
+
+        bufs_a = {}
+        for ga, grp_a in enumerate(groups):
+            bufs_a = {i: H.empty(self._np * Cp).view(Cp, self._np) for i in grp_a}
+            for i in grp_a:
+                sweep(i, bufs_a[i], True)
+                for j in grp_a:
+                    if j < i:
+                        cross(i, bufs_a[i], j, bufs_a[j])
+            for grp_b in groups[ga + 1:]:
+                for i in grp_b:                                              # a later group's chunks, one scratch at a time
+                    bi = H.empty(self._np * Cp).view(Cp, self._np)
+                    sweep(i, bi, False)
+                    for j in grp_a:
+                        cross(i, bi, j, bufs_a[j])
+                    del bi
+            bufs_a = {}
+        H.sync()
+        return mean_h, S_h
 
     def _variance_from_inverse(self, x_pred):
         H, n = self._H, self.point_number
@@ -1094,6 +1191,8 @@ class GP(ValidationMixin):
             return
         L_host, a_host = st.pop("_L_host"), st.pop("_alpha_host")
         self.__dict__.update(st)
+        for k, v in (("_posterior_chunk", 1024), ("_posterior_scratch_bytes", None), ("_posterior_groups", 0)):
+            self.__dict__.setdefault(k, v)                            # (objects pickled before the chunked posterior)
         self._H = default_handle()
         if self.__dict__.get("_linalg_callables") is not None:       # the user's factor object does not travel: rebuild the state
             self._set_data(self.x_data, self.y_data, self.noise_variances)

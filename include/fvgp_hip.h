@@ -57,9 +57,10 @@ enum fvgp_uplo { FVGP_FULL = 0, FVGP_LOWER = 1 };
 int fvgp_hip_version(void);
 const char *fvgp_hip_last_error_string(void);
 int64_t fvgp_hip_padded_dim(int64_t n);
-/* rows AND columns of the square scratch fvgp_hip_loglik wants for n points and ncol columns of y: padded_dim(n) while that leaves
- * ncol padding rows for the appended (y-m)^T, else 128 more (n a multiple of 128: gp_kv.py:589-593's forward solve then rides in
- * the factorisation for every n).  A scratch of only padded_dim(n) is accepted: the forward solve is then a sweep of its own. */
+/* rows AND columns of the square scratch fvgp_hip_loglik_rows wants for n points and ncol columns of y: padded_dim(n) while that
+ * leaves ncol padding rows for the appended (y-m)^T, else 128 more (n a multiple of 128: gp_kv.py:589-593's forward solve then
+ * rides in the factorisation for every n).  A scratch of only padded_dim(n) rows is accepted: the forward solve is then a sweep of
+ * its own. */
 int64_t fvgp_hip_loglik_dim(int64_t n, int ncol);
 /* device bytes a handle allocates by itself for problems of n points (npred prediction points, 0 = none);
  * every N x N buffer is the caller's (gp_kv.py keeps Chol_factor / KVinvY as attributes the same way) */
@@ -120,6 +121,9 @@ int fvgp_hip_chain_verify_counts(fvgp_handle *h, int64_t *out2_host);
  * out[7] = host milliseconds the last row-sharded evaluation (fvgp_hip_loglik_dist) took to ENQUEUE (no synchronisation inside).
  * out needs 8 doubles. */
 int fvgp_hip_get_profile(fvgp_handle *h, double *out8_host);
+/* the same eight, then out[8] = summed ALGORITHMIC bytes of those trailing-update launches (every C tile read and written once, the
+ * panel's rows read once: what bench.py's roofline.traffic is compared with); out[9..15] reserved (0).  out needs 16 doubles. */
+int fvgp_hip_get_profile_ex(fvgp_handle *h, double *out16_host);
 /* The handle keeps the inverted 128 x 128 diagonal blocks of the LAST factor it produced or solved with, keyed
  * on (pointer, n, ld).  A caller that fills a factor buffer by any other means than fvgp_hip_potrf / _loglik
  * (upload of a pickled factor, bordering update, device-to-device copy: gp_kv.py:462-476,718-765) must call
@@ -209,6 +213,15 @@ int fvgp_hip_all_gather(fvgp_handle *h, const double *send, double *recv, int64_
 /* out[0..1] = calls, out[2..3] = bytes received, out[4..5] = milliseconds on the chain stream of the all_gather /
  * all_reduce calls since the last call of this function (option "profile" on); out needs 6 doubles */
 int fvgp_hip_comm_profile(fvgp_handle *h, double *out6_host);
+/* what the handle's communicator is, as the communicator itself reports it (the reference's analogue: the Dask client's own view of its
+ * workers, gp_prior.py:319-322): out[0] = 0 none / 1 RCCL / 2 direct IPC / 3 caller's callbacks, out[1] = nranks and out[2] = rank as
+ * bound; RCCL only: out[3] = ncclCommCount, out[4] = ncclCommUserRank, out[5] = ncclCommCuDevice, out[6] = ncclGetVersion; -1 where
+ * not applicable.  out needs 8 int64. */
+int fvgp_hip_comm_info(fvgp_handle *h, int64_t *out8_host);
+/* 0, or 2200 once a poll of the direct (IPC) collectives has given up waiting for a peer: everything the collectives delivered since is
+ * stale.  Ask after synchronising; fvgp_hip_sync and every entry that returns host values do (they fail with 2200 instead of
+ * returning results computed from stale windows).  The condition is sticky: destroy the communicator and build a new one. */
+int fvgp_hip_comm_check(fvgp_handle *h);
 
 /* One GP sharded over the ranks.  Every buffer is the caller's (sizes in doubles from fvgp_hip_dist_workspace):
  *   x_all (n, d) and vdiag (n) replicated; zt (128, np): (y-m)^T in the first ncol rows, zeros below;
@@ -268,8 +281,12 @@ int fvgp_hip_syrk_rowshard(fvgp_handle *h, int64_t M, int64_t N, int64_t K, cons
  * loglik: GPMarginalLikelihood.log_likelihood(theta)  gp_marginal_likelihood.py:137-179
  *         = kernel -> addKV -> potrf -> potrs -> logdet -> scalar, nothing leaves HBM.
  *   ymean  (n, ncol) row-major = y - m   (default mean: gp_prior.py:449-458, done by caller)
- *   KV     SQUARE scratch of ld rows and ld columns, ld >= padded_dim(n) (fvgp_hip_loglik_dim(n, ncol) to fuse the forward solve
- *          for every n); holds the factor L of the n x n matrix (identity on the padding) at leading dimension ld on return
+ *   KV     scratch of padded_dim(n) rows at leading dimension ld >= padded_dim(n); holds the factor L of the n x n matrix (identity
+ *          on the padding) on return.  NOTHING below row padded_dim(n) is read or written, whatever ld is (a pitched buffer, a row
+ *          slice of a larger arena): where n leaves fewer than ncol padding rows the forward solve is a sweep of its own.
+ *          fvgp_hip_loglik_rows takes the number of rows the caller really owns: with kv_rows and ld >= fvgp_hip_loglik_dim(n, ncol)
+ *          the appended (y-m)^T rows go into the extra block row and the forward solve is fused for every n (rows
+ *          padded_dim(n) .. kv_rows - 1 are identity padding again on return)
  *   alpha  (padded_dim(n), ncol) receives KVinvY
  *   out_host[0] = log marginal likelihood, [1] = log|KV|, [2] = sum((y-m)*KVinvY)/ncol
  *   vdiag is REQUIRED here (n positive noise variances, gp_likelihood.py:89-110): returns -8 when NULL;
@@ -278,6 +295,10 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
                     const double *theta_host, int ntheta, const double *vdiag,
                     const double *ymean, int ncol, double *KV, int64_t ld,
                     double *alpha, double *out_host, int *info_host);
+int fvgp_hip_loglik_rows(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
+                         const double *theta_host, int ntheta, const double *vdiag,
+                         const double *ymean, int ncol, double *KV, int64_t kv_rows, int64_t ld,
+                         double *alpha, double *out_host, int *info_host);
 
 /* loglik_grad: GPMarginalLikelihood.neg_log_likelihood_gradient  gp_marginal_likelihood.py:224-309
  *   g_i = 1/2 sum_jk (KVinv_jk - b_j b_k) dK_jk/dtheta_i,  b = KVinvY[:,component];

@@ -288,6 +288,14 @@ int fvgp_hip_loglik(fvgp_handle *h, int kernel_id, const double *x, int64_t n, i
     out_host[2] = quad;
     return 0;
 }
+/* the rows the caller owns below padded_dim(n) are not needed on the host (no fused forward solve here): same results */
+int fvgp_hip_loglik_rows(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d, const double *theta, int ntheta,
+                         const double *vdiag, const double *ymean, int ncol, double *KV, int64_t kv_rows, int64_t ld, double *alpha,
+                         double *out_host, int *info_host) {
+    if (KV && n > 0 && kv_rows < pad128(n)) { set_err("loglik: the scratch needs at least padded_dim(n) rows"); return -12; }
+    const int rc = fvgp_hip_loglik(h, kernel_id, x, n, d, theta, ntheta, vdiag, ymean, ncol, KV, ld, alpha, out_host, info_host);
+    return rc <= -12 && rc > -100 ? rc - 1 : rc;
+}
 int fvgp_hip_loglik_grad(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d, const double *theta, int ntheta,
                          const double *alpha, int ncol, int component, double *KV, int64_t ld, double *work, int64_t ldw,
                          double *grad_host) {

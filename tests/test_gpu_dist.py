@@ -261,6 +261,70 @@ def test_bench_multi_rank_line_is_the_sharded_evaluation(tmp_path):
     assert out["replicas"]["value"] > 0 and out["replicas"]["scaling"] == "weak"
 
 
+def test_bench_plain_python_form_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` with NO launcher around it (the form the driver uses): bench.py itself starts the two ranks as
+    children of a parent that never touches the GPU, relays rank 0's ONE JSON line and its exit code.  The line says what the
+    communicator saw (2 ranks), carries the A/B of the two collective backends (the process group's own and the direct IPC pulls, two
+    evaluations each) with the faster one timed, per-collective milliseconds and per-link rates, and agrees with one GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FVGP_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--npoints", "12000", "--backend", "gloo"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and "error" not in out
+    assert out["ranks_seen_by_communicator"] == 2 and out["communicator"]["torch_distributed"]["world_size"] == 2
+    ab = out["collectives_ab"]
+    assert set(ab) == {"torch", "ipc"} and all("ms_per_eval" in r and "error" not in r for r in ab.values()), ab
+    assert abs(ab["torch"]["loglik"] - ab["ipc"]["loglik"]) <= 1e-10 * abs(ab["ipc"]["loglik"])
+    assert out["collectives_chosen"] == min(ab, key=lambda k: ab[k]["ms_per_eval"])
+    assert out["rel_diff_vs_single_gpu"] < 1e-10
+    ag = out["collectives"]["all_gather"]
+    assert ag["bytes_received_per_rank_per_eval"] > 0 and ag["ms_per_call"] > 0 and ag["GBps_per_peer_link"] > 0
+    assert out["roofline"]["launches"] > 0 and 0.0 < out["roofline"]["frac"] < 1.0
+
+
+def test_ipc_collective_that_never_completes_fails_loudly(tmp_path):
+    """A peer that never shows up: the poll of the direct collectives gives up (FVGP_IPC_TIMEOUT_S), the copies behind it have run
+    on stale windows -- and the synchronisation that follows must FAIL with status 2200 (it used to return 0 and hand the
+    stale result to the host; only the NEXT collective noticed)."""
+    code = r'''
+import os, sys, json
+os.environ["FVGP_DEVICE"] = "0"; os.environ["FVGP_IPC_TIMEOUT_S"] = "2"
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from fvgp_amd import _lib
+from fvgp_amd.dist import HipOps
+torch.cuda.set_device(0)
+dist.init_process_group(backend="gloo")
+rank = dist.get_rank()
+o = HipOps(_lib.Handle(0))
+both = [None, None]
+dist.all_gather_object(both, o.ipc_window(1 << 20))
+name = [f"/fvgp_ipc_test_{{os.getpid()}}" if rank == 0 else None]
+dist.broadcast_object_list(name, src=0)
+o.comm_init_ipc(both, name[0], rank, 2)
+dist.barrier()
+if rank == 0:
+    os.unlink("/dev/shm" + name[0])
+    send, recv = o.zeros(1024) + 1.0, o.zeros(2048)
+    o.all_gather(send, recv)                   # rank 1 never calls its side
+    try:
+        o.sync()
+        print('RESULT "no error"')
+    except _lib.HipExtensionError as e:
+        print("RESULT " + json.dumps("2200" if "2200" in str(e) else str(e)))
+dist.barrier()
+o.close()
+dist.destroy_process_group()
+'''
+    out = _spawn(tmp_path, code.format(root=ROOT), 2)
+    assert out == "2200", out
+
+
 def test_bench_line_when_the_sharded_evaluation_raises(tmp_path):
     """bench.py with 2 ranks whose sharded evaluation raises (test hook): the ONE line says value 0.0 + error like the watchdog's,
     the replicas ride along as a side record, the exit code is 4."""
@@ -361,7 +425,7 @@ if rank == 0:
     np.savez({out!r}, lls=np.array(lls), ev=np.array(ev), alpha=gp.alpha[:n, 0].cpu().numpy(), mean=mean, S=S, g=g,
              calls=np.array([prof["all_gather"][0], prof["all_reduce"][0]]), ms=np.array([prof["all_gather"][2], prof["all_reduce"][2]]))
     print("RESULT " + json.dumps(dict(ok=True)))
-gp.ops.close()
+gp.close()
 if {world} > 1:
     dist.destroy_process_group()
 '''

@@ -3,6 +3,7 @@ host-side logic (tile map, index-set transform, MCMC driver, argument rules) -- 
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -298,26 +299,45 @@ def test_user_proposal_distributions_drive_the_mcmc():
         T.ProposalDistribution([0], proposal_dist=3)
 
 
-def test_no_wide_buffer_store_with_a_scalar_offset(tmp_path):
-    """A 16-byte (or 12-byte) buffer store whose data registers the next vector instruction overwrites needs a wait state; the
-    compiler inserts it unless the store carries an SGPR offset (the documented exception of that hazard) -- and on gfx950 such a
-    store was seen going out with the NEW register contents in its last lanes (profiles/r05_store_hazard_chain_verify.txt).
-    No kernel of the library may contain a wide buffer store with a scalar offset register: scan the ISA hipcc generates."""
-    import re
+def test_isa_lint_of_the_built_code_objects():
+    """tools/isa_lint.py over the objects the library was linked from (the Makefile runs the same lint after every link): no 16-byte
+    buffer store with an SGPR offset (the gfx950 store hazard of profiles/r05_store_hazard_chain_verify.txt), a wait state behind
+    every wide store, sc1 on every vector load of the resident panel kernel.  The rules themselves are exercised on hand-written
+    disassembly lines, so a lint that stopped matching anything cannot pass silently."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import glob
+    import isa_lint
+    objs = sorted(glob.glob(os.path.join(ROOT, "fvgp_amd", "csrc", "*.o")))
+    assert objs, "no objects: build() first"
+    bad, seen = isa_lint.lint_objects(objs)
+    assert seen >= 6 and not bad, bad[:5]
+    head = "0000000000001000 <_ZN12_GLOBAL__N_112chain_kernelILb0EEEvNS_9ChainArgsE>:\n"
+    r1 = head + "\tbuffer_store_dwordx4 v[2:5], v77, s[8:11], s70 offen   // 0: 0\n\ts_nop 0\n"
+    r2 = head + "\tbuffer_store_dwordx4 v[2:5], v77, s[8:11], 0 offen offset:16 // 0: 0\n\tv_add_f64 v[4:5], v[10:11], v[12:13] // 0\n"
+    ok2 = head + "\tbuffer_store_dwordx4 v[2:5], v77, s[8:11], 0 offen // 0: 0\n\ts_nop 0\n\tv_add_f64 v[4:5], v[10:11], v[12:13] // 0\n"
+    g2 = head + "\tglobal_store_dwordx4 v[8:9], v[20:23], off sc1 // 0\n\tv_mov_b32_e32 v21, v3 // 0\n"
+    r3 = head + "\tbuffer_load_dwordx4 v[2:5], v77, s[8:11], 0 offen // 0\n"
+    ok3 = head + "\tbuffer_load_dwordx4 v[2:5], v77, s[8:11], 0 offen sc1 // 0\n\tbuffer_load_dword v1, s[4:7], 0 offen sc1 lds // 0\n"
+    assert [b[0] for b in isa_lint.lint_text(r1, "t")] == ["R1"]
+    assert [b[0] for b in isa_lint.lint_text(r2, "t")] == ["R2"]
+    assert [b[0] for b in isa_lint.lint_text(g2, "t")] == ["R2"]
+    assert isa_lint.lint_text(ok2, "t") == [] and isa_lint.lint_text(ok3, "t") == []
+    assert [b[0] for b in isa_lint.lint_text(r3, "t")] == ["R3"]
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """bench.py: `--gpus N` and the number of ranks a launcher started must agree in EVERY combination (WORLD_SIZE=1 with --gpus 8
+    used to run one GPU and print n_gpus = 1); with no launcher and N > 1 bench.py starts the N ranks itself -- here, without a
+    GPU, both ranks refuse loudly and the parent hands their exit code on without printing a line."""
     import subprocess
-    src = os.path.join(ROOT, "fvgp_amd", "csrc")
-    bad = []
-    for f in sorted(os.listdir(src)):
-        if not f.endswith(".hip"):
-            continue
-        text = open(os.path.join(src, f)).read()
-        if "buffer_store" not in text and "leaf_body.h" not in text:
-            continue                                   # no buffer stores in this unit
-        out = tmp_path / (f + ".s")
-        res = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
-                              "-Wno-unused-function", os.path.join(src, f), "-o", str(out)], capture_output=True, text=True)
-        assert res.returncode == 0, res.stderr[-2000:]
-        for line in open(out):
-            if re.search(r"buffer_store_dwordx[34] .*\], s[0-9]+ ", line):
-                bad.append((f, line.strip()))
-    assert not bad, bad[:5]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0"), timeout=300, cwd=ROOT)
+    assert res.returncode != 0 and "must agree" in res.stderr and not res.stdout.strip()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=dict(env, WORLD_SIZE="4", RANK="0"), timeout=300, cwd=ROOT)
+    assert res.returncode != 0 and "must agree" in res.stderr
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert res.returncode != 0 and not [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert res.stderr.count("needs an MI355X") == 2, res.stderr[-2000:]          # one refusal per rank it started

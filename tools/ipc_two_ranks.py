@@ -37,5 +37,5 @@ if dist.get_rank() == 0:
     ref = H.loglik(0, H.to_device(x), th * 1.01, H.to_device(np.full(n, 0.01)), H.to_device((y - y.mean()).reshape(n, 1)), KV, al)[0]
     print(json.dumps({"ranks_on_one_gpu": 2, "n": n, "panel": panel, "evaluation_ms": 1e3 * wall, "rel_diff_vs_single_gpu": abs(ll - ref) / abs(ref),
                       "all_gather": {"calls": prof["all_gather"][0], "bytes_from_peers": prof["all_gather"][1], "ms_on_chain_stream_beside_update": prof["all_gather"][2]}}), flush=True)
-gp.ops.close()
+gp.close()
 dist.destroy_process_group()
