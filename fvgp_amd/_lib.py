@@ -215,7 +215,7 @@ def lib():
     L.fvgp_hip_syrk_rowshard.argtypes = [c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i]
     L.fvgp_hip_debug_tile_map.argtypes = [c_i, c_i, c_i, c_i, c_i, P_i, P_i, c_l]
     L.fvgp_hip_debug_tile_map.restype = c_l
-    L.fvgp_hip_debug_chain_ticket.argtypes = [c_i, c_i, c_i, P_i]
+    L.fvgp_hip_debug_chain_ticket.argtypes = [c_i, c_i, c_i, c_i, P_i]
     L.fvgp_hip_debug_chain_ticket.restype = c_i
     L.fvgp_hip_debug_tile_table.argtypes = [c_i, c_i, c_i, c_i, c_i, P_i, c_l]
     L.fvgp_hip_debug_tile_table.restype = c_l
@@ -285,7 +285,7 @@ class Handle(DistCalls):
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(lib().fvgp_hip_create(ctypes.byref(self._h), self.device, ctypes.c_void_p(stream)), "fvgp_hip_create")
-        for key in ("lookahead", "outer_block", "outer_block_big", "big_threshold", "inner_block", "small_tile_max", "small_tile_max_update", "tile_tables", "block_inverses", "k128_kernels", "leaf_tiles", "leaf_tiles_rows", "panel_recursive", "potri_kminor", "leaf_yield", "chain_yield", "lookahead_min", "posterior_halves", "posterior_block", "outer_block_small", "small_threshold", "panel_chain", "panel_chain_min", "cols_split", "cols_split_rows", "bwd_sweep", "fwd_sweep", "chain_verify", "chain_wide", "wide_block", "wide_block_big", "wide_threshold", "wide_inner", "wide_inner_rows", "chain_sleep_rows", "chain_single_rows"):        # tuning overrides, e.g. FVGP_OUTER_BLOCK=512
+        for key in ("lookahead", "outer_block", "outer_block_big", "big_threshold", "inner_block", "small_tile_max", "small_tile_max_update", "tile_tables", "block_inverses", "k128_kernels", "leaf_tiles", "leaf_tiles_rows", "panel_recursive", "potri_kminor", "leaf_yield", "chain_yield", "lookahead_min", "posterior_halves", "posterior_block", "outer_block_small", "small_threshold", "panel_chain", "panel_chain_min", "cols_split", "cols_split_rows", "bwd_sweep", "fwd_sweep", "chain_verify", "chain_wide", "wide_block", "wide_block_big", "wide_threshold", "wide_inner", "wide_inner_rows", "chain_sleep_rows", "chain_single_rows", "chain_ahead"):        # tuning overrides, e.g. FVGP_OUTER_BLOCK=512
             val = os.environ.get("FVGP_" + key.upper())
             if val is not None:
                 self.set_option(key, int(val))
@@ -312,11 +312,12 @@ class Handle(DistCalls):
         return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=f"cuda:{self.device}")
 
     def to_host(self, t):
-        """Device tensor (a strided view is fine) -> numpy array.  Results of a few MB (a posterior covariance at 1000 points is
-        8 MB) come back through torch's cached PINNED host memory, which the returned array keeps alive: one DMA at the link's
-        rate instead of a staged copy into freshly mapped pages (about 0.4 ms of 8.8 at N=20k, P=1000).  Anything larger takes
-        the ordinary pageable path so that kept results cannot pin host memory without bound."""
-        if t.numel() * t.element_size() > (64 << 20) or t.numel() == 0:
+        """Device tensor (a strided view is fine) -> numpy array.  Results up to 1 GB (a posterior covariance at 1000 points is
+        8 MB, at 4000 points 128 MB) come back through torch's cached PINNED host memory, which the returned array keeps alive:
+        one DMA at the link's rate instead of a staged copy into freshly mapped pages (about 0.4 ms of 8.8 at N=20k, P=1000; 128 MB:
+        3 ms instead of 15).  Anything larger takes the ordinary pageable path so that kept results cannot pin host memory
+        without bound."""
+        if t.numel() * t.element_size() > (1 << 30) or t.numel() == 0:
             return t.cpu().numpy()
         out = self.torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         out.copy_(t, non_blocking=True)

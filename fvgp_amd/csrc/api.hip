@@ -159,6 +159,7 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
     if (!strcmp(key, "panel_chain_min")) { h->panel_chain_min = value; return 0; }
     if (!strcmp(key, "chain_wide")) { h->chain_wide = (int)value; return 0; }
     if (!strcmp(key, "chain_sleep_rows")) { h->chain_sleep_rows = (int)value; return 0; }
+    if (!strcmp(key, "chain_ahead")) { if (value < 0 || value > 8) return -3; h->chain_ahead = (int)value; return 0; }
     if (!strcmp(key, "chain_single_rows")) { h->chain_single_rows = (int)value; return 0; }
     if (!strcmp(key, "wide_block") || !strcmp(key, "wide_block_big")) {
         if (value < TILE || value % TILE || value / TILE > FVGP_CHAIN_MAX_BLOCKS) { fvgp_set_error("wide_block: a multiple of 128, at most 4096"); return -2; }
@@ -1383,6 +1384,16 @@ int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n
             // an XCD (64 workgroup slots) gets ceil(tiles / 8) tiles of every K slice: 36 tiles -> 5 -> 12 slices, not 14
             int64_t split = tiles >= 512 ? 1 : 64 / ((tiles + 7) / 8);
             const int64_t max_split = np / 512 > 0 ? np / 512 : 1;       // at least 512 of K per workgroup
+            if (tiles >= 512) {
+                // more tiles than slots: unsplit, 528 tiles (4096 points) take TWO rounds of 512 for 1.03 rounds of work; s slices per
+                // tile take ceil(tiles s / 512) / s rounds -- the smallest s <= 8 that brings that within 15 % of the work
+                double best = (double)((tiles + 511) / 512);
+                for (int64_t sp = 2; sp <= 8 && sp <= max_split; ++sp) {
+                    const double rounds = (double)((tiles * sp + 511) / 512) / (double)sp;
+                    if (rounds < best * 0.97) { best = rounds; split = sp; }
+                    if (best <= 1.15 * (double)tiles / 512.0) break;
+                }
+            }
             if (split > max_split) split = max_split;
             if (split > 1) {
                 rc = ensure_scratch(h, (split * Pp * Pp + 7) / 8); if (rc) return rc;

@@ -20,10 +20,17 @@
 //   (it waits for row_done[k] = k only), then the solve against L_kk (trsm_sub).  Every resident workgroup holds a slot of the
 //   update there, and a workgroup per block mostly waits.
 //
-// Tickets are dealt in start order, block column after block column ((0,0), (1,0), .. (1,1), (2,1), ..), and a workgroup only
-// ever waits for workgroups with a LOWER ticket -- which have started: nothing depends on dispatch order or on all workgroups
-// being resident together (a 4096-wide panel over 50 000 rows has twelve thousand).  Every wait is bounded (about 3 s): a
-// workgroup that gives up raises the abort word, everybody leaves, and the host reports an error instead of hanging the GPU.
+// Tickets are dealt in START order (one atomic add per workgroup), and a ticket maps to a task by a fixed order in which a workgroup
+// only ever waits for LOWER tickets -- which have started -- or, for the few tasks dealt ahead, for tickets at most a column's worth
+// higher, which start as slots free: nothing depends on dispatch order or on all workgroups being resident together (a 4096-wide
+// panel over 50 000 rows has twelve thousand).  The order: per block column the CRITICAL tasks -- the diagonal block and the two blocks
+// under it, what the chain of leaves runs through -- and the BULK tasks (every other block of the column); the critical tasks of
+// column k + ahead come right before the bulk tasks of column k.  ahead = 0 is plain column order ((0,0), (1,0), .. (1,1), (2,1), ..:
+// the default).  ahead = 3 (option "chain_ahead", measurement only): the block the next leaf waits for has done all but its last
+// products by the time the leaf before it ends, instead of starting them behind the hundreds of blocks of the column before -- the
+// leaves of a tall panel then end 10 % earlier and the launch takes as long as before: it is bound by the products' throughput and by
+// the drain behind the last column's workgroups, not by the chain of leaves (profiles/r06_chain_occupancy_n30000.txt).  Every wait is bounded (about 3 s): a workgroup that gives
+// up raises the abort word, everybody leaves, and the host reports an error instead of hanging the GPU.
 //
 // Who gets the compute unit: two workgroups fit one.  The leaf, the block the next leaf waits for, and the block under it raise the
 // unit's yield counter while they are on the critical path; the early products of the other blocks read that counter once per
@@ -57,13 +64,14 @@ struct ChainArgs {
     int *info; int info_base;
     unsigned long long *flags;        // 16 words (one 128-byte line) apart: ticket, leaf_done, abort, diag_ready[32], row_done[32]
     unsigned long long tick0, tag0;
+    int ahead;                        // block columns the critical tasks are dealt in front of the bulk tasks (chain_ticket_role)
     unsigned long long cols_tag;      // != 0: the block rows below the square wait for flags[F_COLS] to reach it (their part of the trailing update runs beside this launch)
     int *yield;
     int yield_below;                  // the block rows below the square raise their compute unit's yield counter too
     int leaf_preloaded;
     int leaf_factor, leaf_tiles;      // 1, 1 (run-time values: as constants they change the leaf's code, and its register allocation, for the worse)
     unsigned long *leaf_stamps;       // diagnostics (option "leaf_stamps"): phase times of the runner's leaves
-    unsigned long long *stamps; int seq;      // diagnostics (option "chain_stamps"): {launch, code, ticket << 16 | row << 8 | step, 100 MHz time} per event
+    unsigned long long *stamps; int seq;      // diagnostics (option "chain_stamps"): {launch, code, task id << 24 | row << 8 | step, 100 MHz time} per event
     unsigned long long *vhash;        // option "chain_verify" (chain_kernel<true>): payload sums of the hand-offs, see VH_* below
 };
 
@@ -75,19 +83,36 @@ struct ChainArgs {
 constexpr int VH_ROWS = 1024;           // block rows that may have a workgroup per block
 constexpr int VH_ROW = 0, VH_LEAF = VH_ROWS * 32, VH_BAD = VH_LEAF + 32, VH_CHECKS = VH_BAD + 1, VH_WORDS = VH_CHECKS + 1;
 
-// ticket -> role of the resident panel kernel (also replayed on the host: fvgp_hip_debug_chain_ticket).  The first
-// nsq = n n2 - n (n - 1) / 2 tickets are the blocks (row, k), k <= row < n2, of the first n2 block rows, block column after block
-// column: kind 0 = diagonal block (row == k), 1 = block below it.  Later tickets: kind 2, a whole block row (row = n2 + ticket - nsq,
-// then every `stride`-th row).  What a role waits for always has a LOWER ticket:
-//   (row, k), row > k : (row, j) and (k, j) for j < k -- block column j < k --, and the leaf of (k, k), the first ticket of column k;
-//   (k, k)            : (k, j), j < k;      a block row: (k, j) for j < k < n and every leaf.
-__host__ __device__ inline void chain_ticket_role(const int n, const int n2, const int t, int *kind, int *row, int *col) {
-    const int nsq = n * n2 - n * (n - 1) / 2;
-    if (t < nsq) {
-        int k = 0, off = 0;
-        while (t >= off + (n2 - k)) { off += n2 - k; ++k; }
-        *row = k + (t - off); *col = k; *kind = *row == k ? 0 : 1;
-    } else { *kind = 2; *row = n2 + (t - nsq); *col = -1; }
+// ticket -> task of the resident panel kernel (also replayed on the host: fvgp_hip_debug_chain_ticket).  The first
+// nsq = n n2 - n (n - 1) / 2 tickets are the blocks (row, k), k <= row < n2, of the first n2 block rows: kind 0 = diagonal block
+// (row == k), 1 = block below it.  Per block column k the CRITICAL tasks are the diagonal block and rows k + 1 .. k + CHAIN_CRIT, the
+// BULK tasks rows k + CHAIN_CRIT + 1 .. n2 - 1.  Order: critical columns 0 .. ahead, then for k = 0, 1, ..: bulk column k, critical
+// column k + ahead + 1.  Later tickets: kind 2, a whole block row (row = n2 + ticket - nsq, then every `stride`-th row).
+// What a task waits for is always in a column before its own, or the leaf of its own column:
+//   (row, k), row > k : (row, j) and (k, j) for j < k, and the leaf of (k, k);   (k, k): (k, j), j < k;
+//   a block row: (k, j) for j < k < n and every leaf.
+// So a BULK task of column k only waits for lower tickets (every critical task of columns <= k + ahead and every bulk task of the
+// columns before k come first); with ahead = 0 so does a critical task.  A critical task dealt ahead may wait for bulk tickets of
+// the `ahead` columns in between: they start as slots free, and at most (ahead + 1) (CHAIN_CRIT + 1) critical tasks are ahead at any
+// time (tests/test_host_logic.py replays the order with as few as 16 slots).
+constexpr int CHAIN_CRIT = 2;
+__host__ __device__ inline void chain_ticket_role(const int n, const int n2, const int ahead, const int t, int *kind, int *row, int *col) {
+    int pos = t;
+    int kc = 0;                                   // next critical column to place
+    for (int k = -1; k < n; ++k) {
+        if (k >= 0) {                             // bulk column k
+            const int below = n2 - 1 - k, nc = below < CHAIN_CRIT ? below : CHAIN_CRIT, cnt = below - nc;
+            if (pos < cnt) { *col = k; *row = k + nc + 1 + pos; *kind = 1; return; }
+            pos -= cnt;
+        }
+        // critical columns up to k + ahead + 1 (k = -1: columns 0 .. ahead)
+        for (; kc < n && kc <= k + ahead + 1; ++kc) {
+            const int below = n2 - 1 - kc, cnt = 1 + (below < CHAIN_CRIT ? below : CHAIN_CRIT);
+            if (pos < cnt) { *col = kc; *row = kc + pos; *kind = pos == 0 ? 0 : 1; return; }
+            pos -= cnt;
+        }
+    }
+    *kind = 2; *row = n2 + pos; *col = -1;
 }
 
 constexpr int FL = 16;                // 64-bit words between two flags
@@ -107,7 +132,7 @@ __device__ __forceinline__ void chain_stamp(const ChainArgs &g, const int code, 
         const unsigned long long i = atomicAdd(g.stamps, 1ull);
         if (i < (1ull << 20)) {
             unsigned long long *e = g.stamps + 8 + 4 * i;
-            e[0] = (unsigned long long)g.seq; e[1] = (unsigned long long)code; e[2] = ((unsigned long long)t << 16) | ((unsigned long long)row << 8) | (unsigned long long)step;
+            e[0] = (unsigned long long)g.seq; e[1] = (unsigned long long)code; e[2] = ((unsigned long long)t << 24) | ((unsigned long long)row << 8) | (unsigned long long)step;
             e[3] = __builtin_amdgcn_s_memrealtime();
         }
     }
@@ -776,7 +801,7 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
     const int n2 = g.n2;
     const int nsq = n * n2 - n * (n - 1) / 2;
     int bk = 0, brow = 0;
-    if (t < nsq) { int kind; chain_ticket_role(n, n2, t, &kind, &brow, &bk); }
+    if (t < nsq) { int kind; chain_ticket_role(n, n2, g.ahead, t, &kind, &brow, &bk); }
     if (t < nsq && brow != bk) {
         // ---- block (row, k) of the panel below the diagonal: A[row,k] - sum_{j<k} L[row,j] L[k,j]^T, one K = 128 product per
         //      block column j as soon as both operands are published (the sum stays in registers), then the solve against L_kk
@@ -1063,6 +1088,9 @@ int launch_panel_chain(fvgp_handle *h, double *A, int64_t n_valid, int64_t np, i
     if (below > room) below = room;
     const int grid = nsq + below;
     h->chain_tick += (unsigned long long)grid;
+    // option "chain_ahead" (default 0 = plain column order; measured: no gain): alone on the chip (>= 256 slots) the critical tasks are
+    // dealt that many columns in front; never beside an update or with rows below the blocks
+    g.ahead = (h->chain_alone == 1 && n2 == g.rows) ? h->chain_ahead : 0;
     g.vhash = nullptr;
     if (h->chain_verify) {
         // per launch: VH_WORDS checksum words, zeroed on the launch's stream; the counters of all launches add up in the handle's
@@ -1097,10 +1125,10 @@ int chain_verify_counts(fvgp_handle *h, unsigned long long *out2) {
     return 0;
 }
 
-// host-only replay of the panel kernel's ticket -> role map for a panel of n block columns whose first n2 block rows have a workgroup per
-// block (chain_ticket_role): out3 = {kind, block row, block column}
-extern "C" int fvgp_hip_debug_chain_ticket(int n, int n2, int ticket, int *out3) {
-    if (n < 1 || n > FVGP_CHAIN_MAX_BLOCKS || n2 < n || ticket < 0 || !out3) return -1;
-    chain_ticket_role(n, n2, ticket, &out3[0], &out3[1], &out3[2]);
+// host-only replay of the panel kernel's ticket -> task map for a panel of n block columns whose first n2 block rows have a workgroup per
+// block, the critical tasks dealt `ahead` columns in front (chain_ticket_role): out3 = {kind, block row, block column}
+extern "C" int fvgp_hip_debug_chain_ticket(int n, int n2, int ahead, int ticket, int *out3) {
+    if (n < 1 || n > FVGP_CHAIN_MAX_BLOCKS || n2 < n || ahead < 0 || ticket < 0 || !out3) return -1;
+    chain_ticket_role(n, n2, ahead, ticket, &out3[0], &out3[1], &out3[2]);
     return 0;
 }

@@ -105,6 +105,7 @@ struct fvgp_handle {
     // ONE resident kernel alone on the chip + one trailing update; a panel over >= wide_inner_rows rows in sub-panels of wide_inner columns
     int chain_wide = 1; int64_t wide_block = 4096, wide_block_big = 4096, wide_threshold = 1 << 30, wide_inner = 2048, wide_inner_rows = 16384;
     int chain_alone = 1;              // set per factorisation: 1 no update runs beside the panel kernels, 0 look-ahead, 2 the row-sharded driver (a workgroup per block, not alone)
+    int chain_ahead = 0;              // measurement only: alone on the chip, block columns the critical tasks (diagonal block + the two blocks under it) are dealt in front of the bulk tasks (chain.hip; no gain measured)
     int chain_sleep_rows = 96;        // panels of at most this many block rows: early products yield their compute unit to the critical blocks
     int chain_single_rows = 96;       // ... and run one workgroup per compute unit (alone only)
     int chain_verify = 0; unsigned long long *chain_vhash = nullptr;   // option "chain_verify": payload checksums on every hand-off of the resident panel kernel (chain.hip, VH_*)

@@ -94,7 +94,7 @@ class GP(ValidationMixin):
         self.args = {} if args is None else args
         # posterior covariance at many points (gp_posterior.py:229-288): points per device chunk and the cap on the resident L^-1 k
         # scratch (None: a third of the free device memory), see _posterior_chunked
-        self._posterior_chunk = int(self.args.get("posterior_chunk", 1024))
+        self._posterior_chunk = int(self.args.get("posterior_chunk", 4096))
         self._posterior_scratch_bytes = self.args.get("posterior_scratch_bytes")
         self._posterior_groups = 0
         self.compute_device = "gpu"
@@ -759,26 +759,35 @@ class GP(ValidationMixin):
     def _posterior_chunked(self, x_pred, hps, L, alpha):
         """Posterior mean and covariance at MANY prediction points with bounded device memory (gp_posterior.py:120-136,229-288 form
         k (N x P), L^-1 k and the P x P result in one piece each).  The points go through the device in chunks of
-        `posterior_chunk` (1024: the sweep's fastest shape): fvgp_hip_posterior per chunk gives its mean, its diagonal block of S and
-        leaves V_i^T = (L^-1 k_i)^T in the chunk's scratch; the off-diagonal blocks are S_ij = k(x_i, x_j) - V_i^T V_j, one MFMA
-        product each, and S is assembled on the host block row by block row (the device never holds more than a chunk x chunk
-        piece of it).  The V_i stay resident while N x P doubles fit `posterior_scratch_bytes` (default: a third of the free device
-        memory); beyond that the chunks are walked in groups and a group's V is recomputed for every earlier group it meets."""
+        `posterior_chunk` (4096): fvgp_hip_posterior per chunk gives its mean, its diagonal block of S and leaves
+        V_i^T = (L^-1 k_i)^T in the chunk's scratch; the off-diagonal blocks are S_ij = k(x_i, x_j) - V_i^T V_j, one MFMA product
+        each.  S is assembled on the device while P x P doubles fit a third of the budget (one copy to the host at the end), else
+        on the host block by block (the device then never holds more than a chunk x chunk piece of it).  The V_i stay resident
+        while N x P doubles fit `posterior_scratch_bytes` (default: a third of the free device memory); beyond that the chunks
+        are walked in groups and a group's V is recomputed for every earlier group it meets."""
         H, n, ncol = self._H, self.point_number, self.y_data.shape[1]
         torch = H.torch
         P, C, kid = len(x_pred), int(self._posterior_chunk), self._native.kernel_id
+        assert C % 128 == 0 and C >= 128, "posterior_chunk must be a multiple of 128"
         spans = [(s0, min(s0 + C, P)) for s0 in range(0, P, C)]
         Cp = _lib.pad128(C)
+        Pp = _lib.pad128(P)
         budget = self._posterior_scratch_bytes
         if budget is None:
             budget = torch.cuda.mem_get_info(H.device)[0] // 3
-        fit = max(2, int(budget // (self._np * Cp * 8)))                      # chunk scratches that may be resident at once
+        on_device = 8 * Pp * Pp <= budget // 3
+        vbudget = budget - (8 * Pp * Pp if on_device else 2 * 8 * Cp * Cp)
+        fit = max(2, int(vbudget // (self._np * Cp * 8)))                     # chunk scratches that may be resident at once
         gsz = len(spans) if len(spans) <= fit else max(1, fit // 2)           # chunks per group (two groups resident when walking pairs)
         groups = [list(range(g0, min(g0 + gsz, len(spans)))) for g0 in range(0, len(spans), gsz)]
         self._posterior_groups = len(groups)                                  # (diagnostic: 1 = nothing was recomputed)
-        mean_h, S_h = np.empty((P, ncol)), np.empty((P, P))
+        mean_h = np.empty((P, ncol))
+        S_dev = H.empty(Pp, Pp) if on_device else None
+        S_h = None if on_device else np.empty((P, P))
         xp_dev = [H.to_device(x_pred[a:b]) for a, b in spans]
-        Sblk, kk = H.empty(Cp, Cp), H.empty(Cp, Cp)
+        Sblk = kk = None
+        if not on_device:
+            Sblk, kk = H.empty(Cp, Cp), H.empty(Cp, Cp)
         mean_d = H.empty(C, ncol)
         var_d = H.empty(C)
 
@@ -786,23 +795,26 @@ class GP(ValidationMixin):
             """buf <- V_i^T (pad128(P_i) x np, leading dimension np); first: also the chunk's mean and diagonal block"""
             a, b = spans[i]
             if first:
-                H.posterior(kid, self._x_dev, hps, L, alpha, ncol, xp_dev[i], buf, mean_d, None, Sblk)
+                out = S_dev[a:, a:] if on_device else Sblk
+                H.posterior(kid, self._x_dev, hps, L, alpha, ncol, xp_dev[i], buf, mean_d, None, out)
                 mean_h[a:b] = mean_d[:b - a].cpu().numpy()
-                S_h[a:b, a:b] = H.to_host(Sblk[:b - a, :b - a])
+                if not on_device:
+                    S_h[a:b, a:b] = H.to_host(Sblk[:b - a, :b - a])
             else:
                 H.posterior(kid, self._x_dev, hps, L, alpha, ncol, xp_dev[i], buf, None, var_d, None)
 
         def cross(i, bi, j, bj):
-            """S[i-rows, j-cols] = k(x_i, x_j) - V_i^T V_j  (i > j), mirrored on the host"""
+            """S[i-rows, j-cols] = k(x_i, x_j) - V_i^T V_j  (i > j); the upper half is mirrored at the end"""
             (a, b), (c, e) = spans[i], spans[j]
             pi, pj = _lib.pad128(b - a), _lib.pad128(e - c)
-            H.kmat(kid, xp_dev[i], xp_dev[j], hps, kk, pad=_lib.PAD_ZERO)
-            H.gemm(0, 0, 0, pi, pj, self._np, -1.0, bi, bj, 1.0, kk)
-            blk = H.to_host(kk[:b - a, :e - c])
-            S_h[a:b, c:e] = blk
-            S_h[c:e, a:b] = blk.T
+            out = S_dev[a:, c:] if on_device else kk
+            H.kmat(kid, xp_dev[i], xp_dev[j], hps, out, pad=_lib.PAD_ZERO)
+            H.gemm(0, 0, 0, pi, pj, self._np, -1.0, bi, bj, 1.0, out)
+            if not on_device:
+                blk = H.to_host(kk[:b - a, :e - c])
+                S_h[a:b, c:e] = blk
+                S_h[c:e, a:b] = blk.T
 
-        bufs_a = {}
         for ga, grp_a in enumerate(groups):
             bufs_a = {i: H.empty(self._np * Cp).view(Cp, self._np) for i in grp_a}
             for i in grp_a:
@@ -817,7 +829,11 @@ class GP(ValidationMixin):
                     for j in grp_a:
                         cross(i, bi, j, bufs_a[j])
                     del bi
-            bufs_a = {}
+            del bufs_a
+        if on_device:
+            H.symmetrize(S_dev, P)
+            H.sync()
+            return mean_h, H.to_host(S_dev[:P, :P])
         H.sync()
         return mean_h, S_h
 
@@ -1191,7 +1207,7 @@ class GP(ValidationMixin):
             return
         L_host, a_host = st.pop("_L_host"), st.pop("_alpha_host")
         self.__dict__.update(st)
-        for k, v in (("_posterior_chunk", 1024), ("_posterior_scratch_bytes", None), ("_posterior_groups", 0)):
+        for k, v in (("_posterior_chunk", 4096), ("_posterior_scratch_bytes", None), ("_posterior_groups", 0)):
             self.__dict__.setdefault(k, v)                            # (objects pickled before the chunked posterior)
         self._H = default_handle()
         if self.__dict__.get("_linalg_callables") is not None:       # the user's factor object does not travel: rebuild the state

@@ -92,7 +92,9 @@ int fvgp_hip_stream_destroy(void *stream);
  *       per 128 columns ("inner_block" / "panel_recursive": how those split a panel); 2: in the row-sharded driver a workgroup per
  *       block ROW below the square instead of per block) ("order"), "chain_sleep_rows" (96: in panels of at most this many block rows
  *       a block's early products yield their compute unit to a leaf or to the block the next leaf waits for), "chain_single_rows"
- *       (96: such panels run one workgroup per compute unit),
+ *       (96: such panels run one workgroup per compute unit), "chain_ahead" (measurement only, default 0 = plain column order: alone on
+ *       the chip the diagonal block and the two blocks under it of the next block columns are started this many columns ahead of the
+ *       other blocks; the leaves of a tall panel end earlier, the launch does not: profiles/r06_chain_ahead_ab.txt),
  *       "cols_split" (look-ahead schedule; 1: while at most "cols_split_rows" = 8192 rows remain only the next panel's square is
  *       brought up to date before its resident kernel starts; the rows below follow on the main stream and the kernel's block rows
  *       wait for a flag in memory),
@@ -361,11 +363,14 @@ int64_t fvgp_hip_debug_tile_map(int tiles_m, int tiles_n, int lower, int scale, 
  * on XCD b % 8; each XCD gets a contiguous, equally long run of the REAL tiles in super-tile order).  Entries are
  * (tile row << 16) | tile col, or -1; returns the grid size, fills min(grid, cap) entries. */
 int64_t fvgp_hip_debug_tile_table(int tiles_m, int tiles_n, int lower, int scale, int off, int *out, int64_t cap);
-/* host-only: the role a start-order ticket gets in the resident panel kernel (csrc/chain.hip) for a panel of n block columns whose
- * first n2 >= n block rows have a workgroup per 128 x 128 block: out3 = {kind, block row, block column}, kind 0 = diagonal block
- * (updates it, then its leaf), 1 = block below the diagonal (products, then the solve behind the leaf), 2 = a whole block row
- * (column = -1).  tests/test_host_logic.py replays every role's waits on it: a workgroup only ever waits for LOWER tickets. */
-int fvgp_hip_debug_chain_ticket(int n, int n2, int ticket, int *out3);
+/* host-only: the task a start-order ticket gets in the resident panel kernel (csrc/chain.hip) for a panel of n block columns whose first
+ * n2 >= n block rows have a workgroup per 128 x 128 block: out3 = {kind, block row, block column}, kind 0 = diagonal block (updates it,
+ * then its leaf), 1 = block below the diagonal (products, then the solve behind the leaf), 2 = a whole block row (column = -1).
+ * Per block column the diagonal block and the two blocks under it are CRITICAL (the chain of leaves runs through them), the rest BULK;
+ * the critical tasks of column k + ahead are dealt right before the bulk tasks of column k ("chain_ahead").  tests/test_host_logic.py
+ * replays the order: a bulk task only ever waits for LOWER tickets (ahead = 0: every task does), and the order makes progress with as
+ * few as 16 slots. */
+int fvgp_hip_debug_chain_ticket(int n, int n2, int ahead, int ticket, int *out3);
 /* diagnostic: blocks x 256 threads each issue iters x 16 register-only fp64 MFMAs (2048 flop each per wave);
  * out needs blocks*256 doubles.  Gives the sustained fp64 MFMA ceiling of the device. */
 int fvgp_hip_mfma_peak(fvgp_handle *h, double *out, int blocks, int iters);

@@ -659,3 +659,85 @@ def test_repeated_appends_stay_in_the_factor_buffer_until_it_is_full():
             np.testing.assert_allclose(a.neg_log_likelihood_gradient(th), b.neg_log_likelihood_gradient(th), rtol=1e-7, atol=1e-8)
             del b
     assert same_buffer == [True, False, True, True, True]
+
+
+@pytest.mark.parametrize("chunk,budget,groups", [(256, None, 1), (256, 13_900_000, 2), (128, 8 << 20, None)])
+def test_posterior_covariance_in_chunks_of_prediction_points(chunk, budget, groups):
+    """Many prediction points with bounded device memory (gp_posterior.py:120-136,229-288 hold k, L^-1 k and S in one piece): the
+    points go through the device in chunks, the off-diagonal blocks of S are k(x_i, x_j) - V_i^T V_j from the chunks' L^-1 k.  Small
+    chunk sizes stand in for the 4096 of production: S on the device (one group), S on the host with the chunks walked in two groups
+    (a group's L^-1 k recomputed), and a budget so small that every chunk is a group -- against the oracle's one-piece result."""
+    import fvgp_amd
+    rng = np.random.default_rng(77)
+    n, P = 1500, 700
+    x = rng.random((n, 3)); y = np.sin(3 * x.sum(1)) + 0.1 * rng.standard_normal(n)
+    th = np.array([1.2, 0.3, 0.35, 0.4]); nv = np.full(n, 0.01)
+    xp = rng.random((P, 3))
+    args = {"posterior_chunk": chunk}
+    if budget is not None:
+        args["posterior_scratch_bytes"] = budget
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function="rbf_ard", args=args)
+        one = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function="rbf_ard")
+    o = orc.OracleGP(x, y, th, nv, kernel="rbf_ard")
+    got, want = gp.posterior_covariance(xp), o.posterior_covariance(xp)
+    if groups is not None:
+        assert gp._posterior_groups == groups
+    else:
+        assert gp._posterior_groups >= 3
+    assert got["S"].shape == (P, P) and np.array_equal(got["S"], got["S"].T)
+    assert np.max(np.abs(got["S"] - want["S"])) <= 1e-10 * th[0]
+    assert np.max(np.abs(got["v(x)"] - want["v(x)"])) <= 1e-10 * th[0]
+    # the one-piece device call (P below the default chunk) and the chunked one agree far inside the tolerance
+    assert np.max(np.abs(got["S"] - one.posterior_covariance(xp)["S"])) <= 1e-12 * th[0]
+    gn = gp.posterior_covariance(xp, add_noise=True, variance_only=True)
+    np.testing.assert_allclose(gn["v(x)"], o.posterior_covariance(xp, add_noise=True)["v(x)"], rtol=0, atol=1e-10)
+
+
+def test_failed_append_leaves_the_object_as_it_was():
+    """update_gp_data(append=True) is all or nothing (cholesky_update_rank_n raises when the Schur complement is not positive definite,
+    gp_lin_alg.py:1310-1477): after a failure in the middle -- here the factorisation of the Schur complement reports a non-positive
+    pivot -- data, factor (the padding rows it had started to write included) and every cached result are the ones from before."""
+    import fvgp_amd
+    from fvgp_amd.gp_lin_alg import NonPositiveDefiniteError
+    rng = np.random.default_rng(5)
+    n, m = 900, 20
+    x = rng.random((n + m, 3)); y = np.sin(3 * x.sum(1)) + 0.1 * rng.standard_normal(n + m)
+    th = np.array([1.1, 0.3, 0.35, 0.4]); nv = np.full(n + m, 0.01)
+    xp = rng.random((5, 3))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = fvgp_amd.GP(x[:n], y[:n], init_hyperparameters=th, noise_variances=nv[:n], kernel_function="rbf_ard")
+    before = (gp.log_likelihood(), gp.posterior_covariance(xp)["S"].copy(), gp.KVinvY.copy(), gp._L.data_ptr(), gp._L.clone())
+    H = gp._H
+    real_potrf, real_potrs = H.potrf, H.potrs
+    try:
+        H.potrf = lambda S, mm: 3                                    # the Schur complement "is not positive definite"
+        with pytest.raises(NonPositiveDefiniteError):
+            gp.update_gp_data(x[n:], y[n:], noise_variances_new=nv[n:], append=True)
+        H.potrf = real_potrf
+
+        def boom(*a, **k):
+            raise _lib_error("injected failure after the factor's rows were written")
+        from fvgp_amd._lib import HipExtensionError as _lib_error
+        H.potrs = boom                                               # fails AFTER the in-place rows have been written
+        with pytest.raises(_lib_error):
+            gp.update_gp_data(x[n:], y[n:], noise_variances_new=nv[n:], append=True)
+    finally:
+        H.potrf, H.potrs = real_potrf, real_potrs
+    assert gp.point_number == n and len(gp.x_data) == n and len(gp.noise_variances) == n and gp._L.data_ptr() == before[3]
+    assert torch_equal_lower(gp._L, before[4], gp._L.shape[0])
+    assert gp.log_likelihood() == before[0] and np.array_equal(gp.KVinvY, before[2])
+    assert np.max(np.abs(gp.posterior_covariance(xp)["S"] - before[1])) <= 1e-13
+    # ... and the append still works afterwards
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp.update_gp_data(x[n:], y[n:], noise_variances_new=nv[n:], append=True)
+        fresh = fvgp_amd.GP(x, y, init_hyperparameters=th, noise_variances=nv, kernel_function="rbf_ard")
+    np.testing.assert_allclose(gp.log_likelihood(), fresh.log_likelihood(), rtol=1e-10)
+
+
+def torch_equal_lower(a, b, n):
+    import torch
+    return bool(torch.equal(torch.tril(a[:n, :n]), torch.tril(b[:n, :n])))

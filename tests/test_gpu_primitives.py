@@ -293,8 +293,8 @@ def test_kmat_rectangular(H, name, d):
     H.kmat(_lib.KERNEL_IDS[name], H.to_device(x1), H.to_device(x2), theta, K, pad=_lib.PAD_NONE)
     H.sync()
     got = K.cpu().numpy()
-    # K entries within a few ulp of sigma^2
-    assert np.max(np.abs(got - ref)) <= 8 * EPS * theta[0]
+    # K entries within 4 ulp sigma^2 (measured worst over 7.5e6 entries per case: RBF 1.9, Matern-3/2 3.2, Matern-5/2 3.7: profiles/r06_kmat_ulp.txt)
+    assert np.max(np.abs(got - ref)) <= 4 * EPS * theta[0]
     # padded variant with zero fill
     Kp = H.to_device(np.full((384, 256), np.nan))
     H.kmat(_lib.KERNEL_IDS[name], H.to_device(x1), H.to_device(x2), theta, Kp, pad=_lib.PAD_ZERO)
@@ -327,7 +327,7 @@ def test_kmat_nan_and_far_points_follow_numpy(H, name):
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     assert np.all(np.isnan(got[7])) and np.all(np.isnan(got[:, 5]))
     ok = ~np.isnan(ref)
-    assert np.max(np.abs(got[ok] - ref[ok])) <= 8 * EPS * theta[0]
+    assert np.max(np.abs(got[ok] - ref[ok])) <= 4 * EPS * theta[0]
     far = np.zeros_like(ok); far[:, 3] = True; far &= ok
     assert np.all(got[far] == 0.0) and np.all(ref[far] == 0.0)
 
@@ -347,7 +347,7 @@ def test_kmat_lower_padded_with_noise(H, name, d):
     H.sync()
     got = K.cpu().numpy()
     il = np.tril_indices(n)
-    assert np.max(np.abs(got[:n, :n][il] - ref[il])) <= 8 * EPS * theta[0]
+    assert np.max(np.abs(got[:n, :n][il] - ref[il])) <= 4 * EPS * theta[0]
     # padding = identity (lower tiles), and tiles strictly above the block diagonal untouched (NaN)
     assert np.array_equal(np.tril(got[n:, :])[:, :n], np.zeros((384 - n, n)))
     assert np.array_equal(np.diag(got)[n:], np.ones(384 - n))

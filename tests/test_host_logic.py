@@ -89,34 +89,51 @@ def test_gemm_tile_map_covers_each_tile_once(L, case):
 
 
 @pytest.mark.parametrize("n,n2", [(1, 1), (1, 9), (4, 4), (4, 32), (8, 8), (8, 57), (16, 16), (16, 235), (32, 32), (32, 63), (32, 391)])
-def test_panel_kernel_roles_only_wait_for_lower_tickets(L, n, n2):
-    """The resident panel kernel (csrc/chain.hip) deals its roles by a start-order ticket and never needs all workgroups resident: a
-    workgroup may only wait for what a LOWER ticket produces.  Host replay of the ticket -> role map (the function the kernel calls):
-    every block of the first n2 block rows has exactly one ticket, and for every role each thing it waits for -- the blocks left of it
-    in its row and in the row of its column's diagonal block, the leaf of that diagonal block; for a whole block row: every block
-    of the square and every leaf -- has a lower ticket."""
-    nsq = n * n2 - n * (n - 1) // 2
+@pytest.mark.parametrize("ahead,slots", [(0, 1), (3, 16), (3, 512), (8, 40)])
+def test_panel_kernel_ticket_order_makes_progress_and_bulk_tasks_wait_for_lower_tickets_only(L, n, n2, ahead, slots):
+    """The resident panel kernel (csrc/chain.hip) deals its tasks by a start-order ticket and never needs all workgroups resident.  Host
+    replay of the ticket -> task map (the function the kernel calls).  Per block column the diagonal block and the two blocks under it
+    are critical, the rest bulk; the critical tasks of column k + ahead come right before the bulk tasks of column k:
+      * every block of the first n2 block rows has exactly one ticket; later tickets are whole block rows;
+      * everything a BULK task waits for -- the blocks left of it in its row and in the row of its column's diagonal block, that
+        diagonal block's leaf -- has a LOWER ticket (ahead = 0: that holds for every task: plain column order);
+      * with `slots` workgroup slots, a task holding its slot until everything it waits for has completed, the order never stalls
+        (ahead = 3 with 16 slots: at most 12 critical tasks are ever ahead)."""
     out = (ctypes.c_int * 3)()
-    ticket = {}
+    nsq = n * n2 - n * (n - 1) // 2
+    ticket, order = {}, []
     for t in range(nsq + 3):
-        assert L.fvgp_hip_debug_chain_ticket(n, n2, t, out) == 0
+        assert L.fvgp_hip_debug_chain_ticket(n, n2, ahead, t, out) == 0
         kind, row, col = out[0], out[1], out[2]
         if t < nsq:
             assert kind in (0, 1) and 0 <= col < n and col <= row < n2 and (kind == 0) == (row == col)
             assert (row, col) not in ticket
             ticket[(row, col)] = t
+            order.append((row, col))
         else:
             assert kind == 2 and row == n2 + (t - nsq) and col == -1
     assert set(ticket) == {(r, k) for k in range(n) for r in range(k, n2)}
-    for (row, k), t in ticket.items():
+
+    def waits(row, k):
         if row == k:
-            waits = [(k, j) for j in range(k)]                                   # the solved blocks of its row, column by column
-        else:
-            waits = [(row, j) for j in range(k)] + [(k, j) for j in range(k)] + [(k, k)]      # both operands of its products; the leaf
-        for w in waits:
-            assert ticket[w] < t, (n, n2, (row, k), "waits for", w)
-    # a whole block row (tickets >= nsq) waits for blocks of the square and for leaves only
-    assert max(ticket.values()) == nsq - 1
+            return [(k, j) for j in range(k)]                                  # the solved blocks of its row, column by column
+        return [(row, j) for j in range(k)] + [(k, j) for j in range(k)] + [(k, k)]      # both operands of its products; the leaf
+
+    for (row, k), t in ticket.items():
+        if ahead == 0 or row - k > 2:
+            for w in waits(row, k):
+                assert ticket[w] < t, (n, n2, ahead, (row, k), "waits for", w)
+        else:                                                                      # a critical task: at most `ahead` columns in front
+            for w in waits(row, k):
+                assert ticket[w] < t or (w[0] - w[1] > 2 and k - w[1] <= ahead), (n, n2, ahead, (row, k), "waits for", w)
+    done, running, nxt = set(), [], 0
+    while len(done) < nsq:
+        while len(running) < slots and nxt < nsq:
+            running.append(order[nxt]); nxt += 1
+        finished = [t for t in running if all(w in done for w in waits(*t))]
+        assert finished, (n, n2, ahead, slots, "stalled with", running[:6])
+        done.update(finished)
+        running = [t for t in running if t not in finished]
 
 
 @pytest.mark.parametrize("case", [(391, 391, 1), (131, 131, 1), (100, 100, 1), (64, 64, 1), (375, 16, 1), (40, 300, 0),

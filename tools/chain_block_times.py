@@ -27,15 +27,15 @@ cnt = min(int(s[0]), 1 << 20); e = s[8:8 + 4 * cnt].reshape(cnt, 4)
 seqs = np.unique(e[:, 0])
 w = e[e[:, 0] == seqs[which]]
 t0 = w[:, 3].min()
-tk = w[:, 2] >> 16
+tk = w[:, 2] >> 24
 start = {int(a): (b - t0) / 100.0 for a, b in zip(tk[w[:, 1] == 0], w[w[:, 1] == 0][:, 3])}
 rec = {}
 for code, packed, t in zip(w[:, 1], w[:, 2], w[:, 3]):
     if code in (10, 3, 4):
-        rec.setdefault(int(packed >> 16), {})[int(code)] = ((t - t0) / 100.0, int((packed >> 8) & 255), int(packed & 255))
+        rec.setdefault(int(packed >> 24), {})[int(code)] = ((t - t0) / 100.0, int((packed >> 8) & 0xffff), int(packed & 255))
 span = (w[:, 3].max() - t0) / 100.0
 print(f"launch {which}: {len(start)} workgroups, span {span:.0f} us")
-leaf = sorted((r[3], t) for code, p, t in zip(w[:, 1], w[:, 2], w[:, 3]) if code == 2 for r in [((p >> 16), (p >> 8) & 255, p & 255, (t - t0) / 100.0)])
+leaf = sorted((r[3], t) for code, p, t in zip(w[:, 1], w[:, 2], w[:, 3]) if code == 2 for r in [((p >> 24), (p >> 8) & 0xffff, p & 255, (t - t0) / 100.0)])
 print("leaves done at (us):", " ".join(f"{a:.0f}" for a, _ in leaf))
 byk = {}
 for ticket, r in rec.items():

@@ -37,6 +37,6 @@ for q in ([seqs[which]] if which >= 0 else seqs):
         continue
     for row in w:
         code, packed, t = int(row[1]), int(row[2]), (row[3] - t0) / 100.0
-        tk, r, st = packed >> 16, (packed >> 8) & 255, packed & 255
-        if code in (1, 2, 3, 4, 5, 10) or (code in (6, 7, 8, 9) and r == int(w[:, 2].max() >> 8) & 255) or (code == 0 and tk < 12):
+        tk, r, st = packed >> 24, (packed >> 8) & 0xffff, packed & 255
+        if code in (1, 2, 3, 4, 5, 10) or (code in (6, 7, 8, 9) and r == int(w[:, 2].max() >> 8) & 0xffff) or (code == 0 and tk < 12):
             print(f"  {t:9.1f} us  ticket {tk:4d} row {r:3d} step {st:2d}  {names[code]}")
