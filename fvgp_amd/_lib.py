@@ -30,7 +30,7 @@ SYMBOLS = [
     "fvgp_hip_debug_tile_map", "fvgp_hip_debug_tile_table", "fvgp_hip_debug_chain_ticket", "fvgp_hip_invalidate_factor", "fvgp_hip_trsm_lower_t", "fvgp_hip_panel_trsm", "fvgp_hip_panel_potrf_dev", "fvgp_hip_syrk_rowshard",
     "fvgp_hip_grad_trace_cols", "fvgp_hip_comm_unique_id", "fvgp_hip_comm_init", "fvgp_hip_comm_init_callbacks", "fvgp_hip_comm_destroy", "fvgp_hip_ipc_window", "fvgp_hip_comm_init_ipc", "fvgp_hip_all_reduce",
     "fvgp_hip_all_gather", "fvgp_hip_comm_profile", "fvgp_hip_dist_workspace", "fvgp_hip_loglik_dist", "fvgp_hip_dist_scratch", "fvgp_hip_solve_dist",
-    "fvgp_hip_posterior_dist", "fvgp_hip_grad_dist", "fvgp_hip_loglik_rows", "fvgp_hip_get_profile_ex", "fvgp_hip_comm_info", "fvgp_hip_comm_check",
+    "fvgp_hip_posterior_dist", "fvgp_hip_grad_dist", "fvgp_hip_loglik_rows", "fvgp_hip_get_profile_ex", "fvgp_hip_comm_info", "fvgp_hip_comm_check", "fvgp_hip_posterior_prepare",
 ]
 
 
@@ -199,6 +199,7 @@ def lib():
     L.fvgp_hip_grad_trace.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_l, c_p, c_l, c_p, P_d]
     L.fvgp_hip_posterior.argtypes = [c_p, c_i, c_p, c_l, c_i, P_d, c_i, c_p, c_l, c_p, c_i, c_p, c_l,
                                      c_p, c_l, c_p, c_p, c_p, c_l]
+    L.fvgp_hip_posterior_prepare.argtypes = [c_p, c_p, c_l, c_l]
     L.fvgp_hip_gemm.argtypes = [c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l]
     L.fvgp_hip_mfma_selftest.argtypes = [c_p, c_p, c_p, c_p]
     L.fvgp_hip_symmetrize.argtypes = [c_p, c_p, c_l, c_l]
@@ -513,6 +514,10 @@ class Handle(DistCalls):
                                         _ptr(alpha), int(ncol), _ptr(xpred), xpred.shape[0], _ptr(kx), kx.stride(0),
                                         _ptr(mean_out), _ptr(var_out), _ptr(S_out),
                                         0 if S_out is None else S_out.stride(0)), "fvgp_hip_posterior")
+
+    def posterior_prepare(self, L, n):
+        """enqueue the inverted diagonal blocks the posterior's sweep substitutes with (fvgp_hip_posterior_prepare)"""
+        _check(lib().fvgp_hip_posterior_prepare(self._h, _ptr(L), int(n), L.stride(0)), "fvgp_hip_posterior_prepare")
 
     def gemm(self, a_kmajor, b_nmajor, lower, M, N, K, alpha, A, B, beta, C):
         _check(lib().fvgp_hip_gemm(self._h, int(a_kmajor), int(b_nmajor), int(lower), M, N, K, float(alpha),

@@ -1302,6 +1302,17 @@ int fvgp_hip_grad_trace_cols(fvgp_handle *h, int kernel_id, const double *x, int
     return grad_trace_host(h, kernel_id, x, n, d, theta, ntheta, W, ldw, b, ldb, partial, grad_host, col0, ncols);
 }
 
+int fvgp_hip_posterior_prepare(fvgp_handle *h, const double *L, int64_t n, int64_t ldl) {
+    if (!h) return -1;
+    int rc = check_square(L, n, ldl, 2, 3, 4);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->block_inverses || pad128(n) < 2 * TILE) return 0;
+    // what the first fvgp_hip_posterior on this factor would build before its sweep: the inverted diagonal blocks at the width a call
+    // with up to 1024 points takes (enqueue only)
+    return ensure_winv(h, L, n, ldl, h->posterior_block, h->posterior_block);
+}
+
 int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
                        const double *theta, int ntheta, const double *L, int64_t ldl,
                        const double *alpha, int ncol, const double *xpred, int64_t P,

@@ -345,6 +345,10 @@ class GP(ValidationMixin):
             ll, logdet, m, V, _ = self._evaluate_sharded(self._hps, state=True)
         else:
             ll, logdet, m, V = self._evaluate(self._hps, self._L, self._alpha)
+            if self._native is not None and self._linalg_callables is None:
+                # the state changed: what posterior queries on it need is enqueued now (gp_kv.py:404-428 refreshes KVinvY and the
+                # log-det the same way), not in front of the first query's sweep; the host does not wait for it
+                self._H.posterior_prepare(self._L, self.point_number)
         self._loglik, self._logdet, self.m, self.V = ll, logdet, m, V
         self._K_host = None
         self._refresh_inverse()

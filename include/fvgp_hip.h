@@ -336,6 +336,10 @@ int fvgp_hip_grad_trace_cols(fvgp_handle *h, int kernel_id, const double *x, int
  *   mean_out (P, ncol) device  = k^T alpha          (prior mean added by the caller)
  *   S_out (padded_dim(P), lds) device or NULL  = kk - k^T KV^-1 k  (full, symmetric)
  *   var_out (P) device  = diag of the above (unclipped; clipping is gp_posterior.py:248-259, caller side) */
+/* Enqueue what the first fvgp_hip_posterior on a new factor would otherwise do in front of its sweep (the inverted diagonal blocks,
+ * 2.6 ms at N = 20k) -- GPkv._refresh computes what the posterior queries need when the state changes, not at the first query
+ * (gp_kv.py:404-428).  Asynchronous; a no-op where the sweep does not use inverted blocks. */
+int fvgp_hip_posterior_prepare(fvgp_handle *h, const double *L, int64_t n, int64_t ldl);
 int fvgp_hip_posterior(fvgp_handle *h, int kernel_id, const double *x, int64_t n, int d,
                        const double *theta_host, int ntheta, const double *L, int64_t ldl,
                        const double *alpha, int ncol, const double *xpred, int64_t P,

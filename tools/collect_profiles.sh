@@ -1,9 +1,10 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round (run on the GPU box from the repo root): TAG=r02 tools/collect_profiles.sh
-# Kernel trace + stats of the headline command, the two PMC passes for the trailing update's traffic (separate runs:
+# Kernel trace + stats of the headline command, the two PMC passes for the trailing update's traffic and for what the covariance
+# assembly (kmat_kernel) wrote (tools/summarize_profiles.py reads both kernels out of the same passes; separate runs:
 # FETCH_SIZE and WRITE_SIZE do not fit one pass; no tracing next to --pmc), and kernel stats of the C2 / C3 / C5 paths.
 set -o pipefail
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 OUT=gpurun_out/${TAG}_profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

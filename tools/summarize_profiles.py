@@ -9,16 +9,16 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join(ROOT, "gpurun_out", f"{tag}_profiles")
 dst = os.path.join(ROOT, "profiles")
 KERNEL = "gemm_f64_kernel<0, 0, 1>"
 
 
-def counter_sum(path, name):
+def counter_sum(path, name, kernel=KERNEL):
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name:
+        if kernel in r["Kernel_Name"] and r["Counter_Name"] == name:
             tot += float(r["Counter_Value"])
             n += 1
     return tot, n
@@ -50,5 +50,25 @@ if os.path.exists(l2):
     if hit + miss > 0:
         rec["l2_hit_rate"] = hit / (hit + miss)
         rec["l2_note"] = "TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) over the same launches, a third --pmc pass"
+# the covariance assembly (north star: "rocprof HBM GB/s for K-assembly"): what kmat_kernel WROTE, from the same WRITE_SIZE pass, against
+# the algorithmic 4 N (N + 1) B of the lower 128-tiles; its duration from the kernel-trace stats of the headline command
+kw_kb, nk = counter_sum(os.path.join(src, "pmc_write", "write_counter_collection.csv"), "WRITE_SIZE", "kmat_kernel")
+kf_kb, _ = counter_sum(os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE", "kmat_kernel")
+if nk:
+    n = 50000
+    npad = (n + 127) // 128 * 128
+    tiles = (npad // 128) * (npad // 128 + 1) // 2
+    algo = tiles * 128 * 128 * 8.0 + n * 3 * 8.0
+    avg_ns = None
+    for r in csv.DictReader(open(os.path.join(src, "stats", "bench_kernel_stats.csv"))):
+        if "kmat_kernel" in r["Name"]:
+            avg_ns = float(r["AverageNs"])
+    k = {"kernel": "kmat_kernel<0, 3> (N=50000 d=3 RBF, lower 128-tiles + noise on the diagonal)", "launches_counted": nk,
+         "write_bytes_per_launch": kw_kb * 1024.0 / nk, "fetch_bytes_per_launch_corrected_x2": 2.0 * kf_kb * 1024.0 / nk,
+         "algorithmic_bytes_per_launch": algo, "written_over_algorithmic": kw_kb * 1024.0 / nk / algo}
+    if avg_ns:
+        gbs = algo / (avg_ns * 1e-9) / 1e9
+        k.update(avg_launch_ms_rocprof=avg_ns * 1e-6, achieved_GBps=gbs, frac_of_8000_spec=gbs / 8000.0, frac_of_6290_achievable=gbs / 6290.0)
+    rec["k_assembly"] = k
 json.dump(rec, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(rec, indent=1))
