@@ -286,7 +286,7 @@ class Handle(DistCalls):
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(lib().fvgp_hip_create(ctypes.byref(self._h), self.device, ctypes.c_void_p(stream)), "fvgp_hip_create")
-        for key in ("lookahead", "outer_block", "outer_block_big", "big_threshold", "inner_block", "small_tile_max", "small_tile_max_update", "tile_tables", "block_inverses", "k128_kernels", "leaf_tiles", "leaf_tiles_rows", "panel_recursive", "potri_kminor", "leaf_yield", "chain_yield", "lookahead_min", "posterior_halves", "posterior_block", "outer_block_small", "small_threshold", "panel_chain", "panel_chain_min", "cols_split", "cols_split_rows", "bwd_sweep", "fwd_sweep", "chain_verify", "chain_wide", "wide_block", "wide_block_big", "wide_threshold", "wide_inner", "wide_inner_rows", "chain_sleep_rows", "chain_single_rows", "chain_ahead"):        # tuning overrides, e.g. FVGP_OUTER_BLOCK=512
+        for key in ("schedule", "lookahead", "outer_block", "outer_block_big", "big_threshold", "inner_block", "small_tile_max", "small_tile_max_update", "tile_tables", "block_inverses", "k128_kernels", "leaf_tiles", "leaf_tiles_rows", "panel_recursive", "potri_kminor", "leaf_yield", "chain_yield", "lookahead_min", "posterior_halves", "posterior_block", "outer_block_small", "small_threshold", "panel_chain", "panel_chain_min", "cols_split", "cols_split_rows", "bwd_sweep", "fwd_sweep", "chain_verify", "chain_wide", "wide_block", "wide_block_big", "wide_threshold", "wide_inner", "wide_inner_rows", "chain_sleep_rows", "chain_single_rows", "chain_ahead"):        # tuning overrides, e.g. FVGP_OUTER_BLOCK=512
             val = os.environ.get("FVGP_" + key.upper())
             if val is not None:
                 self.set_option(key, int(val))

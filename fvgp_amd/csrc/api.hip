@@ -130,6 +130,15 @@ int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value) {
         h->outer_block = value;
         return 0;
     }
+    if (!strcmp(key, "schedule")) {
+        // THE schedule switch: one of the three factorisation schedules, each with the settings it was tuned with; every other
+        // schedule key below is a measurement knob underneath one of them
+        if (value == 0) { h->chain_wide = 1; h->lookahead_min = (int64_t)1 << 40; h->panel_chain = 1; h->lookahead = 1; }            // wide: 4096-wide panels, each alone on the chip
+        else if (value == 1) { h->chain_wide = 0; h->lookahead_min = 4608; h->panel_chain = 1; h->lookahead = 1; }                  // lookahead: 2048/1024/512 panels, the next one under the update (the row-sharded driver's form)
+        else if (value == 2) { h->chain_wide = 0; h->lookahead_min = 4608; h->panel_chain = 0; h->lookahead = 1; }                  // narrow: the same panels, three launches per 128 columns instead of the resident kernel
+        else { fvgp_set_error("schedule: 0 = wide (default), 1 = lookahead, 2 = narrow"); return -3; }
+        return 0;
+    }
     if (!strcmp(key, "profile")) { h->profile = value ? 1 : 0; return 0; }
     if (!strcmp(key, "lookahead")) { h->lookahead = value ? 1 : 0; return 0; }
     if (!strcmp(key, "outer_block_big")) {

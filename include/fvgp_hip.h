@@ -76,23 +76,32 @@ int fvgp_hip_sync(fvgp_handle *h);
  * the panel chain a few CUs of its own so its small kernels never queue behind the trailing update. */
 int fvgp_hip_stream_create(void **out_stream, int device, int high_priority, const uint32_t *cu_mask, int mask_words);
 int fvgp_hip_stream_destroy(void *stream);
-/* Every key has a default and a test (tests/test_gpu_primitives.py); none changes a result except where noted "order": another,
- * equally valid order of the same sums (LAPACK accuracy either way).
- *   schedule ("order"): by default a matrix is factored in panels of "wide_block" = 4096 columns ("wide_block_big" while more than
- *       "wide_threshold" rows remain), each ONE resident kernel (csrc/chain.hip, a workgroup per 128 x 128 block) ALONE on the chip,
- *       followed by ONE trailing update with K = the panel's width; a panel over at least "wide_inner_rows" = 16384 rows goes in
- *       sub-panels of "wide_inner" = 2048 columns with the update kernel bringing the rest of the panel up to date in between.
- *       "chain_wide" = 0 or "lookahead_min" <= the padded size give the schedule of the earlier rounds instead: panels of
+/* Options.  Three keys are the library's interface; none changes a result except where noted "order": another, equally valid order of
+ * the same sums (LAPACK accuracy either way: dpotrf behind gp_lin_alg.py:245 has no fixed order either).
+ *   "schedule" ("order"): how a matrix is factored.
+ *       0 = wide (default): panels of 4096 columns, each ONE resident kernel (csrc/chain.hip, a workgroup per 128 x 128 block) ALONE on
+ *           the chip, followed by ONE trailing update with K = the panel's width; a panel over at least 16384 rows goes in sub-panels of
+ *           2048 columns with the update kernel bringing the rest of the panel up to date in between;
+ *       1 = lookahead: panels of 2048 / 1024 / 512 columns, the next panel factored on a high-priority side stream under the trailing
+ *           update (the default until round 5; the row-sharded driver still runs its stacked panels this way);
+ *       2 = narrow: the same panels, three launches per 128 columns instead of the resident kernel (panels wider than 4096 columns
+ *           always take this form).
+ *   "profile" (0/1): time the trailing-update launches with HIP events -> fvgp_hip_get_profile.
+ *   "chain_verify" (0/1): checksummed hand-offs of the resident panel kernel, see fvgp_hip_chain_verify_counts.
+ * Everything below is a MEASUREMENT knob underneath one of the schedules -- kept because each has a test
+ * (tests/test_gpu_primitives.py) and a measured A/B behind its default; not an interface, no promise that a key
+ * survives a round:
+ *   wide: "chain_wide" (1), "wide_block" = 4096 ("wide_block_big" while more than "wide_threshold" rows remain), "wide_inner" = 2048 and
+ *       "wide_inner_rows" = 16384 (the sub-panels);
+ *   lookahead / narrow: "lookahead_min" (2^40 = off; padded size from which look-ahead runs, 4608 under schedule 1), "lookahead" (1),
  *       "outer_block" (1024; "outer_block_big" = 2048 while more than "big_threshold" = 24576 rows remain, "outer_block_small" = 512
- *       for the last "small_threshold" = 12288; any multiple of 128, panels wider than 4096 take the launch-per-step chain),
- *       with "lookahead" (1) from "lookahead_min" padded rows on: the next panel factored on a high-priority side stream under
- *       the trailing update ("lookahead_min" defaults to 2^40: off; 4608 was the default until round 5);
+ *       for the last "small_threshold" = 12288; any multiple of 128),
  *   panel chain: "panel_chain" (1: one resident kernel per panel -- in the look-ahead schedule for panels with at least
  *       "panel_chain_min" = 4096 rows below their first column -- and for the row-sharded driver's stacked panel; 0: three launches
  *       per 128 columns ("inner_block" / "panel_recursive": how those split a panel); 2: in the row-sharded driver a workgroup per
  *       block ROW below the square instead of per block) ("order"), "chain_sleep_rows" (96: in panels of at most this many block rows
  *       a block's early products yield their compute unit to a leaf or to the block the next leaf waits for), "chain_single_rows"
- *       (96: such panels run one workgroup per compute unit), "chain_ahead" (measurement only, default 0 = plain column order: alone on
+ *       (96: such panels run one workgroup per compute unit), "chain_ahead" (0 = plain column order: alone on
  *       the chip the diagonal block and the two blocks under it of the next block columns are started this many columns ahead of the
  *       other blocks; the leaves of a tall panel end earlier, the launch does not: profiles/r06_chain_ahead_ab.txt),
  *       "cols_split" (look-ahead schedule; 1: while at most "cols_split_rows" = 8192 rows remain only the next panel's square is
@@ -100,15 +109,14 @@ int fvgp_hip_stream_destroy(void *stream);
  *       wait for a flag in memory),
  *       "leaf_tiles" / "leaf_tiles_rows" / "k128_kernels" / "small_tile_max" / "small_tile_max_update" (kernels of the three-launch
  *       chain) ("order"), "leaf_yield" / "chain_yield" (1: the trailing update's waves sleep while a workgroup of the chain shares
- *       their compute unit; chain_yield 2: also for the resident kernel's rows below the square), "chain_verify" (see
- *       fvgp_hip_chain_verify_counts); "tile_tables" (1: XCD-balanced block -> tile tables instead of the formula map);
+ *       their compute unit; chain_yield 2: also for the resident kernel's rows below the square); "tile_tables" (1: XCD-balanced
+ *       block -> tile tables instead of the formula map);
  *   solves / posterior / gradient: "bwd_sweep" / "fwd_sweep" (1: the backward / forward vector sweep with one right-hand side in
- *       one launch), "block_inverses" (1: the posterior
- *       substitutes with inverted diagonal blocks) ("order"), "posterior_block" (2048 / 1024: width of those blocks up to 1024
- *       prediction points; 1024 beyond) ("order"), "posterior_halves" (1: 512-1024 points as two halves on two streams)
- *       ("order"), "potri_kminor" (1: POTRI on (M,K) x (N,K) products only) ("order");
- *   measurement: "profile" (0/1: time the trailing-update launches with HIP events -> fvgp_hip_get_profile), "chain_stamps" /
- *       "leaf_stamps" (device pointers, 0 = off: in-kernel timestamps of the panel kernel's hand-offs / the leaf's phases). */
+ *       one launch), "block_inverses" (1: the posterior substitutes with inverted diagonal blocks) ("order"), "posterior_block"
+ *       (2048 / 1024: width of those blocks up to 1024 prediction points; 1024 beyond) ("order"), "posterior_halves" (1: 512-1024
+ *       points as two halves on two streams) ("order"), "potri_kminor" (1: POTRI on (M,K) x (N,K) products only) ("order");
+ *   diagnostics: "chain_stamps" / "leaf_stamps" (device pointers, 0 = off: in-kernel timestamps of the panel kernel's hand-offs /
+ *       the leaf's phases). */
 int fvgp_hip_set_option(fvgp_handle *h, const char *key, int64_t value);
 /* Option "chain_verify" (0/1, default 0): every in-launch hand-off of the resident panel kernel (csrc/chain.hip: a solved block row,
  * a factored diagonal block with its tile inverses) carries a checksum of its payload, taken by the producer from what it stores and

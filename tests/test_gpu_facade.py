@@ -661,7 +661,7 @@ def test_repeated_appends_stay_in_the_factor_buffer_until_it_is_full():
     assert same_buffer == [True, False, True, True, True]
 
 
-@pytest.mark.parametrize("chunk,budget,groups", [(256, None, 1), (256, 13_900_000, 2), (128, 8 << 20, None)])
+@pytest.mark.parametrize("chunk,budget,groups", [(256, None, 1), (256, 3 * 256 * 1536 * 8, 3), (128, 8 << 20, None)])
 def test_posterior_covariance_in_chunks_of_prediction_points(chunk, budget, groups):
     """Many prediction points with bounded device memory (gp_posterior.py:120-136,229-288 hold k, L^-1 k and S in one piece): the
     points go through the device in chunks, the off-diagonal blocks of S are k(x_i, x_j) - V_i^T V_j from the chunks' L^-1 k.  Small

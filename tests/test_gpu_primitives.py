@@ -453,7 +453,8 @@ def test_trsm_lower_few_columns_against_a_long_factor(H, n, nrhs):
                                    dict(wide_block=1024, wide_block_big=1024),
                                    dict(wide_block=512, wide_block_big=2048, wide_threshold=1500),
                                    dict(wide_block=2048, wide_block_big=2048, wide_inner=512, wide_inner_rows=0),
-                                   dict(wide_block=4096, wide_block_big=4096, wide_inner=1024, wide_inner_rows=2048)])
+                                   dict(wide_block=4096, wide_block_big=4096, wide_inner=1024, wide_inner_rows=2048),
+                                   dict(schedule=0), dict(schedule=1), dict(schedule=2), dict(schedule=0, chain_ahead=3)])
 def test_potrf_panel_schedules_agree(H, sched):
     """Every panel schedule (regular / wide panels, sub-panels of a third block size, with and without look-ahead; the
     chain's TRSM by the inverted 128-block, by substitution with the 16 x 16 tile inverses, or switching between the two
@@ -493,8 +494,9 @@ def _restore_schedule_defaults(H):
     for k, v in dict(outer_block=1024, outer_block_big=2048, big_threshold=24576, inner_block=512, lookahead=1, leaf_tiles=1,
                      leaf_tiles_rows=4096, panel_recursive=1, panel_chain=1, panel_chain_min=4096, outer_block_small=512,
                      small_threshold=12288, lookahead_min=1 << 40, cols_split=1, cols_split_rows=8192, chain_wide=1, wide_block=4096,
-                     wide_block_big=4096, wide_threshold=1 << 30, wide_inner=2048, wide_inner_rows=16384).items():
+                     wide_block_big=4096, wide_threshold=1 << 30, wide_inner=2048, wide_inner_rows=16384, chain_ahead=0).items():
         H.set_option(k, v)
+    H.set_option("schedule", 0)
 
 
 def test_panels_wider_than_the_resident_kernel_takes(H):
