@@ -733,9 +733,23 @@ static int trsm_fwd_gemm(fvgp_handle *h, const double *L, int64_t n, int64_t ldl
 // the time to partly filled rounds (measured at N = 20k, P = 1000: 7.3 ms for 3.9e11 flops); here every launch is one round.
 // `slots`: the workgroups one launch should bring (512 = the whole chip; 256 when two halves of the rows run side by side on two
 // streams, trsm_fwd_gemm_t below); scratch: trsm_fwd_scratch(rows, slots) doubles.
+// workgroups per output tile of a launch with fewer tiles than slots (split K): s slices take ceil(tiles s / slots) / s rounds of the
+// unsplit tile's time; the floor slots / tiles leaves up to a third of the chip idle (192 tiles: 384 of 512), a larger s in two
+// rounds can beat it (192 tiles x 5 = 960: 0.4 instead of 0.5).  A small charge per slice for the partial sums' traffic.
+static int64_t fill_split(int64_t tiles, int64_t slots) {
+    if (tiles >= slots) return 1;
+    int64_t best = slots / tiles;
+    double cost = 1.0 / (double)best + 0.012 * (double)best;
+    for (int64_t sp = best + 1; sp <= 8; ++sp) {
+        const double c = (double)((tiles * sp + slots - 1) / slots) / (double)sp + 0.012 * (double)sp;
+        if (c < cost - 1e-9) { cost = c; best = sp; }
+    }
+    return best;
+}
+
 static int64_t trsm_fwd_scratch(int64_t rows, int64_t slots, int64_t NB) {
     const int64_t tiles = (rows / TILE) * (NB / TILE);
-    const int64_t want = tiles >= slots ? 1 : slots / tiles;
+    const int64_t want = fill_split(tiles, slots);
     return rows * NB + want * rows * NB;
 }
 
@@ -747,7 +761,7 @@ static int trsm_fwd_gemm_t_block(fvgp_handle *h, const double *L, int64_t n, int
     int rc = 0;
     // scratch: tmp (rows x NB: block J with everything to its left applied) and the split-K partials behind it
     const int64_t tiles = (rows / TILE) * (NB / TILE);
-    const int64_t want = tiles >= slots ? 1 : slots / tiles;              // workgroups per output tile that fill the launch's share of the chip
+    const int64_t want = fill_split(tiles, slots);                       // workgroups per output tile that fill the launch's share of the chip
     const int64_t tmp_d = rows * NB;
     double *tmp = scratch, *ws = scratch + tmp_d;
     {
