@@ -287,6 +287,25 @@ def test_bench_plain_python_form_starts_its_own_ranks(tmp_path):
     assert out["roofline"]["launches"] > 0 and 0.0 < out["roofline"]["frac"] < 1.0
 
 
+def test_bench_keeps_the_completed_backend_when_the_other_hangs(tmp_path):
+    """--collectives auto runs the process group's own collectives through the whole timed region FIRST; if the direct pulls tried after
+    them never return (test hook), the watchdog prints the completed backend's line -- a full measurement, not value 0.0 -- with the
+    hang recorded under collectives_ab, and the run exits 0: one lease on a multi-GPU node is not lost to the experimental backend."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FVGP_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--npoints", "4000", "--backend", "gloo", "--inject-ipc-hang", "--sharded-timeout", "45"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["n_gpus"] == 2 and out["collectives_chosen"] == "torch" and out["steps"] == 2
+    assert "ms_per_eval" in out["collectives_ab"]["torch"] and "did not complete" in out["collectives_ab"]["ipc"]["error"]
+    assert out["rel_diff_vs_single_gpu"] < 1e-10
+
+
 def test_ipc_collective_that_never_completes_fails_loudly(tmp_path):
     """A peer that never shows up: the poll of the direct collectives gives up (FVGP_IPC_TIMEOUT_S), the copies behind it have run
     on stale windows -- and the synchronisation that follows must FAIL with status 2200 (it used to return 0 and hand the
