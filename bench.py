@@ -294,7 +294,7 @@ def config_records():
         del KV
         torch.cuda.empty_cache()
         with _stdout_to_stderr():
-            sh = ShardedGP(x, y, nv, kernel="rbf_ard", panel=1024, rank=0, world=1, force_collectives=True, collectives="rccl")
+            sh = ShardedGP(x, y, nv, kernel="rbf_ard", panel=2048, rank=0, world=1, force_collectives=True, collectives="rccl")
         svals = []
         sharded = best(lambda: svals.append(sh.log_likelihood(th * 1.01)[0]), reps=1)
         # the collectives of ONE more evaluation, timed with events on the chain stream, i.e. beside the rank's trailing update
@@ -308,7 +308,7 @@ def config_records():
         flops = float(n) ** 3 / 3
         out["C4_size_one_gpu"] = {
             "workload": "N=100000 d=3 RBF log_likelihood(theta) on ONE MI355X: fused driver vs the row-sharded driver at one rank "
-                        "(panel buffers, diagonal-block gather and panel all-gather through a one-rank RCCL communicator)",
+                        "(2048-wide panels; panel buffers, diagonal-block gather and panel all-gather through a one-rank RCCL communicator)",
             "fused_ms": fused, "fused_tflops": flops / fused / 1e9, "sharded_world1_rccl_ms": sharded,
             "sharded_world1_rccl_tflops": flops / sharded / 1e9, "bound_ms": 1e3 * flops / peak,
             "rel_diff": abs(vals[-1] - svals[-1]) / abs(vals[-1]),
@@ -322,7 +322,7 @@ def config_records():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from shard_emulate import emulate
-            ms8, _, enq8 = emulate(n, world=8, rank=0, panel=1024, steps=2)
+            ms8, _, enq8 = emulate(n, world=8, rank=0, panel=2048, steps=2)
             out["C4_size_one_gpu"]["p8_rank0_schedule_emulated_ms"] = ms8
             out["C4_size_one_gpu"]["p8_rank_flop_bound_ms"] = 1e3 * flops / 8 / peak
             out["C4_size_one_gpu"]["p8_frac_of_flop_bound"] = (1e3 * flops / 8 / peak) / ms8
@@ -411,6 +411,10 @@ def sharded_main(args, x, y, world, rank, local, dist):
 
 def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d, state):
     import torch
+    # panel width of the row-sharded driver: 2048 from N = 40 000 on -- the per-rank schedule is as fast as with 1024 (emulated:
+    # profiles/r06_shard_emulation.txt: P=8 N=50k 94.2 vs 94.1 ms, N=100k 618 vs 626) and an evaluation issues half as many
+    # collectives, each of which starts 0.34 ms late beside the update
+    panel = args.outer_block or (2048 if n >= 40000 else 1024)
     from fvgp_amd import _lib
     from fvgp_amd.dist import ShardedGP
     # side record + cross-check, measured FIRST (no data-path collective: if the sharded run below hangs on this node, the
@@ -453,7 +457,7 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d, 
 
     def build(kind):
         with _stdout_to_stderr():
-            return ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=args.outer_block or 1024,
+            return ShardedGP(x, y, np.full(n, 0.01), kernel="rbf_ard", panel=panel,
                              rank=None if dist is not None else 0, world=None if dist is not None else 1,
                              force_collectives=force, collectives=kind)
 
@@ -483,7 +487,7 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d, 
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N={n} d={d} RBF(ARD) log_likelihood(theta): K-assembly+noise, Cholesky, forward solve, log-det; "
                                    f"ONE evaluation row-sharded over the GPUs", "n": n, "d": d, "kernel": "rbf_ard",
-                       "parallelism": f"block-cyclic 128-row blocks over {world} GPUs; per {args.outer_block or 1024}-wide panel: all-gather of the "
+                       "parallelism": f"block-cyclic 128-row blocks over {world} GPUs; per {panel}-wide panel: all-gather of the "
                                       f"diagonal block from its owners, RCCL all-gather of the panel factor over xGMI, one panel of look-ahead"},
             "cholesky_tflops": whole, "cholesky_tflops_per_gpu": whole / world,
             "cholesky_frac_of_fp64_mfma_peak": whole / world / PEAK_FP64_MFMA_TFLOPS,

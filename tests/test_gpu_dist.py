@@ -391,6 +391,7 @@ dist.destroy_process_group()
 @pytest.mark.parametrize("world,n,panel,kernel,npred", [
     (4, 3000, 512, "rbf_ard", 150),            # one 128-block per rank and panel: the diagonal block is gathered IN PLACE (dist_driver.h, chain step 1)
     (2, 20000, 1024, "rbf_ard", 200),          # C2's size at the default panel width
+    (3, 9000, 2048, "rbf_ard", 130),           # the width bench.py takes from N = 40 000 on (half as many collectives), three ranks
 ])
 def test_default_panel_shapes_over_gloo_against_the_oracle(tmp_path, world, n, panel, kernel, npred):
     """The row-sharded path at the panel shapes an 8-GPU run takes by default -- 1024-wide panels, and the in-place gather of the
