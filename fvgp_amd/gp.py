@@ -795,17 +795,27 @@ class GP(ValidationMixin):
         mean_d = H.empty(C, ncol)
         var_d = H.empty(C)
 
+        def new_buf():
+            return H.empty(self._np * Cp)                                     # flat: handed over as (np x Pp_i), read back as (Pp_i x np)
+
+        def vt(i, buf):
+            """the chunk's V_i^T as the call left it: pad128(P_i) x np, leading dimension np"""
+            pi = _lib.pad128(spans[i][1] - spans[i][0])
+            return buf[:pi * self._np].view(pi, self._np)
+
         def sweep(i, buf, first):
-            """buf <- V_i^T (pad128(P_i) x np, leading dimension np); first: also the chunk's mean and diagonal block"""
+            """buf <- V_i^T; first: also the chunk's mean and diagonal block"""
             a, b = spans[i]
+            pi = _lib.pad128(b - a)
+            kx = buf[:self._np * pi].view(self._np, pi)                       # the ABI's scratch: padded N x padded P_i
             if first:
                 out = S_dev[a:, a:] if on_device else Sblk
-                H.posterior(kid, self._x_dev, hps, L, alpha, ncol, xp_dev[i], buf, mean_d, None, out)
+                H.posterior(kid, self._x_dev, hps, L, alpha, ncol, xp_dev[i], kx, mean_d, None, out)
                 mean_h[a:b] = mean_d[:b - a].cpu().numpy()
                 if not on_device:
                     S_h[a:b, a:b] = H.to_host(Sblk[:b - a, :b - a])
             else:
-                H.posterior(kid, self._x_dev, hps, L, alpha, ncol, xp_dev[i], buf, None, var_d, None)
+                H.posterior(kid, self._x_dev, hps, L, alpha, ncol, xp_dev[i], kx, None, var_d, None)
 
         def cross(i, bi, j, bj):
             """S[i-rows, j-cols] = k(x_i, x_j) - V_i^T V_j  (i > j); the upper half is mirrored at the end"""
@@ -813,14 +823,14 @@ class GP(ValidationMixin):
             pi, pj = _lib.pad128(b - a), _lib.pad128(e - c)
             out = S_dev[a:, c:] if on_device else kk
             H.kmat(kid, xp_dev[i], xp_dev[j], hps, out, pad=_lib.PAD_ZERO)
-            H.gemm(0, 0, 0, pi, pj, self._np, -1.0, bi, bj, 1.0, out)
+            H.gemm(0, 0, 0, pi, pj, self._np, -1.0, vt(i, bi), vt(j, bj), 1.0, out)
             if not on_device:
                 blk = H.to_host(kk[:b - a, :e - c])
                 S_h[a:b, c:e] = blk
                 S_h[c:e, a:b] = blk.T
 
         for ga, grp_a in enumerate(groups):
-            bufs_a = {i: H.empty(self._np * Cp).view(Cp, self._np) for i in grp_a}
+            bufs_a = {i: new_buf() for i in grp_a}
             for i in grp_a:
                 sweep(i, bufs_a[i], True)
                 for j in grp_a:
@@ -828,7 +838,7 @@ class GP(ValidationMixin):
                         cross(i, bufs_a[i], j, bufs_a[j])
             for grp_b in groups[ga + 1:]:
                 for i in grp_b:                                              # a later group's chunks, one scratch at a time
-                    bi = H.empty(self._np * Cp).view(Cp, self._np)
+                    bi = new_buf()
                     sweep(i, bi, False)
                     for j in grp_a:
                         cross(i, bi, j, bufs_a[j])
