@@ -336,8 +336,10 @@ int fvgp_hip_grad_trace_cols(fvgp_handle *h, int kernel_id, const double *x, int
 
 /* posterior: GPposterior.posterior_mean / posterior_covariance  gp_posterior.py:139-182,229-288
  *   L: factor (padded), alpha: KVinvY (padded_dim(n), ncol)
- *   kx: scratch of padded_dim(n) x ldk doubles with ldk >= padded_dim(P); contents unspecified on return (the cross
- *       covariance and L^-1 k pass through it transposed, padded_dim(P) x padded_dim(n)).  The first call after a new factor
+ *   kx: scratch of padded_dim(n) x ldk doubles with ldk >= padded_dim(P).  On return (P >= 2, var_out or S_out given) its first
+ *       padded_dim(P) x padded_dim(n) doubles hold V^T = (L^-1 k)^T, row-major with leading dimension padded_dim(n): a caller that
+ *       walks many prediction points in chunks builds the off-diagonal blocks S_ij = k(x_i, x_j) - V_i^T V_j from the chunks'
+ *       scratches (fvgp_amd/gp.py _posterior_chunked; gp_posterior.py:120-136).  One point: unspecified.  The first call after a new factor
  *       also inverts its diagonal blocks into the handle (2048 x 2048 up to 1024 points, option "posterior_block"; 1024 x 1024
  *       beyond; fvgp_hip_workspace_bytes counts them).  The block width depends on P and the option only: the same call returns
  *       the same bits whether it is the first on a factor or a later one
