@@ -6,7 +6,10 @@ PROD us, shared between the product-phase workgroups on it), each one runnable o
 the solve behind leaf k (SOLVE us alone, SOLVE2 beside a co-resident product stream).  Diagonal task k: rank-16 updates behind its
 row's solves, then the leaf (LEAF us alone, LEAF2 when it shares the unit with a product stream that does not yield).
 Calibration targets (profiles/r05 + DESIGN section 12): N=30000 first sub-panel (235 x 16 blocks) 2.7 ms with a leaf every ~170 us;
-N=50000 (391 x 16) 4.97 ms.
+N=50000 (391 x 16) 4.97 ms.  The model is OPTIMISTIC (2.07 ms for the 235 x 16 case: it has no slot turnover, no per-call overheads and a
+solve that never competes for the MFMA pipe) but it got the one thing it was built for right before the GPU did: the ticket order
+does not matter for a tall panel (col / sq / crit orders within 2 %), the launch is bound by throughput and by the drain behind the
+last column.  The measured counterpart is tools/chain_occupancy.py (profiles/r06_chain_occupancy_n30000.txt).
 
   python tools/chain_sim.py R n [policy]      policy: col (column-major, shipped), crit<c> (near-diagonal blocks dealt ahead), sq (square first)
 """
