@@ -107,7 +107,7 @@ struct fvgp_handle {
     int chain_alone = 1;              // set per factorisation: 1 no update runs beside the panel kernels, 0 look-ahead, 2 the row-sharded driver (a workgroup per block, not alone)
     int chain_ahead = 0;              // measurement only: alone on the chip, block columns the critical tasks (diagonal block + the two blocks under it) are dealt in front of the bulk tasks (chain.hip; no gain measured)
     int chain_sleep_rows = 96;        // panels of at most this many block rows: early products yield their compute unit to the critical blocks
-    int chain_single_rows = 96;       // ... and run one workgroup per compute unit (alone only)
+    int chain_single_rows = 80;       // panels of at most this many block rows run one workgroup per compute unit (alone only; 96 until round 6: N=12k -2.8 %, N=16k -1.7 %, N=8k -1 %)
     int chain_verify = 0; unsigned long long *chain_vhash = nullptr;   // option "chain_verify": payload checksums on every hand-off of the resident panel kernel (chain.hip, VH_*)
     int cols_split = 1; int64_t cols_split_rows = 8192;   // (potrf_driver: the next panel's square is updated first, the rows below it beside its chain, while at most this many rows remain)
     int64_t panel_chain_min = 4096;   // ... for panels with at least this many rows from their first column down (below that the chain runs alone on the chip and the three launches per step are as fast)

@@ -101,7 +101,7 @@ int fvgp_hip_stream_destroy(void *stream);
  *       per 128 columns ("inner_block" / "panel_recursive": how those split a panel); 2: in the row-sharded driver a workgroup per
  *       block ROW below the square instead of per block) ("order"), "chain_sleep_rows" (96: in panels of at most this many block rows
  *       a block's early products yield their compute unit to a leaf or to the block the next leaf waits for), "chain_single_rows"
- *       (96: such panels run one workgroup per compute unit), "chain_ahead" (0 = plain column order: alone on
+ *       (80: panels of at most this many block rows run one workgroup per compute unit), "chain_ahead" (0 = plain column order: alone on
  *       the chip the diagonal block and the two blocks under it of the next block columns are started this many columns ahead of the
  *       other blocks; the leaves of a tall panel end earlier, the launch does not: profiles/r06_chain_ahead_ab.txt),
  *       "cols_split" (look-ahead schedule; 1: while at most "cols_split_rows" = 8192 rows remain only the next panel's square is
