@@ -488,7 +488,7 @@ def _sharded_body(args, x, y, world, rank, local, dist, sync_all, theta0, n, d, 
             "config": {"workload": f"N={n} d={d} RBF(ARD) log_likelihood(theta): K-assembly+noise, Cholesky, forward solve, log-det; "
                                    f"ONE evaluation row-sharded over the GPUs", "n": n, "d": d, "kernel": "rbf_ard",
                        "parallelism": f"block-cyclic 128-row blocks over {world} GPUs; per {panel}-wide panel: all-gather of the "
-                                      f"diagonal block from its owners, RCCL all-gather of the panel factor over xGMI, one panel of look-ahead"},
+                                      f"diagonal block from its owners, all-gather of the panel factor over xGMI (by: collectives_via), one panel of look-ahead"},
             "cholesky_tflops": whole, "cholesky_tflops_per_gpu": whole / world,
             "cholesky_frac_of_fp64_mfma_peak": whole / world / PEAK_FP64_MFMA_TFLOPS,
             "loglik_last": ll,
