@@ -1,6 +1,6 @@
 """Timeline of ONE launch of the resident panel kernel (chain.hip; diagnostic option "chain_stamps"): when the runner's leaves start and
 end, when the square's block rows publish, when the rows below finish.
-  python tools/chain_timeline.py N [launch_index]"""
+  python tools/chain_timeline.py N [launch_index] [key=value ...]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,6 +8,8 @@ from fvgp_amd import _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 H = _lib.Handle(0)
+for kv in sys.argv[3:]:
+    H.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 rng = np.random.default_rng(20240501)
 x = rng.random((n, 3)); y = np.sin(3 * x.sum(1)) + 0.1 * rng.standard_normal(n)
 xd = H.to_device(x); npad = _lib.pad128(n)
