@@ -166,6 +166,42 @@ __device__ __forceinline__ bool chain_wait(const ChainArgs &g, const int flag, c
     return ok != 0;
 }
 
+// lane 0 polls TWO progress flags at once until both have reached `need`, and hands back how far the SLOWER one has come (its value
+// minus `base`, at most `cap`): the row flags of a block's two operand rows.  One round trip per poll for both flags and one
+// barrier pair, where two chain_waits and a separate reading of both flags cost six barriers and four dependent round trips (5-6 us
+// in front of every product of a block that follows its columns' publication one by one).  -1: the launch is being abandoned.
+__device__ __forceinline__ int chain_wait2(const ChainArgs &g, const int flag_a, const int flag_b, const unsigned long long base, const unsigned long long need,
+                                           const int cap, int *s_ok, const bool relaxed) {
+    if (threadIdx.x == 0) {
+        int it = 0;
+        unsigned long long t0 = 0;
+        const unsigned long long *pa = g.flags + (long)flag_a * FL, *pb = g.flags + (long)flag_b * FL;
+        long long m;
+        for (;;) {
+            const unsigned long long a = flag_load(pa), b = flag_load(pb);
+            const long long da = (long long)(a - base), db = (long long)(b - base);
+            m = da < db ? da : db;
+            if (m >= (long long)(need - base)) break;
+            if (relaxed) __builtin_amdgcn_s_sleep(40); else __builtin_amdgcn_s_sleep(8);
+            if ((++it & 127) == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+                if (t0 == 0) t0 = now;
+                if (now - t0 > 300000000ull || flag_load(g.flags + F_ABORT * FL) == g.tag0) {
+                    flag_store(g.flags + F_ABORT * FL, g.tag0);
+                    atomicCAS(g.info, 0, 0x7fffffff);
+                    m = -1;
+                    break;
+                }
+            }
+        }
+        *s_ok = m < 0 ? -1 : (m > cap ? cap : (int)m);
+    }
+    __syncthreads();
+    const int r = *s_ok;
+    __syncthreads();
+    return r;
+}
+
 // every store of this workgroup has left, then one lane raises the flag
 __device__ __forceinline__ void chain_publish(const ChainArgs &g, const int flag, const unsigned long long value) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -819,18 +855,11 @@ __global__ __launch_bounds__(512, 4) void chain_kernel(ChainArgs g) {
         if (k > 0) {
             load_c_neg(acc, Ar + k * 128, g.lda);      // (before the first wait: the block itself has been final since the last trailing update)
             for (int j = 0; j < k;) {
-                if (!chain_wait(g, F_ROW + row, tag + j + 1, &s_i[1], row != k + 1) || !chain_wait(g, F_ROW + k, tag + j + 1, &s_i[1], row != k + 1)) { if (yslot) atomicAdd(yslot, -1); return; }
                 // every block column already published on both rows goes into ONE product (they are contiguous along K: a workgroup that
-                // starts late -- most do, a tall panel has twenty times more of them than slots -- restarts its K loop once, not per column)
-                if (tid == 0) {
-                    const unsigned long long fa = flag_load(g.flags + (long)(F_ROW + row) * FL) - tag, fb = flag_load(g.flags + (long)(F_ROW + k) * FL) - tag;
-                    unsigned long long m = fa < fb ? fa : fb;
-                    if (m > (unsigned long long)k) m = (unsigned long long)k;
-                    s_i[1] = (int)m;
-                }
-                __syncthreads();
-                int m = s_i[1];
-                __syncthreads();
+                // starts late -- most do, a tall panel has twenty times more of them than slots -- restarts its K loop once, not per column);
+                // both rows' flags in one poll (chain_wait2)
+                int m = chain_wait2(g, F_ROW + row, F_ROW + k, tag, tag + j + 1, k, &s_i[1], row != k + 1);
+                if (m < 0) { if (yslot) atomicAdd(yslot, -1); return; }
                 // the LAST product of a block is what its solve behind leaf k waits for (and with it, one way or another, every later
                 // leaf): from there on this workgroup raises its compute unit's yield counter; the earlier products have whole steps to
                 // spare and sleep wherever a workgroup in that state -- or a leaf -- shares their compute unit.  (Every block right of
